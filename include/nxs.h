@@ -1,0 +1,106 @@
+/*
+ * nxs.h -- query-side C API of the MI355X-native nxsearch ranking engine.
+ *
+ * Drop-in for the query path of the reference's public header
+ * (reference src/core/nxs.h:21-101, docs/c-api.md:113-148): same names,
+ * signatures, ownership and error conventions, so that a program linked
+ * against libnxsearch can be relinked against libnxsearch_gpu.so for
+ * searching an index that the reference (or anything writing the same
+ * on-disk format, src/index/storage.h:13-134) has produced.
+ *
+ * Not provided (out of scope): index creation and
+ * mutation (nxs_index_create/add/remove/destroy), Lua filters.
+ *
+ * Added: nxs_index_search_batch() -- the reference API is one query per call;
+ * a GPU wants many (SURVEY.md 8b last row).
+ */
+#ifndef NXS_GPU_PUBLIC_H
+#define NXS_GPU_PUBLIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t nxs_doc_id_t;			/* nxs.h:21 */
+
+struct nxs;
+typedef struct nxs nxs_t;
+
+nxs_t *		nxs_open(const char *basedir);	/* nxs.h:26, nxs.c:91-133 */
+void		nxs_close(nxs_t *);		/* nxs.h:27 */
+
+/* nxs.h:33-46 -- ABI-frozen codes */
+typedef enum {
+	NXS_ERR_SUCCESS		= 0,
+	NXS_ERR_FATAL,
+	NXS_ERR_SYSTEM,
+	NXS_ERR_INVALID,
+	NXS_ERR_EXISTS,
+	NXS_ERR_MISSING,
+	NXS_ERR_LIMIT,
+} nxs_err_t;
+
+nxs_err_t	nxs_get_error(const nxs_t *, const char **);	/* nxs.h:48 */
+
+/* Parameters (nxs.h:54-67); the query path reads limit / algo / fuzzymatch */
+struct nxs_params;
+typedef struct nxs_params nxs_params_t;
+
+nxs_params_t *	nxs_params_create(void);
+int		nxs_params_set_str(nxs_params_t *, const char *, const char *);
+int		nxs_params_set_uint(nxs_params_t *, const char *, uint64_t);
+int		nxs_params_set_bool(nxs_params_t *, const char *, bool);
+void		nxs_params_release(nxs_params_t *);
+
+/* Index handles (nxs.h:73-85): open/close only */
+struct nxs_index;
+typedef struct nxs_index nxs_index_t;
+
+nxs_index_t *	nxs_index_open(nxs_t *, const char *name);
+void		nxs_index_close(nxs_index_t *);
+
+/* Query and response API (nxs.h:87-101) */
+struct nxs_resp;
+typedef struct nxs_resp nxs_resp_t;
+
+nxs_resp_t *	nxs_index_search(nxs_index_t *, nxs_params_t *,
+		    const char *query, size_t len);
+
+void		nxs_resp_iter_reset(nxs_resp_t *);
+bool		nxs_resp_iter_result(nxs_resp_t *, nxs_doc_id_t *, float *);
+unsigned	nxs_resp_resultcount(const nxs_resp_t *);
+char *		nxs_resp_tojson(nxs_resp_t *, size_t *);
+void		nxs_resp_release(nxs_resp_t *);
+
+/*
+ * Batch entry point (new).  Runs `n` queries with one set of params as one
+ * device batch.  resps[i] receives a response object or NULL if query i
+ * failed (its code/message are then in errs[i]/the nxs_t error slot for the
+ * last failure).  Returns the number of failed queries, or -1 if the batch as
+ * a whole could not run (nxs_get_error() tells why).
+ */
+int		nxs_index_search_batch(nxs_index_t *, nxs_params_t *,
+		    const char *const *queries, size_t n,
+		    nxs_resp_t **resps, nxs_err_t *errs);
+
+/*
+ * Opens an index straight from the two files (no basedir/params.db): the
+ * entry used by the bench and tests for synthetic corpora.  `algo` is the
+ * index default ("BM25" / "TF-IDF"); `lowercase` enables the ASCII part of
+ * the reference's "normalizer" filter for query tokens.
+ */
+nxs_index_t *	nxs_index_open_files(nxs_t *, const char *terms_path,
+		    const char *dtmap_path, const char *algo, bool lowercase);
+
+/* The device-side handle behind an index (see nxs_gpu.h), for benches. */
+struct nxsgpu_index;
+struct nxsgpu_index *nxs_index_device(nxs_index_t *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

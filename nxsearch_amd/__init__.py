@@ -1,0 +1,394 @@
+"""nxsearch_amd -- MI355X-native query/ranking path behind nxsearch's C API.
+
+Thin ctypes binding over ``csrc/libnxsearch_gpu.so`` (C11 host code + HIP
+kernels for gfx950).  The class layout mirrors the reference's Lua binding
+(`nxs.open(basedir)`, `index:search(query, params)`, reference
+src/core/lua.c:341-366) and, underneath, its C API (include/nxs.h).
+
+There is no CPU fallback: importing works anywhere, but opening an index
+without a HIP device raises, and a missing shared library raises on import of
+the binding (`lib()`).
+"""
+import ctypes as C
+import os
+
+__all__ = ["Nxs", "Index", "NxsError", "lib", "build", "LIB_PATH"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libnxsearch_gpu.so")
+SYNTH_PATH = os.path.join(CSRC, "libnxssynth.so")
+
+MAX_TOKENS, MAX_PROG, FAST_K = 32, 256, 64
+TF_IDF, BM25 = 0, 1
+ERR_NAMES = ["SUCCESS", "FATAL", "SYSTEM", "INVALID", "EXISTS", "MISSING", "LIMIT"]
+
+
+class NxsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("NXS_ERR_%s: %s" % (ERR_NAMES[code] if 0 <= code < 7 else code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class GpuQuery(C.Structure):
+    """nxsgpu_query_t (include/nxs_gpu.h)"""
+    _fields_ = [("n_tokens", C.c_uint32),
+                ("term_id", C.c_uint32 * MAX_TOKENS),
+                ("prog_len", C.c_uint32),
+                ("prog", C.c_uint8 * MAX_PROG),
+                ("truth", C.c_uint32 * 8)]
+
+
+class GpuBkNode(C.Structure):
+    """nxsgpu_bknode_t"""
+    _fields_ = [("bitmap", C.c_uint64), ("first_child", C.c_uint32),
+                ("term_id", C.c_uint32), ("str_off", C.c_uint32),
+                ("str_len", C.c_uint16), ("flags", C.c_uint16),
+                ("inl", C.c_uint8 * 8)]
+
+
+class BkImage(C.Structure):
+    """nxs_bkimage_t (csrc/nxs_impl.h)"""
+    _fields_ = [("nodes", C.POINTER(GpuBkNode)), ("n", C.c_uint32),
+                ("depth", C.c_uint32), ("bytes", C.POINTER(C.c_uint8)),
+                ("bytes_len", C.c_uint64)]
+
+
+class GpuResults(C.Structure):
+    """nxsgpu_results_t"""
+    _fields_ = [("n_queries", C.c_uint32), ("counts", C.POINTER(C.c_uint32)),
+                ("offsets", C.POINTER(C.c_uint64)), ("doc_ids", C.POINTER(C.c_uint64)),
+                ("scores", C.POINTER(C.c_float)), ("postings", C.c_uint64),
+                ("candidates", C.c_uint64), ("exact_requeries", C.c_uint32)]
+
+
+class GpuProfile(C.Structure):
+    """nxsgpu_profile_t"""
+    _fields_ = [("launches", C.c_uint64), ("scan_ms", C.c_double),
+                ("replay_ms", C.c_double), ("fuzzy_ms", C.c_double),
+                ("postings", C.c_uint64), ("fuzzy_visits", C.c_uint64)]
+
+
+# every symbol include/nxs.h and include/nxs_gpu.h declare
+NXS_H_SYMBOLS = [
+    "nxs_open", "nxs_close", "nxs_get_error", "nxs_params_create",
+    "nxs_params_set_str", "nxs_params_set_uint", "nxs_params_set_bool",
+    "nxs_params_release", "nxs_index_open", "nxs_index_close",
+    "nxs_index_search", "nxs_resp_iter_reset", "nxs_resp_iter_result",
+    "nxs_resp_resultcount", "nxs_resp_tojson", "nxs_resp_release",
+    "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
+]
+NXS_GPU_H_SYMBOLS = [
+    "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
+    "nxsgpu_index_destroy", "nxsgpu_index_df", "nxsgpu_index_postings",
+    "nxsgpu_index_docs", "nxsgpu_index_first_bad_doc", "nxsgpu_search",
+    "nxsgpu_results_free", "nxsgpu_search_dev", "nxsgpu_fuzzy",
+    "nxsgpu_set_profiling", "nxsgpu_get_profile", "nxsgpu_synchronize",
+]
+
+_lib = None
+
+
+def build():
+    """(Re)build the shared libraries in-tree with make + hipcc."""
+    import subprocess
+    subprocess.run(["make", "-C", CSRC], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    """The loaded libnxsearch_gpu.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `make -C %s` (hipcc, gfx950). "
+            "There is no CPU fallback for the query path." % (LIB_PATH, CSRC))
+    L = C.CDLL(LIB_PATH)
+    vp, cp = C.c_void_p, C.c_char_p
+    L.nxs_open.restype = vp
+    L.nxs_open.argtypes = [cp]
+    L.nxs_close.argtypes = [vp]
+    L.nxs_get_error.restype = C.c_int
+    L.nxs_get_error.argtypes = [vp, C.POINTER(cp)]
+    L.nxs_params_create.restype = vp
+    L.nxs_params_set_str.argtypes = [vp, cp, cp]
+    L.nxs_params_set_uint.argtypes = [vp, cp, C.c_uint64]
+    L.nxs_params_set_bool.argtypes = [vp, cp, C.c_bool]
+    L.nxs_params_release.argtypes = [vp]
+    L.nxs_index_open.restype = vp
+    L.nxs_index_open.argtypes = [vp, cp]
+    L.nxs_index_open_files.restype = vp
+    L.nxs_index_open_files.argtypes = [vp, cp, cp, cp, C.c_bool]
+    L.nxs_index_close.argtypes = [vp]
+    L.nxs_index_device.restype = vp
+    L.nxs_index_device.argtypes = [vp]
+    L.nxs_index_search.restype = vp
+    L.nxs_index_search.argtypes = [vp, vp, cp, C.c_size_t]
+    L.nxs_index_search_batch.restype = C.c_int
+    L.nxs_index_search_batch.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t,
+                                         C.POINTER(vp), C.POINTER(C.c_int)]
+    L.nxs_resp_iter_reset.argtypes = [vp]
+    L.nxs_resp_iter_result.restype = C.c_bool
+    L.nxs_resp_iter_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.nxs_resp_resultcount.restype = C.c_uint
+    L.nxs_resp_resultcount.argtypes = [vp]
+    L.nxs_resp_tojson.restype = vp
+    L.nxs_resp_tojson.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.nxs_resp_release.argtypes = [vp]
+    # device shim
+    L.nxsgpu_device_count.restype = C.c_int
+    L.nxsgpu_last_error.restype = cp
+    L.nxsgpu_index_df.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.nxsgpu_index_postings.restype = C.c_uint64
+    L.nxsgpu_index_postings.argtypes = [vp]
+    L.nxsgpu_index_docs.restype = C.c_uint64
+    L.nxsgpu_index_docs.argtypes = [vp]
+    L.nxsgpu_search.restype = C.c_int
+    L.nxsgpu_search.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(GpuQuery),
+                                C.c_uint32, C.POINTER(GpuResults)]
+    L.nxsgpu_results_free.argtypes = [C.POINTER(GpuResults)]
+    L.nxsgpu_search_dev.restype = C.c_int
+    L.nxsgpu_search_dev.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(GpuQuery),
+                                    C.c_uint32, vp, vp, vp]
+    L.nxsgpu_fuzzy.restype = C.c_int
+    L.nxsgpu_fuzzy.argtypes = [vp, cp, C.POINTER(C.c_uint32), C.c_uint32,
+                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.nxsgpu_set_profiling.argtypes = [vp, C.c_int]
+    L.nxsgpu_get_profile.argtypes = [vp, C.POINTER(GpuProfile), C.c_int]
+    L.nxsgpu_synchronize.argtypes = [vp]
+    # host-only test hooks
+    L.nxs_test_query_repr.restype = vp
+    L.nxs_test_query_repr.argtypes = [cp, C.POINTER(vp)]
+    L.nxs_query_lex.restype = C.c_int
+    L.nxs_query_lex.argtypes = [cp, C.POINTER(C.c_int), C.c_size_t]
+    L.nxs_test_compile.restype = C.c_int
+    L.nxs_test_compile.argtypes = [cp, C.POINTER(cp), C.c_uint32, C.c_bool,
+                                   C.POINTER(GpuQuery), C.POINTER(C.c_int),
+                                   cp, C.c_size_t]
+    L.nxs_test_bk_image.restype = C.c_int
+    L.nxs_test_bk_image.argtypes = [C.POINTER(cp), C.c_uint32, C.POINTER(BkImage)]
+    L.nxs_bk_free.argtypes = [C.POINTER(BkImage)]
+    L.nxs_test_levdist.restype = C.c_int
+    L.nxs_test_levdist.argtypes = [cp, C.c_size_t, cp, C.c_size_t]
+    _lib = L
+    return L
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _take(ptr):
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode("utf-8", "surrogateescape")
+    _libc.free(ptr)
+    return s
+
+
+def _b(s):
+    return s.encode("utf-8", "surrogateescape") if isinstance(s, str) else s
+
+
+class Nxs:
+    """`nxs_t`: a library instance bound to a base directory."""
+
+    def __init__(self, basedir):
+        self._h = lib().nxs_open(os.fsencode(basedir))
+        if not self._h:
+            raise NxsError(2, "nxs_open(%r) failed" % (basedir,))
+
+    def error(self):
+        msg = C.c_char_p()
+        code = lib().nxs_get_error(self._h, C.byref(msg))
+        return code, (msg.value or b"").decode("utf-8", "replace")
+
+    def _raise(self):
+        raise NxsError(*self.error())
+
+    def open_index(self, name):
+        h = lib().nxs_index_open(self._h, _b(name))
+        if not h:
+            self._raise()
+        return Index(self, h)
+
+    def open_files(self, terms_path, dtmap_path, algo="BM25", lowercase=False):
+        h = lib().nxs_index_open_files(self._h, os.fsencode(terms_path),
+                                       os.fsencode(dtmap_path), _b(algo), lowercase)
+        if not h:
+            self._raise()
+        return Index(self, h)
+
+    def close(self):
+        if self._h:
+            lib().nxs_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def _make_params(limit=None, algo=None, fuzzymatch=None):
+    if limit is None and algo is None and fuzzymatch is None:
+        return None
+    L = lib()
+    p = L.nxs_params_create()
+    if limit is not None:
+        L.nxs_params_set_uint(p, b"limit", limit)
+    if algo is not None:
+        L.nxs_params_set_str(p, b"algo", _b(algo))
+    if fuzzymatch is not None:
+        L.nxs_params_set_bool(p, b"fuzzymatch", bool(fuzzymatch))
+    return p
+
+
+def _drain(resp):
+    L = lib()
+    out = []
+    d, s = C.c_uint64(), C.c_float()
+    L.nxs_resp_iter_reset(resp)
+    while L.nxs_resp_iter_result(resp, C.byref(d), C.byref(s)):
+        out.append((d.value, s.value))
+    assert len(out) == L.nxs_resp_resultcount(resp)
+    return out
+
+
+class Index:
+    """`nxs_index_t` opened for searching on the GPU."""
+
+    def __init__(self, nxs, h):
+        self.nxs = nxs
+        self._h = h
+
+    @property
+    def device(self):
+        return lib().nxs_index_device(self._h)
+
+    def search(self, query, limit=None, algo=None, fuzzymatch=None, json=False):
+        """nxs_index_search(): -> [(doc_id, score), ...] (or the JSON text)."""
+        L = lib()
+        p = _make_params(limit, algo, fuzzymatch)
+        q = _b(query)
+        try:
+            resp = L.nxs_index_search(self._h, p, q, len(q))
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        if not resp:
+            self.nxs._raise()
+        try:
+            if json:
+                n = C.c_size_t()
+                return _take(L.nxs_resp_tojson(resp, C.byref(n)))
+            return _drain(resp)
+        finally:
+            L.nxs_resp_release(resp)
+
+    def search_batch(self, queries, limit=None, algo=None, fuzzymatch=None):
+        """nxs_index_search_batch(): list of result lists; a failed query
+        yields an NxsError instance in its slot."""
+        L = lib()
+        n = len(queries)
+        qs = (C.c_char_p * n)(*[_b(q) for q in queries])
+        resps = (C.c_void_p * n)()
+        errs = (C.c_int * n)()
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            r = L.nxs_index_search_batch(self._h, p, qs, n, resps, errs)
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        if r < 0:
+            self.nxs._raise()
+        out = []
+        for i in range(n):
+            if resps[i]:
+                out.append(_drain(resps[i]))
+                L.nxs_resp_release(resps[i])
+            else:
+                out.append(NxsError(errs[i], "query %d failed" % i))
+        return out
+
+    def fuzzy(self, tokens, want_visited=False):
+        """Device BK-tree search for raw tokens -> term ids (0 = none)."""
+        L = lib()
+        toks = [_b(t) for t in tokens]
+        blob = b"".join(toks)
+        offs = [0]
+        for t in toks:
+            offs.append(offs[-1] + len(t))
+        n = len(toks)
+        ids = (C.c_uint32 * max(n, 1))()
+        vis = (C.c_uint64 * max(n, 1))() if want_visited else None
+        r = L.nxsgpu_fuzzy(self.device, blob, (C.c_uint32 * (n + 1))(*offs), n, ids, vis)
+        if r != 0:
+            raise NxsError(1, L.nxsgpu_last_error().decode())
+        if want_visited:
+            return list(ids[:n]), list(vis[:n])
+        return list(ids[:n])
+
+    def set_profiling(self, on=True):
+        lib().nxsgpu_set_profiling(self.device, 1 if on else 0)
+
+    def profile(self, reset=False):
+        p = GpuProfile()
+        lib().nxsgpu_get_profile(self.device, C.byref(p), 1 if reset else 0)
+        return {k: getattr(p, k) for k, _ in GpuProfile._fields_}
+
+    def close(self):
+        if self._h:
+            lib().nxs_index_close(self._h)
+            self._h = None
+
+
+# ---- host-only helpers (run without a GPU; used by the CPU test tier) ------
+
+def query_repr(q):
+    err = C.c_void_p()
+    r = lib().nxs_test_query_repr(_b(q), C.byref(err))
+    return _take(r), _take(err.value)
+
+
+def query_lex(q):
+    kinds = (C.c_int * 512)()
+    n = lib().nxs_query_lex(_b(q), kinds, 512)
+    return list(kinds[:n])
+
+
+def compile_query(q, words, lowercase=False):
+    """-> (code, errmsg, empty, GpuQuery) against a word list (ids 1..n)."""
+    arr = (C.c_char_p * max(len(words), 1))(*[_b(w) for w in words])
+    plan = GpuQuery()
+    empty = C.c_int()
+    err = C.create_string_buffer(256)
+    code = lib().nxs_test_compile(_b(q), arr, len(words), lowercase,
+                                  C.byref(plan), C.byref(empty), err, 256)
+    return code, err.value.decode(), bool(empty.value), plan
+
+
+def bk_image(words):
+    """Flattened BK-tree of a word list -> list of node dicts in BFS order."""
+    arr = (C.c_char_p * max(len(words), 1))(*[_b(w) for w in words])
+    img = BkImage()
+    if lib().nxs_test_bk_image(arr, len(words), C.byref(img)) != 0:
+        raise MemoryError
+    nodes = []
+    for i in range(img.n):
+        nd = img.nodes[i]
+        s = bytes(img.bytes[nd.str_off:nd.str_off + nd.str_len])
+        nodes.append(dict(bitmap=nd.bitmap, first_child=nd.first_child,
+                          term_id=nd.term_id, term=s, flags=nd.flags,
+                          inl=bytes(nd.inl)))
+    depth = img.depth
+    lib().nxs_bk_free(C.byref(img))
+    return nodes, depth
+
+
+def levdist(a, b):
+    a, b = _b(a), _b(b)
+    return lib().nxs_test_levdist(a, len(a), b, len(b))

@@ -1,0 +1,1839 @@
+/*
+ * nxs_gpu.hip -- MI355X (gfx950, CDNA4) kernels of the nxsearch query path and
+ * the C-ABI shim (include/nxs_gpu.h) the C11 host code calls.
+ *
+ * Kernels (all wave64, one independent wavefront per workgroup unless noted):
+ *
+ *  k_expand_pairs   index build: nxsdtmap image (big-endian forward index,
+ *                   reference src/index/storage.h:67-97) -> (term, doc, tf)
+ *                   triples; replaces dtmap_build_tdmap (dtmap.c:386-438).
+ *  k_post_offsets   CSR row offsets of the (rocPRIM radix-)sorted triples.
+ *  k_impacts        per-posting BM25 / TF-IDF scores in fp64 with the exact
+ *                   operation order of src/algo/ranking.c:41-176; log() values
+ *                   come from host libm tables so results are bit-identical.
+ *  k_scan           THE hot kernel: posting-list iteration + f32 score
+ *                   accumulation in token order in per-wavefront LDS tiles,
+ *                   boolean filter, candidate pre-selection; replaces
+ *                   run_query_logic + get_expr_bitmap (search.c:118-278) and
+ *                   nxs_resp_addresult (results.c:128-150).
+ *  k_replay         exact replay of the reference's capped min-heap + heapsort
+ *                   (src/algo/heap.c:58-221; results.c:165-220) over the
+ *                   candidates in descending doc order: bit-exact top-k order
+ *                   including ties.
+ *  k_bk_level       one BFS level of bktree_search (bktree.c:219-275), one
+ *                   lane per (token, node): Levenshtein distance + child
+ *                   range expansion; k_bk_* helpers around it.
+ *
+ * No MFMA anywhere: this is sparse gather/accumulate and byte/integer work,
+ * bounded by HBM bandwidth and load latency.
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdarg>
+#include <vector>
+#include <algorithm>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "nxs_gpu.h"
+#include "nxs_lev.h"
+
+#define	WAVE		64
+#define	TILE_W		2048		/* docs per wavefront LDS tile */
+#define	SEG_CAP_DEFAULT	1024		/* candidate slots per (query, group) */
+
+/* ------------------------------------------------------------------ */
+/* error handling                                                      */
+/* ------------------------------------------------------------------ */
+
+static thread_local char g_err[512];
+
+static void
+set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+#define	HIP_TRY(expr) do {						\
+	hipError_t e_ = (expr);						\
+	if (e_ != hipSuccess) {						\
+		set_error("%s failed: %s (%s:%d)", #expr,		\
+		    hipGetErrorString(e_), __FILE__, __LINE__);		\
+		goto fail;						\
+	}								\
+} while (0)
+
+extern "C" const char *
+nxsgpu_last_error(void)
+{
+	return g_err;
+}
+
+extern "C" int
+nxsgpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* device-side data                                                    */
+/* ------------------------------------------------------------------ */
+
+struct posting_t {
+	uint32_t	doc;	/* dense doc ordinal (rank in ascending doc id) */
+	float		imp;	/* the reference's float score of this (term, doc) */
+};
+
+struct dev_query_t {
+	uint32_t	nt;
+	uint32_t	prog_len;
+	uint64_t	pbeg[NXSGPU_MAX_TOKENS];
+	uint64_t	pend[NXSGPU_MAX_TOKENS];
+	uint32_t	truth[8];
+	uint8_t		prog[NXSGPU_MAX_PROG];
+};
+
+struct nxsgpu_index {
+	int		device;
+	hipStream_t	stream;
+
+	uint64_t	n_docs, n_post;
+	uint32_t	n_terms;
+	uint32_t	hdr_doc_count;
+	uint64_t	hdr_token_count;
+	uint64_t	first_bad;
+	bool		bm25_valid, tfidf_valid;
+
+	uint64_t *	d_doc_ids;	/* [D] */
+	uint32_t *	d_doc_len;	/* [D] */
+	uint64_t *	d_post_off;	/* [T+2] */
+	uint64_t *	d_post_dt;	/* [P] doc<<32 | tf (kept for refresh) */
+	posting_t *	d_post[2];	/* [P] per ranking algo */
+	std::vector<uint64_t> h_post_off;
+
+	nxsgpu_bknode_t *d_bk;
+	uint8_t *	d_bk_bytes;
+	uint32_t	n_bk, bk_depth;
+
+	/* reusable query workspaces */
+	void *		ws;
+	size_t		ws_len;
+	void *		h_pin;
+	size_t		h_pin_len;
+
+	/* fuzzy workspaces */
+	void *		fz;
+	size_t		fz_len;
+
+	bool		profiling;
+	hipEvent_t	ev[4];
+	nxsgpu_profile_t prof;
+};
+
+static inline uint32_t __device__ __host__
+bswap32(uint32_t v)
+{
+	return (v >> 24) | ((v >> 8) & 0xff00) | ((v << 8) & 0xff0000) | (v << 24);
+}
+
+/* ------------------------------------------------------------------ */
+/* index build kernels                                                 */
+/* ------------------------------------------------------------------ */
+
+/*
+ * One wavefront walks 16 doc blocks; lanes stride over the (term_id, count)
+ * pairs of a block (8 bytes each => coalesced).  Block layout:
+ * u64 doc_id | u32 doc_len | u32 n | n x (u32 term_id, u32 count), all BE.
+ */
+__global__ void
+k_expand_pairs(const uint8_t *__restrict__ img, const uint64_t *__restrict__ blk_off,
+    const uint64_t *__restrict__ pair_base, uint64_t n_docs, uint32_t n_terms,
+    const uint8_t *__restrict__ term_ok, uint32_t *__restrict__ keys,
+    uint64_t *__restrict__ vals, uint32_t *__restrict__ doc_len,
+    unsigned long long *__restrict__ first_bad, unsigned int *__restrict__ max_tf)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	uint32_t my_max = 0;
+
+	for (unsigned k = 0; k < 16; k++) {
+		const uint64_t ord = wave * 16 + k;
+		if (ord >= n_docs) {
+			break;
+		}
+		const uint64_t off = blk_off[ord];
+		const uint32_t *blk = (const uint32_t *)(img + off);
+		const uint32_t n = (uint32_t)(pair_base[ord + 1] - pair_base[ord]);
+		const uint64_t base = pair_base[ord];
+
+		if (lane == 0) {
+			doc_len[ord] = bswap32(blk[2]);
+		}
+		for (uint32_t j = lane; j < n; j += WAVE) {
+			const uint2 p = *(const uint2 *)(blk + 4 + 2 * (size_t)j);
+			const uint32_t tid = bswap32(p.x), cnt = bswap32(p.y);
+			bool ok = tid != 0 && tid <= n_terms;
+			if (ok) {
+				ok = term_ok[tid] != 0;
+			}
+			if (!ok) {
+				atomicMin(first_bad, (unsigned long long)off);
+			}
+			keys[base + j] = ok ? tid : 0;
+			vals[base + j] = (ord << 32) | cnt;
+			my_max = max(my_max, cnt);
+		}
+	}
+	for (int o = 32; o; o >>= 1) {
+		my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o));
+	}
+	if (lane == 0 && my_max) {
+		atomicMax(max_tf, my_max);
+	}
+}
+
+/* post_off[t] = first index i with keys[i] >= t, t in [0, n_terms+1] */
+__global__ void
+k_post_offsets(const uint32_t *__restrict__ keys, uint64_t n, uint32_t n_terms,
+    uint64_t *__restrict__ post_off)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > (uint64_t)n_terms + 1) {
+		return;
+	}
+	uint64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint64_t mid = lo + ((hi - lo) >> 1);
+		if (keys[mid] < t) lo = mid + 1; else hi = mid;
+	}
+	post_off[t] = lo;
+}
+
+/*
+ * Per-posting scores.  fp64, -ffp-contract=off, operation order exactly as
+ * written in the reference:
+ *   bm25 (ranking.c:163-175):
+ *	tf = log(term_freq + 1)                       [host libm table]
+ *	tf_bm25 = tf / (tf + k * (1 - b + b * dl / adl))
+ *	idf = log((N - df + 0.5) / (df + 0.5) + 1)    [host libm, per term]
+ *	return (float)(tf_bm25 * idf)
+ *   tf_idf (ranking.c:90-96):
+ *	tf = (float)log(term_freq + 1); idf = (float)(log((float)N / df) + 1)
+ *	return tf * idf                               [f32 multiply]
+ */
+__global__ void
+k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
+    uint64_t n, const uint32_t *__restrict__ doc_len,
+    const double *__restrict__ logtf, const double *__restrict__ idf_bm25,
+    const float *__restrict__ idf_tfidf, double adl, double kk, double bb,
+    posting_t *__restrict__ out_bm25, posting_t *__restrict__ out_tfidf)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const uint32_t t = keys[i];
+		const uint64_t v = vals[i];
+		const uint32_t doc = (uint32_t)(v >> 32), cnt = (uint32_t)v;
+		const double tf = logtf[cnt];
+		const double dl = (double)(int)doc_len[doc];
+		const double one_b = 1 - bb;
+		const double tf_bm25 = tf / (tf + kk * (one_b + bb * dl / adl));
+		posting_t pb, pt;
+
+		pb.doc = doc;
+		pb.imp = (float)(tf_bm25 * idf_bm25[t]);
+		pt.doc = doc;
+		pt.imp = (float)tf * idf_tfidf[t];
+		out_bm25[i] = pb;
+		out_tfidf[i] = pt;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* k_scan: posting iteration + LDS score accumulation + pre-selection   */
+/* ------------------------------------------------------------------ */
+
+enum { MODE_TOPK = 0, MODE_COUNT = 1, MODE_ALL = 2 };
+
+struct scan_args_t {
+	const posting_t *	post;
+	const dev_query_t *	queries;
+	uint64_t		n_docs;
+	uint32_t		n_groups;
+	uint32_t		group_docs;	/* multiple of TILE_W */
+	uint32_t		k;		/* limit (<= 64 in MODE_TOPK) */
+	uint32_t		seg_cap;
+	uint32_t *		seg_count;	/* [Q*G] */
+	const uint64_t *	seg_off;	/* [Q*G+1] (MODE_ALL) */
+	uint32_t *		cand_doc;
+	float *			cand_sc;
+	uint32_t *		overflow;	/* [Q] */
+};
+
+/* lower bound of `doc` in post[lo, hi) by doc ordinal */
+__device__ static inline uint64_t
+post_lower_bound(const posting_t *__restrict__ post, uint64_t lo, uint64_t hi, uint64_t doc)
+{
+	while (lo < hi) {
+		const uint64_t mid = lo + ((hi - lo) >> 1);
+		if (post[mid].doc < doc) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+/* byte index of doc d's mask inside a tile: a u32 read at word (s*64+lane)
+ * yields the four docs s*256 + j*64 + lane, j = 0..3 */
+__device__ static inline uint32_t
+mask_byte(uint32_t d)
+{
+	return ((d >> 8) << 8) | ((d & 63) << 2) | ((d >> 6) & 3);
+}
+
+/* evaluate the postfix boolean program on a presence mask */
+__device__ static inline bool
+eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
+{
+	uint64_t st = 0;	/* bit stack, top at bit 0 */
+	for (uint32_t i = 0; i < len; i++) {
+		const uint8_t op = prog[i];
+		if (op < NXSGPU_MAX_TOKENS) {
+			st = (st << 1) | ((m >> op) & 1);
+		} else if (op == NXSGPU_OP_EMPTY) {
+			st <<= 1;
+		} else {
+			const uint64_t b = st & 1, a = (st >> 1) & 1;
+			uint64_t r;
+			if (op == NXSGPU_OP_AND) r = a & b;
+			else if (op == NXSGPU_OP_OR) r = a | b;
+			else r = a & ~b & 1;
+			st = ((st >> 2) << 1) | r;
+		}
+	}
+	return st & 1;
+}
+
+template <int NTMAX, typename MaskT, int MODE>
+__global__ void __launch_bounds__(WAVE)
+k_scan(const scan_args_t A)
+{
+	/* per-wavefront LDS tile */
+	__shared__ float s_acc[TILE_W];
+	__shared__ MaskT s_mask[TILE_W];
+	__shared__ uint64_t s_hi[NTMAX], s_lo[NTMAX];
+	__shared__ int64_t s_pdoc[NTMAX];	/* doc of posting hi-1, or -1 */
+	__shared__ uint32_t s_truth[8];
+	__shared__ uint8_t s_prog[NXSGPU_MAX_PROG];
+
+	const unsigned lane = threadIdx.x;
+	const uint32_t q = blockIdx.y, g = blockIdx.x;
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const posting_t *__restrict__ post = A.post;
+	const uint64_t seg = (uint64_t)q * A.n_groups + g;
+	const uint64_t dlo = (uint64_t)g * A.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)A.group_docs);
+
+	if (dlo >= A.n_docs) {
+		if (lane == 0 && MODE != MODE_ALL) {
+			A.seg_count[seg] = 0;
+		}
+		return;
+	}
+
+	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
+		s_acc[i] = 0.0f;
+		s_mask[i] = 0;
+	}
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	if (sizeof(MaskT) > 1) {
+		for (uint32_t i = lane; i < Q->prog_len; i += WAVE) {
+			s_prog[i] = Q->prog[i];
+		}
+	}
+	/* initial cursors of the group's doc range: lane t -> hi, lane 32+t -> lo */
+	if (lane < nt || (lane >= 32 && lane - 32 < nt)) {
+		const uint32_t t = lane & 31;
+		const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+		if (lane < 32) {
+			const uint64_t h = post_lower_bound(post, pb, pe, dhi);
+			s_hi[t] = h;
+		} else {
+			s_lo[t] = post_lower_bound(post, pb, pe, dlo);
+		}
+	}
+	__syncthreads();
+	if (lane < nt) {
+		const uint64_t h = s_hi[lane], l = s_lo[lane];
+		s_pdoc[lane] = (h > l) ? (int64_t)post[h - 1].doc : -1;
+	}
+	__syncthreads();
+
+	/* running top-k of the scores this wavefront has seen: lane i holds the
+	 * i-th largest; thr = k-th largest (or -inf).  Everything the global
+	 * heap replay could accept is > thr (see DESIGN.md "candidate filter"). */
+	float top = -INFINITY, thr = -INFINITY;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	for (;;) {
+		/* next non-empty tile = tile of the largest unconsumed doc */
+		int64_t md = -1;
+		for (uint32_t t = 0; t < nt; t++) {
+			md = max(md, s_pdoc[t]);
+		}
+		if (md < 0) {
+			break;
+		}
+		const uint32_t base = (uint32_t)((uint64_t)md / TILE_W) * TILE_W;
+
+		/* accumulate: tokens strictly in token-list order (results.c:134-136) */
+		for (uint32_t t = 0; t < nt; t++) {
+			if (s_pdoc[t] < (int64_t)base) {
+				continue;
+			}
+			uint64_t hi = s_hi[t];
+			const uint64_t lo = s_lo[t];
+			int64_t pdoc = -1;
+			while (hi > lo) {
+				const int64_t i = (int64_t)hi - WAVE + lane;
+				const bool valid = i >= (int64_t)lo;
+				posting_t p;
+				p.doc = 0; p.imp = 0.0f;
+				if (valid) {
+					p = post[i];
+				}
+				const bool in = valid && p.doc >= base;
+				const uint64_t bal = __ballot(in);
+				const uint32_t c = __popcll(bal);
+				if (in) {
+					const uint32_t d = p.doc - base;
+					s_acc[d] += p.imp;
+					if (sizeof(MaskT) == 1) {
+						s_mask[mask_byte(d)] |= (MaskT)(1u << t);
+					} else {
+						s_mask[d] |= (MaskT)(1u << t);
+					}
+				}
+				hi -= c;
+				if (c < WAVE) {
+					if (hi > lo) {
+						pdoc = (int64_t)(uint32_t)__shfl((int)p.doc, WAVE - 1 - c);
+					}
+					break;
+				}
+			}
+			__syncthreads();	/* single wavefront: orders the LDS updates */
+			if (lane == 0) {
+				s_hi[t] = hi;
+				s_pdoc[t] = pdoc;
+			}
+			__syncthreads();
+		}
+
+		/* scan the tile in DESCENDING doc order (results.c:143-147 prepends,
+		 * so the reference feeds its heap in descending doc id) */
+		if (sizeof(MaskT) == 1) {
+			uint32_t *mask32 = (uint32_t *)s_mask;
+			for (int s = TILE_W / 256 - 1; s >= 0; s--) {
+				const uint32_t mw = mask32[s * WAVE + lane];
+				if (__ballot(mw != 0) == 0) {
+					continue;
+				}
+				if (mw) {
+					mask32[s * WAVE + lane] = 0;
+				}
+				for (int j = 3; j >= 0; j--) {
+					const uint32_t m = (mw >> (8 * j)) & 0xff;
+					if (__ballot(m != 0) == 0) {
+						continue;
+					}
+					const uint32_t d = s * 256 + j * 64 + lane;
+					float sc = 0.0f;
+					if (m) {
+						sc = s_acc[d];
+						s_acc[d] = 0.0f;
+					}
+					const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					if (MODE == MODE_COUNT) {
+						n_out += __popcll(__ballot(match));
+						continue;
+					}
+					const bool cand = match && (sc > thr);
+					uint64_t bal = __ballot(cand);
+					if (!bal) {
+						continue;
+					}
+					const uint32_t ne = __popcll(bal);
+					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+						ovf = true;
+					} else {
+						/* slot = number of candidate lanes above me */
+						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+						if (cand) {
+							const uint64_t o = out_base + n_out + __popcll(above);
+							A.cand_doc[o] = base + d;
+							A.cand_sc[o] = sc;
+						}
+					}
+					n_out += ne;
+					if (track) {
+						while (bal) {
+							const int L = 63 - __clzll(bal);
+							bal &= ~(1ull << L);
+							const float v = __shfl(sc, L);
+							if (v > thr) {
+								const uint32_t pos = __popcll(__ballot(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = __shfl(top, kidx);
+							}
+						}
+					}
+				}
+			}
+		} else {
+			for (int s = TILE_W / WAVE - 1; s >= 0; s--) {
+				const uint32_t d = s * WAVE + lane;
+				const uint32_t m = s_mask[d];
+				if (__ballot(m != 0) == 0) {
+					continue;
+				}
+				float sc = 0.0f;
+				if (m) {
+					sc = s_acc[d];
+					s_acc[d] = 0.0f;
+					s_mask[d] = 0;
+				}
+				const bool match = m && eval_prog(s_prog, Q->prog_len, m);
+				if (MODE == MODE_COUNT) {
+					n_out += __popcll(__ballot(match));
+					continue;
+				}
+				const bool cand = match && (sc > thr);
+				uint64_t bal = __ballot(cand);
+				if (!bal) {
+					continue;
+				}
+				const uint32_t ne = __popcll(bal);
+				if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+					ovf = true;
+				} else {
+					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+					if (cand) {
+						const uint64_t o = out_base + n_out + __popcll(above);
+						A.cand_doc[o] = base + d;
+						A.cand_sc[o] = sc;
+					}
+				}
+				n_out += ne;
+				if (track) {
+					while (bal) {
+						const int L = 63 - __clzll(bal);
+						bal &= ~(1ull << L);
+						const float v = __shfl(sc, L);
+						if (v > thr) {
+							const uint32_t pos = __popcll(__ballot(top >= v));
+							const float up = __shfl_up(top, 1);
+							top = (lane < pos) ? top : (lane == pos ? v : up);
+							thr = __shfl(top, kidx);
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* k_replay: the reference's heap, replayed exactly                     */
+/* ------------------------------------------------------------------ */
+
+/* heap_remove_min: src/algo/heap.c:133-189 (comparator: score only) */
+__device__ static void
+heap_remove_min(float *hs, uint32_t *hd, uint32_t *nitems, float *os, uint32_t *od)
+{
+	uint32_t i = 0, max_, left;
+
+	*os = hs[0];
+	*od = hd[0];
+	if ((max_ = --(*nitems)) == 0) {
+		return;
+	}
+	hs[0] = hs[max_];
+	hd[0] = hd[max_];
+	while ((left = i * 2 + 1) < max_) {
+		const float ps = hs[i];
+		const uint32_t pd = hd[i];
+		const uint32_t right = i * 2 + 2;
+		uint32_t smallest = i;
+
+		if (hs[left] < ps) {
+			smallest = left;
+		}
+		if (right < max_ && hs[right] < hs[smallest]) {
+			smallest = right;
+		}
+		if (smallest == i) {
+			break;
+		}
+		hs[i] = hs[smallest];
+		hd[i] = hd[smallest];
+		hs[smallest] = ps;
+		hd[smallest] = pd;
+		i = smallest;
+	}
+}
+
+/* heap_add: src/algo/heap.c:58-124; caller has checked acceptance */
+__device__ static void
+heap_add(float *hs, uint32_t *hd, uint32_t *nitems, uint32_t cap, float s, uint32_t d)
+{
+	uint32_t i;
+
+	if (*nitems == cap) {
+		float ts; uint32_t td;
+		heap_remove_min(hs, hd, nitems, &ts, &td);
+	}
+	i = (*nitems)++;
+	hs[i] = s;
+	hd[i] = d;
+	while (i) {
+		const uint32_t parent = (i - 1) / 2;
+		const float ps = hs[parent];
+		const uint32_t pd = hd[parent];
+		if (s >= ps) {		/* heap.c:103 */
+			break;
+		}
+		hs[parent] = s;
+		hd[parent] = d;
+		hs[i] = ps;
+		hd[i] = pd;
+		i = parent;
+	}
+}
+
+struct replay_args_t {
+	uint32_t		n_groups;
+	uint32_t		seg_cap;	/* 0 => segments addressed by seg_off */
+	const uint32_t *	seg_count;
+	const uint64_t *	seg_off;
+	const uint32_t *	cand_doc;
+	const float *		cand_sc;
+	const uint64_t *	doc_ids;
+	uint32_t		k;		/* heap capacity (limit, clamped) */
+	/* heap storage when it does not fit LDS: [Q] slices via heap_off */
+	float *			gheap_s;
+	uint32_t *		gheap_d;
+	const uint64_t *	heap_off;	/* [Q+1] or NULL */
+	/* outputs */
+	uint64_t *		out_ids;
+	float *			out_sc;
+	uint32_t *		out_count;
+	const uint64_t *	out_off;	/* [Q+1] or NULL => q * k */
+	const uint32_t *	skip;		/* [Q] nonzero => leave untouched */
+};
+
+template <bool LDS_HEAP>
+__global__ void __launch_bounds__(WAVE)
+k_replay(const replay_args_t A)
+{
+	__shared__ float l_hs[NXSGPU_FAST_K];
+	__shared__ uint32_t l_hd[NXSGPU_FAST_K];
+	__shared__ uint32_t s_n;
+	__shared__ float s_min;
+
+	const unsigned lane = threadIdx.x;
+	const uint32_t q = blockIdx.x;
+	float *hs;
+	uint32_t *hd, cap;
+
+	if (A.skip && A.skip[q]) {
+		return;
+	}
+	if (LDS_HEAP) {
+		hs = l_hs;
+		hd = l_hd;
+		cap = A.k;
+	} else {
+		hs = A.gheap_s + A.heap_off[q];
+		hd = A.gheap_d + A.heap_off[q];
+		cap = (uint32_t)min((uint64_t)A.k, A.heap_off[q + 1] - A.heap_off[q]);
+	}
+	if (lane == 0) {
+		s_n = 0;
+		s_min = 0.0f;
+	}
+	__syncthreads();
+
+	/* candidates: groups in descending doc range, each already descending */
+	for (int g = (int)A.n_groups - 1; g >= 0 && cap; g--) {
+		const uint64_t seg = (uint64_t)q * A.n_groups + g;
+		const uint64_t sb = A.seg_cap ? seg * A.seg_cap : A.seg_off[seg];
+		const uint32_t n = A.seg_cap ? A.seg_count[seg]
+		    : (uint32_t)(A.seg_off[seg + 1] - A.seg_off[seg]);
+
+		for (uint32_t off = 0; off < n; off += WAVE) {
+			const uint32_t i = off + lane;
+			const bool valid = i < n;
+			float sc = 0.0f;
+			uint32_t dc = 0;
+			if (valid) {
+				sc = A.cand_sc[sb + i];
+				dc = A.cand_doc[sb + i];
+			}
+			/* heap.c:68-74: when full, an item <= the root is dropped
+			 * without touching the heap */
+			uint32_t nn = s_n;
+			float mn = s_min;
+			uint64_t pend = __ballot(valid && (nn < cap || sc > mn));
+			while (pend) {
+				const int L = __ffsll((long long)pend) - 1;
+				const float v = __shfl(sc, L);
+				const uint32_t dv = (uint32_t)__shfl((int)dc, L);
+				if (lane == 0) {
+					uint32_t cnt = s_n;
+					heap_add(hs, hd, &cnt, cap, v, dv);
+					s_n = cnt;
+					s_min = hs[0];
+				}
+				__syncthreads();
+				nn = s_n;
+				mn = s_min;
+				pend &= pend - 1;
+				pend &= __ballot(valid && (nn < cap || sc > mn));
+			}
+		}
+	}
+	__syncthreads();
+
+	/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
+	const uint32_t cnt = s_n;
+	if (lane == 0) {
+		uint32_t n = cnt;
+		while (n) {
+			const uint32_t last = n - 1;
+			float ms; uint32_t mdoc;
+			heap_remove_min(hs, hd, &n, &ms, &mdoc);
+			hs[last] = ms;
+			hd[last] = mdoc;
+		}
+	}
+	__syncthreads();
+	const uint64_t ob = A.out_off ? A.out_off[q] : (uint64_t)q * A.k;
+	for (uint32_t i = lane; i < cnt; i += WAVE) {
+		A.out_ids[ob + i] = A.doc_ids[hd[i]];
+		A.out_sc[ob + i] = hs[i];
+	}
+	if (lane == 0) {
+		A.out_count[q] = cnt;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* fuzzy: BK-tree BFS on the device                                    */
+/* ------------------------------------------------------------------ */
+
+struct fz_item_t { uint32_t tok, node; };
+
+struct fz_args_t {
+	const nxsgpu_bknode_t *	bk;
+	const uint8_t *		bk_bytes;
+	const uint8_t *		tok_bytes;
+	const uint32_t *	tok_off;
+	const uint64_t *	peq;		/* [n_tok][256] */
+	const fz_item_t *	cur;
+	fz_item_t *		next;
+	const uint32_t *	cur_count;
+	uint32_t *		next_count;
+	uint32_t		cap;
+	uint32_t *		best;		/* [n_tok] min BFS index of a usable match */
+	unsigned long long *	visited;	/* [n_tok] or NULL */
+	uint16_t *		dp_rows;	/* scratch for tokens > 64 bytes */
+	uint32_t		dp_stride;
+	uint32_t *		overflow;
+};
+
+/* distance between token `tok` and the node's term */
+__device__ static inline int
+fz_distance(const fz_args_t &A, uint32_t tok, const nxsgpu_bknode_t &nd, uint64_t slot)
+{
+	const uint32_t qoff = A.tok_off[tok], m = A.tok_off[tok + 1] - qoff;
+	const uint32_t n = nd.str_len;
+
+	if (m == 0) {
+		return (int)n;
+	}
+	if (m <= NXS_MYERS_MAXPAT) {
+		/* Myers bit-vector, pattern = query token */
+		const uint64_t *peq = A.peq + (uint64_t)tok * 256;
+		nxs_myers_t s;
+		nxs_myers_init(&s, m);
+		uint64_t w;
+		memcpy(&w, nd.inl, 8);
+		const uint32_t n0 = min(n, 8u);
+		for (uint32_t i = 0; i < n0; i++) {
+			nxs_myers_step(&s, peq[(w >> (8 * i)) & 0xff]);
+		}
+		const uint8_t *rest = A.bk_bytes + nd.str_off;
+		for (uint32_t i = 8; i < n; i++) {
+			nxs_myers_step(&s, peq[rest[i]]);
+		}
+		return s.score;
+	}
+	/* long token: row DP (levdist.c:67-150) in global scratch */
+	{
+		const uint8_t *a = A.tok_bytes + qoff;		/* length m */
+		const uint8_t *b = A.bk_bytes + nd.str_off;	/* length n */
+		uint16_t *row = A.dp_rows + slot * A.dp_stride;
+		uint32_t la = m, lb = n;
+		if (la < lb) {
+			const uint8_t *t = a; a = b; b = t;
+			const uint32_t tl = la; la = lb; lb = tl;
+		}
+		if (lb == 0) {
+			return (int)la;
+		}
+		for (uint32_t j = 0; j <= lb; j++) {
+			row[j] = (uint16_t)j;
+		}
+		for (uint32_t i = 0; i < la; i++) {
+			uint32_t diag = i, above;
+			row[0] = (uint16_t)(i + 1);
+			for (uint32_t j = 1; j <= lb; j++) {
+				above = row[j];
+				uint32_t v = diag + (a[i] != b[j - 1]);
+				v = min(v, (uint32_t)row[j - 1] + 1);
+				v = min(v, above + 1);
+				row[j] = (uint16_t)v;
+				diag = above;
+			}
+		}
+		return (int)row[lb];
+	}
+}
+
+template <bool LONG>
+__global__ void
+k_bk_level(const fz_args_t A)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const uint32_t count = min(*A.cur_count, A.cap);
+	const uint32_t nthreads = gridDim.x * blockDim.x;
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t rounds = (count + nthreads - 1) / nthreads;
+
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t i = r * nthreads + tid;
+		uint32_t nkids = 0, first = 0, tok = 0;
+		uint64_t bm = 0, full = 0;
+
+		if (i < count) {
+			const fz_item_t it = A.cur[i];
+			const uint32_t m = A.tok_off[it.tok + 1] - A.tok_off[it.tok];
+			tok = it.tok;
+			if (LONG == (m > NXS_MYERS_MAXPAT)) {
+				const nxsgpu_bknode_t nd = A.bk[it.node];
+				const int d = fz_distance(A, it.tok, nd, tid);
+				if (A.visited) {
+					atomicAdd(&A.visited[it.tok], 1ull);
+				}
+				/* match: bktree.c:252-254; winner = first pushed with
+				 * total > 0 (idxterm.c:238-242) = min BFS index */
+				if (d <= 2 && (nd.flags & 1)) {
+					atomicMin(&A.best[it.tok], it.node);
+				}
+				/* children in slots [max(d-2,0), min(d+2,63)):
+				 * bktree.c:150-156,260-264 (x86 shift semantics) */
+				const unsigned min_d = d > 2 ? (unsigned)d - 2 : 0;
+				const unsigned max_d = min((unsigned)d + 2, 63u);
+				const uint64_t lo_mask = ~0ull << (min_d & 63);
+				const uint64_t hi_mask = ~0ull >> ((64 - max_d) & 63);
+				full = nd.bitmap;
+				bm = full & lo_mask & hi_mask;
+				nkids = __popcll(bm);
+				first = nd.first_child;
+			}
+		}
+		/* wave-level inclusive scan of nkids, one atomic per wavefront */
+		uint32_t incl = nkids;
+		for (int o = 1; o < WAVE; o <<= 1) {
+			const uint32_t v = __shfl_up((int)incl, o);
+			if (lane >= (unsigned)o) incl += v;
+		}
+		const uint32_t total = __shfl((int)incl, WAVE - 1);
+		if (total == 0) {
+			continue;
+		}
+		uint32_t wbase = 0;
+		if (lane == WAVE - 1) {
+			wbase = atomicAdd(A.next_count, total);
+		}
+		wbase = __shfl((int)wbase, WAVE - 1);
+		uint32_t o = wbase + incl - nkids;
+		/* ascending slot order = the order bktree_search pushes children */
+		while (bm) {
+			const int slot = __ffsll((long long)bm) - 1;
+			bm &= bm - 1;
+			const uint32_t child = first + __popcll(full & ((1ull << slot) - 1));
+			if (o < A.cap) {
+				fz_item_t ni;
+				ni.tok = tok;
+				ni.node = child;
+				A.next[o] = ni;
+			} else {
+				*A.overflow = 1;
+			}
+			o++;
+		}
+	}
+}
+
+__global__ void
+k_bk_seed(fz_item_t *items, uint32_t *count0, uint32_t n_tok, uint32_t *best,
+    unsigned long long *visited)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_tok) {
+		fz_item_t it;
+		it.tok = i;
+		it.node = 0;
+		items[i] = it;
+		best[i] = 0xffffffffu;
+		if (visited) {
+			visited[i] = 0;
+		}
+	}
+	if (i == 0) {
+		*count0 = n_tok;
+	}
+}
+
+__global__ void
+k_bk_peq(const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok, uint64_t *peq)
+{
+	const uint32_t tok = blockIdx.x;
+	const uint32_t off = tok_off[tok], m = tok_off[tok + 1] - off;
+	for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
+		uint64_t bits = 0;
+		if (m <= NXS_MYERS_MAXPAT) {
+			for (uint32_t j = 0; j < m; j++) {
+				if (tok_bytes[off + j] == c) {
+					bits |= 1ull << j;
+				}
+			}
+		}
+		peq[(uint64_t)tok * 256 + c] = bits;
+	}
+}
+
+__global__ void
+k_bk_finish(const nxsgpu_bknode_t *bk, const uint32_t *best, uint32_t n_tok, uint32_t *term_ids)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_tok) {
+		const uint32_t b = best[i];
+		term_ids[i] = (b == 0xffffffffu) ? 0 : bk[b].term_id;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* host side of the shim                                               */
+/* ------------------------------------------------------------------ */
+
+static bool
+ensure_ws(nxsgpu_index_t *ix, size_t need)
+{
+	if (ix->ws_len >= need) {
+		return true;
+	}
+	if (ix->ws) {
+		(void)hipFree(ix->ws);
+		ix->ws = NULL;
+		ix->ws_len = 0;
+	}
+	need = (need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+	if (hipMalloc(&ix->ws, need) != hipSuccess) {
+		set_error("hipMalloc(%zu) for the query workspace failed", need);
+		return false;
+	}
+	ix->ws_len = need;
+	return true;
+}
+
+static bool
+ensure_pin(nxsgpu_index_t *ix, size_t need)
+{
+	if (ix->h_pin_len >= need) {
+		return true;
+	}
+	if (ix->h_pin) {
+		(void)hipHostFree(ix->h_pin);
+		ix->h_pin = NULL;
+		ix->h_pin_len = 0;
+	}
+	need = (need + 65535) & ~(size_t)65535;
+	if (hipHostMalloc(&ix->h_pin, need, hipHostMallocDefault) != hipSuccess) {
+		set_error("hipHostMalloc(%zu) failed", need);
+		return false;
+	}
+	ix->h_pin_len = need;
+	return true;
+}
+
+template <typename T>
+static T *
+carve(uint8_t *&p, size_t n)
+{
+	uintptr_t a = ((uintptr_t)p + 255) & ~(uintptr_t)255;
+	T *r = (T *)a;
+	p = (uint8_t *)(a + n * sizeof(T));
+	return r;
+}
+
+extern "C" void
+nxsgpu_index_destroy(nxsgpu_index_t *ix)
+{
+	if (!ix) {
+		return;
+	}
+	(void)hipSetDevice(ix->device);
+	if (ix->stream) {
+		(void)hipStreamSynchronize(ix->stream);
+	}
+	(void)hipFree(ix->d_doc_ids);
+	(void)hipFree(ix->d_doc_len);
+	(void)hipFree(ix->d_post_off);
+	(void)hipFree(ix->d_post_dt);
+	(void)hipFree(ix->d_post[0]);
+	(void)hipFree(ix->d_post[1]);
+	(void)hipFree(ix->d_bk);
+	(void)hipFree(ix->d_bk_bytes);
+	(void)hipFree(ix->ws);
+	(void)hipFree(ix->fz);
+	if (ix->h_pin) {
+		(void)hipHostFree(ix->h_pin);
+	}
+	for (int i = 0; i < 4; i++) {
+		if (ix->ev[i]) {
+			(void)hipEventDestroy(ix->ev[i]);
+		}
+	}
+	if (ix->stream) {
+		(void)hipStreamDestroy(ix->stream);
+	}
+	delete ix;
+}
+
+extern "C" nxsgpu_index_t *
+nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
+{
+	nxsgpu_index_t *ix = new nxsgpu_index_t();
+	const uint64_t D = src->n_docs;
+	const uint64_t P = D ? src->pair_base[D] : 0;
+	const uint32_t T = src->n_terms;
+	uint8_t *d_img = NULL, *d_term_ok = NULL;
+	uint64_t *d_blk_off = NULL, *d_pair_base = NULL, *d_vals_in = NULL;
+	uint32_t *d_keys_in = NULL, *d_keys = NULL;
+	unsigned long long *d_first_bad = NULL;
+	unsigned int *d_max_tf = NULL;
+	void *d_tmp = NULL;
+	double *d_logtf = NULL, *d_idf_bm25 = NULL;
+	float *d_idf_tfidf = NULL;
+	size_t tmp_bytes = 0;
+	unsigned long long h_first_bad = ~0ull;
+	unsigned int h_max_tf = 0;
+
+	ix->device = device;
+	ix->n_docs = D;
+	ix->n_post = P;
+	ix->n_terms = T;
+	ix->hdr_doc_count = src->hdr_doc_count;
+	ix->hdr_token_count = src->hdr_token_count;
+	ix->first_bad = ~0ull;
+	ix->n_bk = src->n_bk;
+	ix->bk_depth = src->bk_depth;
+	memset(&ix->prof, 0, sizeof(ix->prof));
+
+	if (D >= (1ull << 32) || P >= (1ull << 40)) {
+		set_error("index too large for 32-bit doc ordinals");
+		goto fail;
+	}
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+	for (int i = 0; i < 4; i++) {
+		HIP_TRY(hipEventCreate(&ix->ev[i]));
+	}
+
+	HIP_TRY(hipMalloc(&ix->d_doc_ids, std::max<uint64_t>(D, 1) * 8));
+	HIP_TRY(hipMalloc(&ix->d_doc_len, std::max<uint64_t>(D, 1) * 4));
+	HIP_TRY(hipMalloc(&ix->d_post_off, ((size_t)T + 2) * 8));
+	HIP_TRY(hipMalloc(&ix->d_post_dt, std::max<uint64_t>(P, 1) * 8));
+	HIP_TRY(hipMalloc(&ix->d_post[0], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
+	HIP_TRY(hipMalloc(&ix->d_post[1], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
+	ix->h_post_off.assign((size_t)T + 2, 0);
+
+	if (D) {
+		/* stage the forward index and transpose it on the device */
+		HIP_TRY(hipMalloc(&d_img, src->dtmap_len));
+		HIP_TRY(hipMalloc(&d_blk_off, D * 8));
+		HIP_TRY(hipMalloc(&d_pair_base, (D + 1) * 8));
+		HIP_TRY(hipMalloc(&d_term_ok, (size_t)T + 1));
+		HIP_TRY(hipMalloc(&d_keys_in, std::max<uint64_t>(P, 1) * 4));
+		HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(P, 1) * 4));
+		HIP_TRY(hipMalloc(&d_vals_in, std::max<uint64_t>(P, 1) * 8));
+		HIP_TRY(hipMalloc(&d_first_bad, 8));
+		HIP_TRY(hipMalloc(&d_max_tf, 4));
+		HIP_TRY(hipMemcpyAsync(d_img, src->dtmap_img, src->dtmap_len, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_blk_off, src->blk_off, D * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_pair_base, src->pair_base, (D + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_term_ok, src->term_ok, (size_t)T + 1, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_doc_ids, src->doc_ids, D * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_first_bad, &h_first_bad, 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemsetAsync(d_max_tf, 0, 4, ix->stream));
+		{
+			const uint64_t waves = (D + 15) / 16;
+			const unsigned blocks = (unsigned)((waves + 3) / 4);
+			hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(256), 0, ix->stream,
+			    d_img, d_blk_off, d_pair_base, D, T, d_term_ok, d_keys_in, d_vals_in,
+			    ix->d_doc_len, d_first_bad, d_max_tf);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipMemcpyAsync(&h_first_bad, d_first_bad, 8, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipMemcpyAsync(&h_max_tf, d_max_tf, 4, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		(void)hipFree(d_img); d_img = NULL;
+		(void)hipFree(d_blk_off); d_blk_off = NULL;
+		(void)hipFree(d_pair_base); d_pair_base = NULL;
+		(void)hipFree(d_term_ok); d_term_ok = NULL;
+		ix->first_bad = h_first_bad;
+		if (h_first_bad != ~0ull) {
+			/* the caller truncates at this doc and rebuilds (partial sync) */
+			goto done_partial;
+		}
+		if (h_max_tf >= (1u << 24)) {
+			set_error("term frequency %u exceeds the supported 2^24", h_max_tf);
+			goto fail;
+		}
+		if (P) {
+			unsigned bits = 1;
+			while (bits < 32 && (1ull << bits) <= T) {
+				bits++;
+			}
+			/* stable LSD radix sort by term id keeps docs ascending inside a term */
+			HIP_TRY(rocprim::radix_sort_pairs(NULL, tmp_bytes, d_keys_in, d_keys,
+			    d_vals_in, ix->d_post_dt, (size_t)P, 0, bits, ix->stream));
+			HIP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8));
+			HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys_in, d_keys,
+			    d_vals_in, ix->d_post_dt, (size_t)P, 0, bits, ix->stream));
+		}
+	}
+	{
+		const unsigned blocks = (unsigned)(((uint64_t)T + 2 + 255) / 256);
+		hipLaunchKernelGGL(k_post_offsets, dim3(blocks), dim3(256), 0, ix->stream,
+		    d_keys, P, T, ix->d_post_off);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipMemcpyAsync(ix->h_post_off.data(), ix->d_post_off, ((size_t)T + 2) * 8,
+	    hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+
+	/* host libm tables (the device only does IEEE + - * / on them) */
+	{
+		const unsigned long N = src->hdr_doc_count;
+		std::vector<double> logtf((size_t)h_max_tf + 2), idf_b((size_t)T + 2, 0.0);
+		std::vector<float> idf_t((size_t)T + 2, 0.0f);
+		double adl = 0.0;
+		static const double kk = 1.2f;		/* ranking.c:141 */
+		static const double bb = 0.75f;		/* ranking.c:142 */
+
+		for (size_t c = 0; c < logtf.size(); c++) {
+			logtf[c] = log((double)((int)c + 1));	/* ranking.c:90,168 */
+		}
+		for (uint32_t t = 1; t <= T; t++) {
+			const unsigned long df = ix->h_post_off[t + 1] - ix->h_post_off[t];
+			if (df == 0 || N == 0) {
+				continue;
+			}
+			/* ranking.c:172 */
+			idf_b[t] = log(((N - df + 0.5) / (df + 0.5)) + 1);
+			/* ranking.c:91: f32 division, double log, f32 result */
+			float idf = log((double)((float)N / (float)df)) + 1;
+			idf_t[t] = idf;
+		}
+		ix->tfidf_valid = N != 0;
+		ix->bm25_valid = false;
+		if (N != 0) {
+			adl = (double)(src->hdr_token_count / N);	/* ranking.c:163 */
+			ix->bm25_valid = !(adl < 1);
+		}
+		if (P) {
+			HIP_TRY(hipMalloc(&d_logtf, logtf.size() * 8));
+			HIP_TRY(hipMalloc(&d_idf_bm25, idf_b.size() * 8));
+			HIP_TRY(hipMalloc(&d_idf_tfidf, idf_t.size() * 4));
+			HIP_TRY(hipMemcpyAsync(d_logtf, logtf.data(), logtf.size() * 8, hipMemcpyHostToDevice, ix->stream));
+			HIP_TRY(hipMemcpyAsync(d_idf_bm25, idf_b.data(), idf_b.size() * 8, hipMemcpyHostToDevice, ix->stream));
+			HIP_TRY(hipMemcpyAsync(d_idf_tfidf, idf_t.data(), idf_t.size() * 4, hipMemcpyHostToDevice, ix->stream));
+			hipLaunchKernelGGL(k_impacts, dim3(4096), dim3(256), 0, ix->stream,
+			    d_keys, ix->d_post_dt, P, ix->d_doc_len, d_logtf, d_idf_bm25,
+			    d_idf_tfidf, adl >= 1 ? adl : 1.0, kk, bb,
+			    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF]);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(ix->stream));
+		}
+	}
+
+	/* BK-tree image */
+	if (src->n_bk) {
+		HIP_TRY(hipMalloc(&ix->d_bk, (size_t)src->n_bk * sizeof(nxsgpu_bknode_t)));
+		HIP_TRY(hipMalloc(&ix->d_bk_bytes, src->bk_bytes_len + 16));
+		HIP_TRY(hipMemcpy(ix->d_bk, src->bk_nodes, (size_t)src->n_bk * sizeof(nxsgpu_bknode_t), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(ix->d_bk_bytes, src->bk_bytes, src->bk_bytes_len, hipMemcpyHostToDevice));
+	}
+
+done_partial:
+	(void)hipFree(d_keys_in);
+	(void)hipFree(d_keys);
+	(void)hipFree(d_vals_in);
+	(void)hipFree(d_first_bad);
+	(void)hipFree(d_max_tf);
+	(void)hipFree(d_tmp);
+	(void)hipFree(d_logtf);
+	(void)hipFree(d_idf_bm25);
+	(void)hipFree(d_idf_tfidf);
+	return ix;
+fail:
+	(void)hipFree(d_img);
+	(void)hipFree(d_blk_off);
+	(void)hipFree(d_pair_base);
+	(void)hipFree(d_term_ok);
+	(void)hipFree(d_keys_in);
+	(void)hipFree(d_keys);
+	(void)hipFree(d_vals_in);
+	(void)hipFree(d_first_bad);
+	(void)hipFree(d_max_tf);
+	(void)hipFree(d_tmp);
+	(void)hipFree(d_logtf);
+	(void)hipFree(d_idf_bm25);
+	(void)hipFree(d_idf_tfidf);
+	nxsgpu_index_destroy(ix);
+	return NULL;
+}
+
+extern "C" int
+nxsgpu_index_df(nxsgpu_index_t *ix, uint32_t *df)
+{
+	df[0] = 0;
+	for (uint32_t t = 1; t <= ix->n_terms; t++) {
+		df[t] = (uint32_t)(ix->h_post_off[t + 1] - ix->h_post_off[t]);
+	}
+	return 0;
+}
+
+extern "C" uint64_t nxsgpu_index_postings(const nxsgpu_index_t *ix) { return ix->n_post; }
+extern "C" uint64_t nxsgpu_index_docs(const nxsgpu_index_t *ix) { return ix->n_docs; }
+extern "C" uint64_t nxsgpu_index_first_bad_doc(const nxsgpu_index_t *ix) { return ix->first_bad; }
+
+extern "C" void
+nxsgpu_set_profiling(nxsgpu_index_t *ix, int on)
+{
+	ix->profiling = on != 0;
+}
+
+extern "C" void
+nxsgpu_get_profile(nxsgpu_index_t *ix, nxsgpu_profile_t *p, int reset)
+{
+	*p = ix->prof;
+	if (reset) {
+		memset(&ix->prof, 0, sizeof(ix->prof));
+	}
+}
+
+extern "C" void
+nxsgpu_synchronize(nxsgpu_index_t *ix)
+{
+	(void)hipSetDevice(ix->device);
+	(void)hipStreamSynchronize(ix->stream);
+}
+
+/* ---- search --------------------------------------------------------- */
+
+template <int MODE>
+static void
+launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t nq, bool wide)
+{
+	const dim3 grid(a.n_groups, nq), block(WAVE);
+	if (wide) {
+		hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
+	} else {
+		hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
+	}
+}
+
+static uint32_t
+pick_groups(const nxsgpu_index_t *ix, uint32_t nq, uint32_t *group_docs)
+{
+	const uint64_t tiles = (ix->n_docs + TILE_W - 1) / TILE_W;
+	const char *env = getenv("NXS_GPU_WAVES");
+	const uint64_t target = env ? strtoull(env, NULL, 10) : 16384;
+	uint64_t g = std::max<uint64_t>(1, target / std::max<uint32_t>(nq, 1));
+
+	g = std::min<uint64_t>(g, std::max<uint64_t>(tiles, 1));
+	g = std::min<uint64_t>(g, 65535);
+	uint64_t tiles_per = (std::max<uint64_t>(tiles, 1) + g - 1) / g;
+	g = (std::max<uint64_t>(tiles, 1) + tiles_per - 1) / tiles_per;
+	*group_docs = (uint32_t)(tiles_per * TILE_W);
+	return (uint32_t)g;
+}
+
+/*
+ * Core of the search: fills device outputs.  If `d_out_*` are NULL the
+ * results are copied to the host into `res`.
+ */
+static int
+search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res, uint64_t *d_out_ids, float *d_out_sc,
+    uint32_t *d_out_cnt)
+{
+	const bool dev_out = d_out_ids != NULL;
+	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
+	const bool fast = limit <= NXSGPU_FAST_K;
+	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
+	uint32_t group_docs = 0;
+	const uint32_t G = pick_groups(ix, nq, &group_docs);
+	const uint64_t nseg = (uint64_t)nq * G;
+	std::vector<dev_query_t> hq(nq);
+	std::vector<uint32_t> h_ovf, h_cnt;
+	bool wide = false;
+	uint64_t total_post = 0;
+	uint8_t *p;
+	dev_query_t *d_q;
+	uint32_t *d_seg_count, *d_cand_doc, *d_ovf, *d_cnt;
+	uint64_t *d_seg_off, *d_ids;
+	float *d_cand_sc, *d_sc;
+	scan_args_t sa;
+	replay_args_t ra;
+	const uint32_t kfast = fast ? (uint32_t)limit : NXSGPU_FAST_K;
+
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (limit == 0) {
+		set_error("invalid limit");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (res) {
+		memset(res, 0, sizeof(*res));
+		res->n_queries = nq;
+	}
+	if (nq == 0) {
+		return 0;
+	}
+
+	for (uint32_t i = 0; i < nq; i++) {
+		const nxsgpu_query_t &q = queries[i];
+		dev_query_t &d = hq[i];
+		memset(&d, 0, sizeof(d));
+		if (q.n_tokens > NXSGPU_MAX_TOKENS || q.prog_len > NXSGPU_MAX_PROG) {
+			set_error("query %u exceeds the device limits", i);
+			return -1;
+		}
+		/* invalid statistics => every pair is skipped (ranking.c:86-88,156-166) */
+		d.nt = valid ? q.n_tokens : 0;
+		d.prog_len = q.prog_len;
+		memcpy(d.prog, q.prog, q.prog_len);
+		memcpy(d.truth, q.truth, sizeof(d.truth));
+		for (uint32_t t = 0; t < d.nt; t++) {
+			const uint32_t tid = q.term_id[t];
+			if (tid == 0 || tid > ix->n_terms) {
+				set_error("query %u: bad term id %u", i, tid);
+				return -1;
+			}
+			d.pbeg[t] = ix->h_post_off[tid];
+			d.pend[t] = ix->h_post_off[tid + 1];
+			total_post += d.pend[t] - d.pbeg[t];
+		}
+		if (d.nt > 8) {
+			wide = true;
+		}
+	}
+
+	/* workspace: queries | seg_count | overflow | fast candidates | fast outputs */
+	{
+		size_t need = 4096 + nq * sizeof(dev_query_t) + nseg * 4 + (nseg + 1) * 8 + nq * 4
+		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
+		if (!ensure_ws(ix, need)) {
+			return -1;
+		}
+	}
+	p = (uint8_t *)ix->ws;
+	d_q = carve<dev_query_t>(p, nq);
+	d_seg_count = carve<uint32_t>(p, nseg);
+	d_seg_off = carve<uint64_t>(p, nseg + 1);
+	d_ovf = carve<uint32_t>(p, nq);
+	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
+	d_cand_sc = carve<float>(p, nseg * seg_cap);
+	d_ids = dev_out ? d_out_ids : carve<uint64_t>(p, (size_t)nq * kfast);
+	d_sc = dev_out ? d_out_sc : carve<float>(p, (size_t)nq * kfast);
+	d_cnt = dev_out ? d_out_cnt : carve<uint32_t>(p, nq);
+
+	if (hipMemcpyAsync(d_q, hq.data(), nq * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess) {
+		set_error("query upload failed");
+		return -1;
+	}
+
+	memset(&sa, 0, sizeof(sa));
+	sa.post = ix->d_post[algo];
+	sa.queries = d_q;
+	sa.n_docs = ix->n_docs;
+	sa.n_groups = G;
+	sa.group_docs = group_docs;
+	sa.k = kfast;
+	sa.seg_cap = seg_cap;
+	sa.seg_count = d_seg_count;
+	sa.seg_off = d_seg_off;
+	sa.cand_doc = d_cand_doc;
+	sa.cand_sc = d_cand_sc;
+	sa.overflow = d_ovf;
+
+	h_ovf.assign(nq, 0);
+	if (fast) {
+		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
+		launch_scan<MODE_TOPK>(ix, sa, nq, wide);
+		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
+
+		memset(&ra, 0, sizeof(ra));
+		ra.n_groups = G;
+		ra.seg_cap = seg_cap;
+		ra.seg_count = d_seg_count;
+		ra.cand_doc = d_cand_doc;
+		ra.cand_sc = d_cand_sc;
+		ra.doc_ids = ix->d_doc_ids;
+		ra.k = kfast;
+		ra.out_ids = d_ids;
+		ra.out_sc = d_sc;
+		ra.out_count = d_cnt;
+		ra.skip = d_ovf;
+		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		if (ix->profiling) (void)hipEventRecord(ix->ev[2], ix->stream);
+		if (hipGetLastError() != hipSuccess) {
+			set_error("kernel launch failed");
+			return -1;
+		}
+		if (hipMemcpyAsync(h_ovf.data(), d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
+			set_error("copy failed");
+			return -1;
+		}
+		if (dev_out) {
+			if (hipStreamSynchronize(ix->stream) != hipSuccess) {
+				set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+				return -1;
+			}
+			if (ix->profiling) {
+				float a = 0, b = 0;
+				(void)hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]);
+				(void)hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]);
+				ix->prof.launches++;
+				ix->prof.scan_ms += a;
+				ix->prof.replay_ms += b;
+				ix->prof.postings += total_post;
+			}
+			for (uint32_t i = 0; i < nq; i++) {
+				if (h_ovf[i]) {
+					return 1;
+				}
+			}
+			return 0;
+		}
+	} else {
+		std::fill(h_ovf.begin(), h_ovf.end(), 1u);
+	}
+
+	/* host copy of the fast results */
+	std::vector<uint64_t> f_ids;
+	std::vector<float> f_sc;
+	h_cnt.assign(nq, 0);
+	if (fast) {
+		f_ids.resize((size_t)nq * kfast);
+		f_sc.resize((size_t)nq * kfast);
+		if (hipMemcpyAsync(f_ids.data(), d_ids, f_ids.size() * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(f_sc.data(), d_sc, f_sc.size() * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(h_cnt.data(), d_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
+			set_error("copy failed");
+			return -1;
+		}
+	}
+	if (hipStreamSynchronize(ix->stream) != hipSuccess) {
+		set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	if (fast && ix->profiling) {
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]);
+		(void)hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]);
+		ix->prof.launches++;
+		ix->prof.scan_ms += a;
+		ix->prof.replay_ms += b;
+		ix->prof.postings += total_post;
+	}
+
+	/*
+	 * Exact two-pass path for queries that overflowed their candidate
+	 * segments or ask for more than NXSGPU_FAST_K results: count matches,
+	 * emit them all, replay with the heap in global memory.
+	 */
+	std::vector<uint32_t> xq;	/* indices of such queries */
+	for (uint32_t i = 0; i < nq; i++) {
+		if (h_ovf[i]) {
+			xq.push_back(i);
+		}
+	}
+	std::vector<uint32_t> x_cnt;
+	std::vector<uint64_t> x_off, x_ids;
+	std::vector<float> x_sc;
+	if (!xq.empty()) {
+		const uint32_t nx = (uint32_t)xq.size();
+		const uint64_t xseg = (uint64_t)nx * G;
+		std::vector<dev_query_t> xhq(nx);
+		std::vector<uint32_t> sc_cnt(xseg);
+		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
+		void *xws = NULL;
+		uint8_t *xp;
+		bool xwide = false;
+		size_t xneed;
+		int rc = -1;
+
+		for (uint32_t j = 0; j < nx; j++) {
+			xhq[j] = hq[xq[j]];
+			if (xhq[j].nt > 8) {
+				xwide = true;
+			}
+		}
+		/* pass 1: count */
+		if (hipMemcpyAsync(d_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+			set_error("query upload failed");
+			return -1;
+		}
+		sa.k = 0xffffffffu;
+		launch_scan<MODE_COUNT>(ix, sa, nx, xwide);
+		if (hipMemcpyAsync(sc_cnt.data(), d_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
+			return -1;
+		}
+		for (uint64_t s = 0; s < xseg; s++) {
+			sc_off[s + 1] = sc_off[s] + sc_cnt[s];
+		}
+		for (uint32_t j = 0; j < nx; j++) {
+			const uint64_t matched = sc_off[(uint64_t)(j + 1) * G] - sc_off[(uint64_t)j * G];
+			const uint64_t hcap = std::min<uint64_t>(limit, matched);
+			hp_off[j + 1] = hp_off[j] + hcap;
+			o_off[j + 1] = o_off[j] + hcap;
+		}
+		const uint64_t tot_c = sc_off[xseg], tot_o = o_off[nx];
+		xneed = 8192 + (xseg + 1) * 8 + tot_c * 8 + tot_o * 8 * 2 + tot_o * 12 + (nx + 1) * 16 + nx * 4;
+		if (hipMalloc(&xws, xneed) != hipSuccess) {
+			set_error("hipMalloc(%zu) for the exact pass failed", xneed);
+			return -1;
+		}
+		xp = (uint8_t *)xws;
+		uint64_t *dx_seg_off = carve<uint64_t>(xp, xseg + 1);
+		uint32_t *dx_cdoc = carve<uint32_t>(xp, tot_c + 1);
+		float *dx_csc = carve<float>(xp, tot_c + 1);
+		float *dx_hs = carve<float>(xp, tot_o + 1);
+		uint32_t *dx_hd = carve<uint32_t>(xp, tot_o + 1);
+		uint64_t *dx_hoff = carve<uint64_t>(xp, nx + 1);
+		uint64_t *dx_ooff = carve<uint64_t>(xp, nx + 1);
+		uint64_t *dx_ids = carve<uint64_t>(xp, tot_o + 1);
+		float *dx_sc = carve<float>(xp, tot_o + 1);
+		uint32_t *dx_cnt = carve<uint32_t>(xp, nx);
+
+		x_cnt.assign(nx, 0);
+		x_ids.resize(tot_o);
+		x_sc.resize(tot_o);
+		x_off = o_off;
+		do {
+			if (hipMemcpyAsync(dx_seg_off, sc_off.data(), (xseg + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+			    hipMemcpyAsync(dx_hoff, hp_off.data(), (nx + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+			    hipMemcpyAsync(dx_ooff, o_off.data(), (nx + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+				set_error("upload failed");
+				break;
+			}
+			/* pass 2: emit every match at its exact offset */
+			scan_args_t sb = sa;
+			sb.seg_off = dx_seg_off;
+			sb.cand_doc = dx_cdoc;
+			sb.cand_sc = dx_csc;
+			launch_scan<MODE_ALL>(ix, sb, nx, xwide);
+			memset(&ra, 0, sizeof(ra));
+			ra.n_groups = G;
+			ra.seg_cap = 0;
+			ra.seg_off = dx_seg_off;
+			ra.cand_doc = dx_cdoc;
+			ra.cand_sc = dx_csc;
+			ra.doc_ids = ix->d_doc_ids;
+			ra.k = (uint32_t)std::min<uint64_t>(limit, 0xffffffffu);
+			ra.gheap_s = dx_hs;
+			ra.gheap_d = dx_hd;
+			ra.heap_off = dx_hoff;
+			ra.out_ids = dx_ids;
+			ra.out_sc = dx_sc;
+			ra.out_count = dx_cnt;
+			ra.out_off = dx_ooff;
+			hipLaunchKernelGGL(k_replay<false>, dim3(nx), dim3(WAVE), 0, ix->stream, ra);
+			if (hipGetLastError() != hipSuccess) {
+				set_error("kernel launch failed");
+				break;
+			}
+			if (hipMemcpyAsync(x_cnt.data(), dx_cnt, nx * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+			    (tot_o && hipMemcpyAsync(x_ids.data(), dx_ids, tot_o * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+			    (tot_o && hipMemcpyAsync(x_sc.data(), dx_sc, tot_o * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+			    hipStreamSynchronize(ix->stream) != hipSuccess) {
+				set_error("exact pass failed: %s", hipGetErrorString(hipGetLastError()));
+				break;
+			}
+			rc = 0;
+		} while (0);
+		(void)hipFree(xws);
+		if (rc != 0) {
+			return -1;
+		}
+		if (res) {
+			res->exact_requeries = nx;
+		}
+	}
+
+	/* assemble host results */
+	if (res) {
+		uint64_t total = 0;
+		res->counts = (uint32_t *)calloc(nq, sizeof(uint32_t));
+		res->offsets = (uint64_t *)calloc((size_t)nq + 1, sizeof(uint64_t));
+		for (uint32_t i = 0, j = 0; i < nq; i++) {
+			uint32_t c;
+			if (h_ovf[i]) {
+				c = x_cnt[j++];
+			} else {
+				c = h_cnt[i];
+			}
+			res->counts[i] = c;
+			res->offsets[i + 1] = res->offsets[i] + c;
+		}
+		total = res->offsets[nq];
+		res->doc_ids = (uint64_t *)malloc((total ? total : 1) * 8);
+		res->scores = (float *)malloc((total ? total : 1) * 4);
+		for (uint32_t i = 0, j = 0; i < nq; i++) {
+			const uint64_t o = res->offsets[i];
+			const uint32_t c = res->counts[i];
+			if (h_ovf[i]) {
+				memcpy(res->doc_ids + o, x_ids.data() + x_off[j], c * 8ull);
+				memcpy(res->scores + o, x_sc.data() + x_off[j], c * 4ull);
+				j++;
+			} else {
+				memcpy(res->doc_ids + o, f_ids.data() + (size_t)i * kfast, c * 8ull);
+				memcpy(res->scores + o, f_sc.data() + (size_t)i * kfast, c * 4ull);
+			}
+		}
+		res->postings = total_post;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res)
+{
+	return search_impl(ix, algo, limit, queries, nq, res, NULL, NULL, NULL);
+}
+
+extern "C" int
+nxsgpu_search_dev(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+{
+	if (limit == 0 || limit > NXSGPU_FAST_K || !d_doc_ids || !d_scores || !d_counts) {
+		set_error("nxsgpu_search_dev: limit must be 1..%d and outputs non-NULL", NXSGPU_FAST_K);
+		return -1;
+	}
+	return search_impl(ix, algo, limit, queries, nq, NULL, d_doc_ids, d_scores, d_counts);
+}
+
+extern "C" void
+nxsgpu_results_free(nxsgpu_results_t *res)
+{
+	free(res->counts);
+	free(res->offsets);
+	free(res->doc_ids);
+	free(res->scores);
+	memset(res, 0, sizeof(*res));
+}
+
+/* ---- fuzzy ----------------------------------------------------------- */
+
+extern "C" int
+nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off,
+    uint32_t n_tok, uint32_t *term_ids, uint64_t *visited)
+{
+	const uint64_t budget = getenv("NXS_GPU_FUZZY_ITEMS") ?
+	    strtoull(getenv("NXS_GPU_FUZZY_ITEMS"), NULL, 10) : (256ull << 20);
+	const uint32_t n_bk = ix->n_bk;
+	uint32_t chunk, max_len = 0;
+	bool any_long = false;
+
+	if (n_tok == 0) {
+		return 0;
+	}
+	if (n_bk == 0) {
+		memset(term_ids, 0, n_tok * sizeof(uint32_t));
+		if (visited) memset(visited, 0, n_tok * sizeof(uint64_t));
+		return 0;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	for (uint32_t i = 0; i < n_tok; i++) {
+		const uint32_t m = tok_off[i + 1] - tok_off[i];
+		max_len = std::max(max_len, m);
+		if (m > NXS_MYERS_MAXPAT) {
+			any_long = true;
+		}
+	}
+	/* worst case one token visits every node: size chunks so the frontier
+	 * queues can never overflow */
+	chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tok, budget / n_bk));
+
+	const uint32_t LONG_THREADS = 64 * 64;
+	const uint64_t cap = (uint64_t)chunk * n_bk;
+	const size_t levels = (size_t)ix->bk_depth + 2;
+	size_t need = 4096 + cap * sizeof(fz_item_t) * 2 + levels * 4 + 256
+	    + (size_t)chunk * (256 * 8 + 4 + 8 + 4) + tok_off[n_tok] + 16 + ((size_t)chunk + 1) * 4
+	    + (any_long ? (size_t)LONG_THREADS * ((size_t)max_len + 2) * 2 : 0) + 16 * 256;
+	if (ix->fz_len < need) {
+		if (ix->fz) {
+			(void)hipFree(ix->fz);
+			ix->fz = NULL;
+			ix->fz_len = 0;
+		}
+		if (hipMalloc(&ix->fz, need) != hipSuccess) {
+			set_error("hipMalloc(%zu) for the fuzzy workspace failed", need);
+			return -1;
+		}
+		ix->fz_len = need;
+	}
+
+	for (uint32_t c0 = 0; c0 < n_tok; c0 += chunk) {
+		const uint32_t nc = std::min(chunk, n_tok - c0);
+		const uint32_t boff = tok_off[c0], blen = tok_off[c0 + nc] - boff;
+		std::vector<uint32_t> roff(nc + 1);
+		uint8_t *p = (uint8_t *)ix->fz;
+		fz_item_t *qa = carve<fz_item_t>(p, cap);
+		fz_item_t *qb = carve<fz_item_t>(p, cap);
+		uint32_t *counts = carve<uint32_t>(p, levels);
+		uint32_t *d_ovf = carve<uint32_t>(p, 1);
+		uint64_t *d_peq = carve<uint64_t>(p, (size_t)nc * 256);
+		uint32_t *d_best = carve<uint32_t>(p, nc);
+		unsigned long long *d_vis = carve<unsigned long long>(p, nc);
+		uint32_t *d_tids = carve<uint32_t>(p, nc);
+		uint8_t *d_bytes = carve<uint8_t>(p, blen + 16);
+		uint32_t *d_off = carve<uint32_t>(p, nc + 1);
+		uint16_t *d_rows = any_long ? carve<uint16_t>(p, (size_t)LONG_THREADS * (max_len + 2)) : NULL;
+		fz_args_t fa;
+		uint32_t h_ovf = 0;
+
+		for (uint32_t i = 0; i <= nc; i++) {
+			roff[i] = tok_off[c0 + i] - boff;
+		}
+		if (hipMemcpyAsync(d_bytes, tok_bytes + boff, blen, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_off, roff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemsetAsync(counts, 0, levels * 4, ix->stream) != hipSuccess ||
+		    hipMemsetAsync(d_ovf, 0, 4, ix->stream) != hipSuccess) {
+			set_error("fuzzy upload failed");
+			return -1;
+		}
+		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
+		hipLaunchKernelGGL(k_bk_peq, dim3(nc), dim3(256), 0, ix->stream, d_bytes, d_off, nc, d_peq);
+		hipLaunchKernelGGL(k_bk_seed, dim3((nc + 255) / 256), dim3(256), 0, ix->stream,
+		    qa, counts, nc, d_best, visited ? d_vis : (unsigned long long *)NULL);
+
+		memset(&fa, 0, sizeof(fa));
+		fa.bk = ix->d_bk;
+		fa.bk_bytes = ix->d_bk_bytes;
+		fa.tok_bytes = d_bytes;
+		fa.tok_off = d_off;
+		fa.peq = d_peq;
+		fa.cap = (uint32_t)std::min<uint64_t>(cap, 0xffffffffu);
+		fa.best = d_best;
+		fa.visited = visited ? d_vis : NULL;
+		fa.dp_rows = d_rows;
+		fa.dp_stride = max_len + 2;
+		fa.overflow = d_ovf;
+		for (uint32_t lvl = 0; lvl < ix->bk_depth; lvl++) {
+			fa.cur = (lvl & 1) ? qb : qa;
+			fa.next = (lvl & 1) ? qa : qb;
+			fa.cur_count = counts + lvl;
+			fa.next_count = counts + lvl + 1;
+			hipLaunchKernelGGL(k_bk_level<false>, dim3(2048), dim3(256), 0, ix->stream, fa);
+			if (any_long) {
+				/* tokens longer than 64 bytes: row DP, bounded scratch */
+				hipLaunchKernelGGL(k_bk_level<true>, dim3(LONG_THREADS / 64), dim3(64), 0, ix->stream, fa);
+			}
+		}
+		hipLaunchKernelGGL(k_bk_finish, dim3((nc + 255) / 256), dim3(256), 0, ix->stream,
+		    ix->d_bk, d_best, nc, d_tids);
+		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
+		if (hipGetLastError() != hipSuccess) {
+			set_error("fuzzy kernel launch failed");
+			return -1;
+		}
+		std::vector<uint32_t> h_counts(levels);
+		if (hipMemcpyAsync(term_ids + c0, d_tids, nc * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    (visited && hipMemcpyAsync(visited + c0, d_vis, nc * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+		    hipMemcpyAsync(&h_ovf, d_ovf, 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(h_counts.data(), counts, levels * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
+			return -1;
+		}
+		if (h_ovf) {
+			set_error("fuzzy frontier overflow (internal error)");
+			return -1;
+		}
+		if (ix->profiling) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
+			ix->prof.fuzzy_ms += ms;
+			for (size_t l = 0; l < levels; l++) {
+				ix->prof.fuzzy_visits += h_counts[l];
+			}
+		}
+	}
+	return 0;
+}

@@ -1,0 +1,149 @@
+/*
+ * nxs_impl.h -- private declarations of the C11 host side.
+ *
+ * Host responsibilities (everything that is not per-posting or per-BK-node
+ * work): mapping and validating the two index files, the term dictionary,
+ * building and flattening the BK-tree image, query lexing/parsing, token
+ * resolution, compiling a query into the device plan, and the nxs_resp_t
+ * object.  All per-posting and per-node work happens in nxs_gpu.hip.
+ */
+#ifndef NXS_IMPL_H
+#define NXS_IMPL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#include "nxs.h"
+#include "nxs_gpu.h"
+
+#define	NXS_DEFAULT_RESULTS_LIMIT	1000	/* nxs_impl.h:39 of the reference */
+#define	NXS_QUERY_RLIMIT		100	/* search.c:70 */
+#define	LEVDIST_TOLERANCE		2	/* index.h:26 */
+
+struct nxs {
+	char *		basedir;
+	char *		errmsg;
+	nxs_err_t	errcode;
+	nxs_index_t **	indexes;
+	size_t		n_indexes;
+};
+
+void	nxs_clear_error(nxs_t *);
+void	nxs_decl_err(nxs_t *, nxs_err_t, const char *fmt, ...)
+	    __attribute__((format(printf, 3, 4)));
+
+/* ---- params ---------------------------------------------------------- */
+
+typedef enum { PV_STR, PV_UINT, PV_BOOL } pv_type_t;
+
+typedef struct {
+	char *		key;
+	pv_type_t	type;
+	char *		s;
+	uint64_t	u;
+	bool		b;
+} param_kv_t;
+
+struct nxs_params {
+	param_kv_t *	kv;
+	size_t		n;
+};
+
+const char *nxs_params_get_str(const nxs_params_t *, const char *);
+int	nxs_params_get_uint(const nxs_params_t *, const char *, uint64_t *);
+int	nxs_params_get_bool(const nxs_params_t *, const char *, bool *);
+
+/* ---- index ----------------------------------------------------------- */
+
+typedef struct {
+	const uint8_t *	val;		/* into the mapped nxsterms image */
+	uint32_t	tot_off;	/* offset of the u64 BE total counter; 0 = dead id */
+	uint16_t	len;
+} hterm_t;
+
+struct nxs_index {
+	nxs_t *		nxs;
+	char *		name;
+	int		algo;		/* NXSGPU_BM25 / NXSGPU_TF_IDF */
+	bool		lowercase;
+
+	uint8_t *	tmap;	size_t tmap_len;
+	uint8_t *	dmap;	size_t dmap_len;
+
+	/* term dictionary: ids 1..last_id (file order, terms.c:404) */
+	hterm_t *	terms;
+	uint32_t	last_id;
+	uint32_t	term_count;
+	uint32_t *	thash;		/* open addressing: term ids */
+	size_t		thash_cap;
+
+	uint64_t	n_docs;
+	nxsgpu_index_t *dev;
+};
+
+/* nxs_index.c */
+int	nxs_index_load(nxs_index_t *, const char *terms_path, const char *dtmap_path);
+void	nxs_index_unload(nxs_index_t *);
+uint32_t nxs_term_lookup(const nxs_index_t *, const uint8_t *val, size_t len);
+
+/* flattened BK-tree built on the host (exported for the CPU-side tests) */
+typedef struct {
+	nxsgpu_bknode_t *nodes;
+	uint32_t	n;
+	uint32_t	depth;
+	uint8_t *	bytes;
+	uint64_t	bytes_len;
+} nxs_bkimage_t;
+
+int	nxs_bk_build(const hterm_t *terms, uint32_t last_id, const uint8_t *tmap,
+	    nxs_bkimage_t *out);
+void	nxs_bk_free(nxs_bkimage_t *);
+
+/* ---- query ----------------------------------------------------------- */
+
+typedef enum {
+	QTK_EOF = 0, QTK_AND, QTK_OR, QTK_NOT, QTK_BR_OPEN, QTK_BR_CLOSE,
+	QTK_FF_STRING, QTK_QUOTED_STRING,
+} qtoken_t;
+
+/* postfix item: a leaf string or an operator */
+typedef struct {
+	uint8_t		op;	/* 0 = leaf, else NXSGPU_OP_AND/OR/ANDNOT */
+	char *		str;	/* leaf value (owned) */
+	int		token;	/* leaf: index into the token list, -1 = none */
+} qitem_t;
+
+typedef struct {
+	qitem_t *	items;
+	size_t		n;
+	bool		error;
+	char *		errmsg;
+} qparse_t;
+
+int	nxs_query_lex(const char *query, int *kinds, size_t cap);
+void	nxs_query_parse(const char *query, qparse_t *out);
+void	nxs_query_free(qparse_t *);
+char *	nxs_query_repr(const qparse_t *);
+
+typedef struct {
+	char *		value;
+	size_t		len;
+	uint32_t	term_id;	/* 0 = unresolved */
+} qtok_t;
+
+typedef struct {
+	qparse_t	parse;
+	qtok_t *	tokens;		/* token-list order (query.c:89-95) */
+	size_t		n_tokens;
+	nxs_err_t	errcode;	/* set when the query cannot run */
+	char *		errmsg;
+	bool		empty;		/* no live tokens: empty result */
+	nxsgpu_query_t	plan;
+} qprep_t;
+
+void	nxs_query_prepare(const nxs_index_t *, const char *query, qprep_t *out);
+int	nxs_query_compile(qprep_t *);	/* after term ids are final */
+void	nxs_query_release(qprep_t *);
+
+#endif

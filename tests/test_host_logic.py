@@ -1,0 +1,220 @@
+"""CPU tier for the product's host side (no GPU): the hand-written lexer /
+parser / plan compiler, the host Levenshtein + BK-tree image, the synthetic
+corpus writer, and the C-ABI surface.  The oracle is used as the checker."""
+import ctypes as C
+import os
+import random
+import re
+
+import pytest
+
+import nxsearch_amd as N
+import nxsfmt
+import oracle_lib as O
+from nxsearch_amd import corpus
+
+TK = {1: "AND", 2: "OR", 3: "NOT", 4: "(", 5: ")", 6: "FF", 7: "QUOTED"}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    L = C.CDLL(N.LIB_PATH)
+    for sym in N.NXS_H_SYMBOLS + N.NXS_GPU_H_SYMBOLS:
+        assert hasattr(L, sym), sym
+    # and the headers declare nothing that the lists above miss
+    for hdr, names in (("nxs.h", N.NXS_H_SYMBOLS), ("nxs_gpu.h", N.NXS_GPU_H_SYMBOLS)):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared = set(re.findall(r"\b(nxs(?:gpu)?_[a-z0-9_]+)\s*\(", text))
+        assert declared == set(names), (hdr, declared ^ set(names))
+
+
+def test_no_gpu_means_loud_failure(tmp_path):
+    if N.lib().nxsgpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    t, d, _ = nxsfmt.write_index(str(tmp_path), "idx", [(1, ["cat"])])
+    with N.Nxs(str(tmp_path)) as nxs:
+        with pytest.raises(N.NxsError) as e:
+            nxs.open_index("idx")
+        assert e.value.code == 2 and "no HIP device" in e.value.msg
+
+
+def test_parser_golden_vectors(golden):
+    for c in golden["queryparser"]["cases"]:
+        assert [TK[k] for k in N.query_lex(c["query"])] == c["tokens"], c["query"]
+        rep, err = N.query_repr(c["query"])
+        if c["repr"] is None:
+            assert rep is None and err.startswith("syntax error near")
+        else:
+            assert rep == c["repr"]
+
+
+def test_parser_matches_oracle_on_random_queries():
+    rng = random.Random(2024)
+    atoms = ["a", "bb", "AND", "and", "OR", "or", "NOT", "not", "&", "|", "(", ")",
+             "(", ")", "'q s'", '"d q"', "'un", "ANDx", "xOR", "\n", "  ", "\t",
+             "ж", "a&b", "'a'b", "\\", "'e\\'s'", "c"]
+    n_err = 0
+    for _ in range(6000):
+        q = " ".join(rng.choice(atoms) for _ in range(rng.randint(0, 9)))
+        if rng.random() < 0.3:
+            q = q.replace(" ", "", rng.randint(1, 3))
+        assert N.query_lex(q) == O.query_lex(q), repr(q)
+        got, want = N.query_repr(q), O.query_repr(q)
+        assert got == want, repr(q)
+        n_err += got[0] is None
+    assert 500 < n_err < 5500          # both outcomes are well exercised
+
+
+def _eval_prog(plan, mask):
+    st = []
+    for op in plan.prog[:plan.prog_len]:
+        if op < 32:
+            st.append((mask >> op) & 1)
+        elif op == 0x40:
+            st.append(0)
+        else:
+            b, a = st.pop(), st.pop()
+            st.append(a & b if op == 0x80 else a | b if op == 0x81 else a & (1 - b))
+    assert len(st) == 1
+    return st[0]
+
+
+def test_plan_token_order_truth_table_and_empty_leaves():
+    words = ["a", "b", "c", "d", "e"]
+    # right-to-left leaf order (query.c:89-95): a AND b AND c => c, b, a
+    code, err, empty, p = N.compile_query("a AND b AND c", words)
+    assert (code, empty, p.n_tokens) == (0, False, 3)
+    assert list(p.term_id[:3]) == [3, 2, 1]
+    # identical strings share a token, an unknown word is an empty-set leaf
+    code, err, empty, p = N.compile_query("a OR zz OR a AND b", words)
+    assert p.n_tokens == 2 and list(p.term_id[:2]) == [2, 1]
+    assert 0x40 in list(p.prog[:p.prog_len])
+    for m in range(4):
+        a, b = (m >> 1) & 1, m & 1
+        assert ((p.truth[0] >> m) & 1) == (a | (a & b)) == _eval_prog(p, m)
+    # all tokens unknown => empty result, not an error (search.c:224-226)
+    code, err, empty, p = N.compile_query("zz OR yy", words)
+    assert (code, empty) == (0, True)
+    # syntax error => NXS_ERR_INVALID with the reference's message shape
+    code, err, empty, p = N.compile_query("a AND", words)
+    assert code == 3 and err == 'query failed with syntax error near 1:5: " ..."'
+    # nesting limit (search.c:70,126-131)
+    code, err, _, _ = N.compile_query(" OR ".join(["a"] * 102), words)
+    assert code == 6 and err == "query nesting limit reached (100 levels)"
+    code, err, _, _ = N.compile_query(" OR ".join(["a"] * 101), words)
+    assert code == 0
+    # lower-casing stand-in for the normalizer filter
+    code, err, empty, p = N.compile_query("A AND B", words, lowercase=True)
+    assert (code, empty, p.n_tokens) == (0, False, 2)
+    code, err, empty, p = N.compile_query("A AND B", words, lowercase=False)
+    assert empty
+
+
+def test_plan_truth_table_matches_set_algebra_on_random_queries():
+    rng = random.Random(5)
+    words = list("abcdefgh")
+    for _ in range(300):
+        n = rng.randint(1, 8)
+        toks = [rng.choice(words) for _ in range(n)]
+        q = toks[0]
+        for t in toks[1:]:
+            q += rng.choice([" AND ", " OR ", " AND NOT ", " "]) + t
+        if rng.random() < 0.3 and n >= 3:
+            q = "(" + q.replace(" ", " ", 1) + ")"
+            if "  " in q or re.search(r"\w \w", q):
+                q = q[1:-1]                    # juxtaposition is top-level only
+        code, err, empty, p = N.compile_query(q, words)
+        assert code == 0, (q, err)
+        nt = p.n_tokens
+        assert 1 <= nt <= 8
+        for m in range(1 << nt):
+            assert ((p.truth[m >> 5] >> (m & 31)) & 1) == _eval_prog(p, m)
+        assert (p.truth[0] & 1) == 0            # no term present => no match
+
+
+def test_host_levdist_matches_oracle(golden):
+    for a, b, exp in golden["levdist"]["pairs"]:
+        assert N.levdist(a, b) == exp
+    rng = random.Random(3)
+    for _ in range(20000):
+        a = bytes(rng.choice(b"abcz\xc4") for _ in range(rng.randint(0, 20)))
+        b = bytes(rng.choice(b"abcz\xc4") for _ in range(rng.randint(0, 20)))
+        if 0 in a or 0 in b:
+            continue
+        assert N.levdist(a, b) == O.levdist(a, b)
+    for _ in range(60):          # around and beyond the 64-byte bit-vector width
+        a = bytes(rng.choice(b"ab") for _ in range(rng.randint(55, 140)))
+        b = bytes(rng.choice(b"ab") for _ in range(rng.randint(55, 140)))
+        assert N.levdist(a, b) == O.levdist(a, b)
+
+
+def _image_search(nodes, q, tol=2):
+    """bktree_search over the flattened image, level-synchronous (what the
+    device does); returns (matches in BFS order, visited)."""
+    frontier, out, visited = [0], [], 0
+    while frontier:
+        nxt = []
+        for i in frontier:
+            nd = nodes[i]
+            d = O.levdist(q, nd["term"])
+            visited += 1
+            if d <= tol:
+                out.append(i)
+            lo, hi = max(d - tol, 0), min(d + tol, 63)
+            for slot in range(lo, hi):          # half-open (Q8)
+                if (nd["bitmap"] >> slot) & 1:
+                    below = bin(nd["bitmap"] & ((1 << slot) - 1)).count("1")
+                    nxt.append(nd["first_child"] + below)
+        frontier = nxt
+    return out, visited
+
+
+@pytest.mark.parametrize("seed,n,alphabet", [(1, 400, "abcd"), (2, 2500, "abcdefghijklmnopqrstuvwxyz")])
+def test_bk_image_search_equals_oracle_bfs(seed, n, alphabet):
+    rng = random.Random(seed)
+    words = []
+    while len(words) < n:
+        w = "".join(rng.choice(alphabet) for _ in range(rng.randint(1, 10)))
+        if rng.random() < 0.03 and words:
+            w = rng.choice(words)
+        words.append(w)
+    nodes, depth = N.bk_image(words)
+    orc = O.BKTree([w.encode() for w in words])
+    assert len(nodes) == len(set(words))
+    for _ in range(150):
+        q = bytearray(rng.choice(words).encode())
+        q[rng.randrange(len(q))] = ord(rng.choice(alphabet))
+        res, nvis = orc.search(bytes(q), 2)
+        got, gvis = _image_search(nodes, bytes(q), 2)
+        # same visit count, same match SET and the same FIRST match (Q7);
+        # BFS rank order == deque push order
+        assert gvis == nvis
+        assert [nodes[i]["term_id"] - 1 for i in got] == res
+
+
+def test_synth_corpus_is_valid_and_deterministic(tmp_path):
+    c1 = corpus.write_corpus(str(tmp_path / "a"), 3000, 500, seed=7, threads=1)
+    c2 = corpus.write_corpus(str(tmp_path / "b"), 3000, 500, seed=7, threads=4)
+    assert open(c1["dtmap"], "rb").read() == open(c2["dtmap"], "rb").read()
+    assert open(c1["terms"], "rb").read() == open(c2["terms"], "rb").read()
+    idx = O.Index(c1["terms"], c1["dtmap"])
+    assert (idx.term_count, idx.dt_count, idx.doc_count) == (500, 3000, 3000)
+    assert idx.token_count == c1["tokens"]
+    assert sum(idx.df(t) for t in range(1, 501)) == c1["postings"]
+    terms = corpus.term_strings(500, seed=7)
+    assert len(set(terms)) == 500 and all(4 <= len(t) <= 12 for t in terms)
+    for tid in (1, 2, 250, 500):
+        assert idx.term(tid) == terms[tid - 1]
+    assert idx.df(1) > idx.df(50) > idx.df(500) >= 0      # Zipf-ish
+    # files are sized in 32 KiB steps (index.h:24)
+    assert os.path.getsize(c1["dtmap"]) % 32768 == 0
+    assert os.path.getsize(c1["terms"]) % 32768 == 0
+    res = idx.search(terms[0].decode(), limit=10)
+    assert len(res) == 10
+    # sparse ids variant
+    c3 = corpus.write_corpus(str(tmp_path / "c"), 500, 100, seed=1, sparse_ids=True)
+    idx3 = O.Index(c3["terms"], c3["dtmap"])
+    assert idx3.dt_count == 500
+    ids = [d for d, _ in idx3.search(corpus.term_strings(100, 1)[0].decode(), limit=1000)]
+    assert ids and max(ids) > 10 ** 6

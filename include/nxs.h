@@ -88,6 +88,18 @@ int		nxs_index_search_batch(nxs_index_t *, nxs_params_t *,
 		    nxs_resp_t **resps, nxs_err_t *errs);
 
 /*
+ * Front half of a batch only: parse + resolve (fuzzy misses on the device) +
+ * compile into device plans (struct nxsgpu_query = nxsgpu_query_t of
+ * nxs_gpu.h), for callers that keep the results on the device
+ * (nxsgpu_search_dev).  plans[i].n_tokens == 0 when query i matches nothing
+ * or failed (errs[i] then holds its code).  Returns #failed or -1.
+ */
+struct nxsgpu_query;
+int		nxs_index_plan_batch(nxs_index_t *, nxs_params_t *,
+		    const char *const *queries, size_t n,
+		    struct nxsgpu_query *plans, nxs_err_t *errs);
+
+/*
  * Opens an index straight from the two files (no basedir/params.db): the
  * entry used by the bench and tests for synthetic corpora.  `algo` is the
  * index default ("BM25" / "TF-IDF"); `lowercase` enables the ASCII part of

@@ -84,7 +84,7 @@ typedef struct {
 } nxsgpu_index_src_t;
 
 /* one resolved query */
-typedef struct {
+typedef struct nxsgpu_query {
 	uint32_t	n_tokens;			/* token-list order */
 	uint32_t	term_id[NXSGPU_MAX_TOKENS];
 	uint32_t	prog_len;

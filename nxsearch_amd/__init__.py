@@ -78,6 +78,7 @@ NXS_H_SYMBOLS = [
     "nxs_index_search", "nxs_resp_iter_reset", "nxs_resp_iter_result",
     "nxs_resp_resultcount", "nxs_resp_tojson", "nxs_resp_release",
     "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
+    "nxs_index_plan_batch",
 ]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -129,6 +130,9 @@ def lib():
     L.nxs_index_search_batch.restype = C.c_int
     L.nxs_index_search_batch.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t,
                                          C.POINTER(vp), C.POINTER(C.c_int)]
+    L.nxs_index_plan_batch.restype = C.c_int
+    L.nxs_index_plan_batch.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t,
+                                       C.POINTER(GpuQuery), C.POINTER(C.c_int)]
     L.nxs_resp_iter_reset.argtypes = [vp]
     L.nxs_resp_iter_result.restype = C.c_bool
     L.nxs_resp_iter_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
@@ -313,6 +317,33 @@ class Index:
             else:
                 out.append(NxsError(errs[i], "query %d failed" % i))
         return out
+
+    def plan_batch(self, queries, limit=None, algo=None, fuzzymatch=None):
+        """nxs_index_plan_batch(): -> (ctypes array of GpuQuery, [err codes])."""
+        L = lib()
+        n = len(queries)
+        qs = (C.c_char_p * n)(*[_b(q) for q in queries])
+        plans = (GpuQuery * max(n, 1))()
+        errs = (C.c_int * max(n, 1))()
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            r = L.nxs_index_plan_batch(self._h, p, qs, n, plans, errs)
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        if r < 0:
+            self.nxs._raise()
+        return plans, list(errs[:n])
+
+    def search_dev(self, plans, n, limit, algo, d_ids, d_scores, d_counts):
+        """nxsgpu_search_dev(): results stay on the device at the given raw
+        device pointers ([n][limit] u64 / f32, [n] u32).  Returns 0, or 1 if
+        some query needs the exact two-pass path."""
+        r = lib().nxsgpu_search_dev(self.device, algo, limit, plans, n,
+                                    d_ids, d_scores, d_counts)
+        if r < 0:
+            raise NxsError(1, lib().nxsgpu_last_error().decode())
+        return r
 
     def fuzzy(self, tokens, want_visited=False):
         """Device BK-tree search for raw tokens -> term ids (0 = none)."""

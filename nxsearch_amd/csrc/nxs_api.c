@@ -554,47 +554,22 @@ get_search_params(nxs_index_t *idx, nxs_params_t *params, search_params_t *sp)
 	return 0;
 }
 
-int
-nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
-    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+/*
+ * Front half of a batch: parse, build the token sets, resolve (exact on the
+ * host, misses through one device BK-tree pass), compile the device plans.
+ * prep[i].errcode / .empty tell how query i ended.
+ */
+static int
+plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
+    size_t n, qprep_t *prep)
 {
 	nxs_t *nxs = idx->nxs;
-	search_params_t sp;
-	qprep_t *prep = NULL;
-	nxsgpu_query_t *plans = NULL;
-	uint32_t *plan_of = NULL, *fz_q = NULL, *fz_t = NULL, *fz_off = NULL, *fz_ids = NULL;
+	uint32_t *fz_q = NULL, *fz_t = NULL, *fz_off = NULL, *fz_ids = NULL;
 	uint8_t *fz_bytes = NULL;
-	size_t n_fz = 0, fz_len = 0, n_plans = 0;
-	nxsgpu_results_t res;
-	int failed = 0, ret = -1;
+	size_t n_fz = 0, fz_len = 0;
+	int ret = -1;
 
-	nxs_clear_error(nxs);
-	memset(&res, 0, sizeof(res));
-	for (size_t i = 0; i < n; i++) {
-		resps[i] = NULL;
-		if (errs) {
-			errs[i] = NXS_ERR_SUCCESS;
-		}
-	}
-	if (get_search_params(idx, params, &sp) == -1) {
-		return -1;
-	}
-	if (n == 0) {
-		return 0;
-	}
-	if (n > UINT32_MAX / 2) {
-		nxs_decl_err(nxs, NXS_ERR_LIMIT, "batch too large");
-		return -1;
-	}
-	prep = calloc(n, sizeof(qprep_t));
-	plans = calloc(n, sizeof(nxsgpu_query_t));
-	plan_of = calloc(n, sizeof(uint32_t));
-	if (!prep || !plans || !plan_of) {
-		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
-		goto out;
-	}
-
-	/* parse, build the token sets, resolve exactly (idxterm_lookup) */
+	/* idxterm_lookup for every token */
 	for (size_t i = 0; i < n; i++) {
 		qprep_t *q = &prep[i];
 
@@ -605,7 +580,7 @@ nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
 		for (size_t j = 0; j < q->n_tokens; j++) {
 			qtok_t *t = &q->tokens[j];
 			t->term_id = nxs_term_lookup(idx, (const uint8_t *)t->value, t->len);
-			if (!t->term_id && sp.fuzzymatch) {
+			if (!t->term_id && sp->fuzzymatch) {
 				n_fz++;
 				fz_len += t->len;
 			}
@@ -649,12 +624,107 @@ nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
 			prep[fz_q[k]].tokens[fz_t[k]].term_id = fz_ids[k];
 		}
 	}
-
-	/* compile the plans */
 	for (size_t i = 0; i < n; i++) {
-		qprep_t *q = &prep[i];
+		if (!prep[i].errcode) {
+			(void)nxs_query_compile(&prep[i]);
+		}
+	}
+	ret = 0;
+out:
+	free(fz_q);
+	free(fz_t);
+	free(fz_off);
+	free(fz_ids);
+	free(fz_bytes);
+	return ret;
+}
 
-		if (!q->errcode && nxs_query_compile(q) == 0 && !q->empty) {
+int
+nxs_index_plan_batch(nxs_index_t *idx, nxs_params_t *params,
+    const char *const *queries, size_t n, struct nxsgpu_query *plans_out,
+    nxs_err_t *errs)
+{
+	nxsgpu_query_t *plans = (nxsgpu_query_t *)plans_out;
+	search_params_t sp;
+	qprep_t *prep;
+	int failed = 0;
+
+	nxs_clear_error(idx->nxs);
+	if (get_search_params(idx, params, &sp) == -1) {
+		return -1;
+	}
+	if ((prep = calloc(n ? n : 1, sizeof(qprep_t))) == NULL) {
+		nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
+		return -1;
+	}
+	if (plan_batch(idx, &sp, queries, n, prep) == -1) {
+		failed = -1;
+	}
+	for (size_t i = 0; i < n; i++) {
+		memset(&plans[i], 0, sizeof(plans[i]));
+		if (failed != -1) {
+			if (prep[i].errcode) {
+				failed++;
+				nxs_decl_err(idx->nxs, prep[i].errcode, "%s",
+				    prep[i].errmsg ? prep[i].errmsg : "");
+			} else if (!prep[i].empty) {
+				plans[i] = prep[i].plan;
+			}
+			if (errs) {
+				errs[i] = prep[i].errcode;
+			}
+		}
+		nxs_query_release(&prep[i]);
+	}
+	free(prep);
+	return failed;
+}
+
+int
+nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
+    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_t *nxs = idx->nxs;
+	search_params_t sp;
+	qprep_t *prep = NULL;
+	nxsgpu_query_t *plans = NULL;
+	uint32_t *plan_of = NULL;
+	size_t n_plans = 0;
+	nxsgpu_results_t res;
+	int failed = 0, ret = -1;
+
+	nxs_clear_error(nxs);
+	memset(&res, 0, sizeof(res));
+	for (size_t i = 0; i < n; i++) {
+		resps[i] = NULL;
+		if (errs) {
+			errs[i] = NXS_ERR_SUCCESS;
+		}
+	}
+	if (get_search_params(idx, params, &sp) == -1) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	if (n > UINT32_MAX / 2) {
+		nxs_decl_err(nxs, NXS_ERR_LIMIT, "batch too large");
+		return -1;
+	}
+	prep = calloc(n, sizeof(qprep_t));
+	plans = calloc(n, sizeof(nxsgpu_query_t));
+	plan_of = calloc(n, sizeof(uint32_t));
+	if (!prep || !plans || !plan_of) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	if (plan_batch(idx, &sp, queries, n, prep) == -1) {
+		goto out;
+	}
+	for (size_t i = 0; i < n; i++) {
+		const qprep_t *q = &prep[i];
+
+		if (!q->errcode && !q->empty) {
 			plan_of[i] = (uint32_t)n_plans;
 			plans[n_plans++] = q->plan;
 		}
@@ -711,11 +781,6 @@ out:
 	free(prep);
 	free(plans);
 	free(plan_of);
-	free(fz_q);
-	free(fz_t);
-	free(fz_off);
-	free(fz_ids);
-	free(fz_bytes);
 	return ret;
 }
 

@@ -568,6 +568,339 @@ k_scan(const scan_args_t A)
 	}
 }
 
+/*
+ * k_scan8: the <= 8 token fast path.  Same contract as k_scan, restructured
+ * for memory-level parallelism and for sparse tiles:
+ *  - every term keeps a 64-posting register window A (the next unconsumed
+ *    postings below its cursor) plus a prefetched window B, so each posting
+ *    is loaded from memory exactly once and every term always has a load in
+ *    flight (no per-tile binary search, no re-loading of windows);
+ *  - LDS updates are single DS atomics (ds_add_f32 / ds_or_rtn_b32), issued
+ *    in token order: one wavefront's DS operations execute in issue order and
+ *    a doc occurs once per term, so the f32 sum order is the reference's;
+ *  - the returned old mask tells a doc's FIRST touch in the tile; first-touched
+ *    docs go to a small LDS list, and a tile with few touched docs is scanned
+ *    through that list (cost ~ touched docs, not tile width).  Its candidates
+ *    are rank-sorted by doc before they are appended, so a segment still is in
+ *    descending doc order.  Dense tiles (list overflow) and tiles with more
+ *    than 64 candidates take the ordered full scan.
+ */
+#define	LIST_CAP	512
+#define	TCAND_CAP	64
+
+template <int MODE, int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scan8(const scan_args_t A)
+{
+	__shared__ float s_acc[TILE_W];
+	__shared__ uint32_t s_mask32[TILE_W / 4];
+	__shared__ uint16_t s_list[LIST_CAP];
+	__shared__ uint32_t s_cd[TCAND_CAP];
+	__shared__ float s_cs[TCAND_CAP];
+	__shared__ uint32_t s_truth[8];
+	__shared__ int64_t s_init[16];
+
+	const unsigned lane = threadIdx.x;
+	const uint64_t lane_lt = (1ull << lane) - 1;
+	const uint32_t q = blockIdx.y, g = blockIdx.x;
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint64_t seg = (uint64_t)q * A.n_groups + g;
+	const uint64_t dlo = (uint64_t)g * A.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)A.group_docs);
+	uint8_t *s_mask8 = (uint8_t *)s_mask32;
+
+	if (dlo >= A.n_docs) {
+		if (lane == 0 && MODE != MODE_ALL) {
+			A.seg_count[seg] = 0;
+		}
+		return;
+	}
+	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
+		s_acc[i] = 0.0f;
+	}
+	for (uint32_t i = lane; i < TILE_W / 4; i += WAVE) {
+		s_mask32[i] = 0;
+	}
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	/* cursors of this group's doc range, relative to the term's list */
+	if (lane < 16) {
+		const uint32_t t = lane & 7;
+		int64_t v = 0;
+		if (t < nt) {
+			const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+			v = (int64_t)(post_lower_bound(A.post, pb, pe, lane < 8 ? dhi : dlo) - pb);
+		}
+		s_init[lane] = v;
+	}
+	__syncthreads();
+
+	/*
+	 * Wave-uniform per-term state (readfirstlane keeps it scalar).  Window A
+	 * of term t covers the 64-aligned slice of its list holding posting
+	 * hi-1: lanes with index in [lo, hi) are unconsumed.
+	 */
+	const posting_t *pt[NT];
+	int32_t hi[NT], lo[NT], pdoc[NT];
+	uint32_t Ad[NT], Bd[NT];
+	float Ai[NT], Bi[NT];
+
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		pt[t] = A.post;
+		hi[t] = lo[t] = 0;
+		pdoc[t] = -1;
+		Ad[t] = Bd[t] = 0;
+		Ai[t] = Bi[t] = 0.0f;
+		if (t < (int)nt) {
+			pt[t] = A.post + Q->pbeg[t];
+			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
+			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
+			if (hi[t] > lo[t]) {
+				const int32_t ab = ((hi[t] - 1) >> 6) << 6;
+				const int32_t ia = ab + (int32_t)lane, ib = ia - WAVE;
+				if (ia >= lo[t] && ia < hi[t]) {
+					const posting_t p = pt[t][ia];
+					Ad[t] = p.doc; Ai[t] = p.imp;
+				}
+				if (ib >= lo[t]) {
+					const posting_t p = pt[t][ib];
+					Bd[t] = p.doc; Bi[t] = p.imp;
+				}
+				pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t], (hi[t] - 1) & 63);
+			}
+		}
+	}
+
+	float top = -INFINITY, thr = -INFINITY;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	for (;;) {
+		int32_t md = -1;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			md = max(md, pdoc[t]);
+		}
+		if (md < 0) {
+			break;
+		}
+		const uint32_t base = ((uint32_t)md / TILE_W) * TILE_W;
+		uint32_t n_list = 0;
+
+		/* accumulate, tokens strictly in token-list order (results.c:134-136) */
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
+				for (;;) {
+					const int32_t ab = ((hi[t] - 1) >> 6) << 6;
+					const int32_t idx = ab + (int32_t)lane;
+					const bool in = idx >= lo[t] && idx < hi[t] && Ad[t] >= base;
+					const uint32_t c = __popcll(__ballot(in));
+					const uint32_t d = Ad[t] - base;
+					bool first = false;
+					if (in) {
+						const uint32_t mb = mask_byte(d), sh = 8 * (mb & 3);
+						atomicAdd(&s_acc[d], Ai[t]);
+						const uint32_t old = atomicOr(&s_mask32[mb >> 2], (1u << t) << sh);
+						first = ((old >> sh) & 0xff) == 0;
+					}
+					const uint64_t fb = __ballot(first);
+					if (fb) {
+						const uint32_t nf = __popcll(fb);
+						if (n_list + nf <= LIST_CAP && first) {
+							s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)d;
+						}
+						n_list += nf;
+					}
+					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)c);
+					if (hi[t] == ab && hi[t] > lo[t]) {
+						/* window drained: rotate in the prefetched one */
+						Ad[t] = Bd[t]; Ai[t] = Bi[t];
+						const int32_t ib = ab - 2 * WAVE + (int32_t)lane;
+						Bd[t] = 0; Bi[t] = 0.0f;
+						if (ib >= lo[t]) {
+							const posting_t p = pt[t][ib];
+							Bd[t] = p.doc; Bi[t] = p.imp;
+						}
+						continue;
+					}
+					break;
+				}
+				pdoc[t] = -1;
+				if (hi[t] > lo[t]) {
+					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t], (hi[t] - 1) & 63);
+				}
+			}
+		}
+		__syncthreads();
+
+		bool full_scan = n_list > LIST_CAP;
+		if (!full_scan) {
+			/* sparse tile: visit only the touched docs */
+			uint32_t ncand = 0;
+			for (uint32_t off = 0; off < n_list && !full_scan; off += WAVE) {
+				const uint32_t i = off + lane;
+				const bool valid = i < n_list;
+				uint32_t d = 0, m = 0;
+				float sc = 0.0f;
+				if (valid) {
+					d = s_list[i];
+					m = s_mask8[mask_byte(d)];
+					sc = s_acc[d];
+				}
+				if (MODE == MODE_COUNT) {
+					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					n_out += __popcll(__ballot(match));
+					continue;
+				}
+				const bool pre = valid && (sc > thr);
+				if (__ballot(pre) == 0) {
+					continue;
+				}
+				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				const uint64_t bal = __ballot(cand);
+				if (!bal) {
+					continue;
+				}
+				const uint32_t ne = __popcll(bal);
+				if (ncand + ne > TCAND_CAP) {
+					full_scan = true;	/* nothing emitted or cleared yet */
+					break;
+				}
+				if (cand) {
+					const uint32_t slot = ncand + __popcll(bal & lane_lt);
+					s_cd[slot] = d;
+					s_cs[slot] = sc;
+				}
+				ncand += ne;
+			}
+			if (!full_scan) {
+				__syncthreads();
+				if (MODE != MODE_COUNT && ncand) {
+					/* rank by doc (descending) so the segment stays ordered */
+					uint32_t cd = 0, rank = 0;
+					float cs = 0.0f;
+					if (lane < ncand) {
+						cd = s_cd[lane];
+						cs = s_cs[lane];
+					}
+					for (uint32_t j = 0; j < ncand; j++) {
+						const uint32_t dj = __builtin_amdgcn_readlane((int)cd, j);
+						rank += dj > cd;
+					}
+					if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
+						ovf = true;
+					} else if (lane < ncand) {
+						const uint64_t o = out_base + n_out + rank;
+						A.cand_doc[o] = base + cd;
+						A.cand_sc[o] = cs;
+					}
+					n_out += ncand;
+					if (track) {
+						for (uint32_t j = 0; j < ncand; j++) {
+							const float v = __shfl(cs, (int)j);
+							if (v > thr) {
+								const uint32_t pos = __popcll(__ballot(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = __shfl(top, kidx);
+							}
+						}
+					}
+				}
+				/* clear what this tile touched */
+				for (uint32_t off = 0; off < n_list; off += WAVE) {
+					const uint32_t i = off + lane;
+					if (i < n_list) {
+						const uint32_t d = s_list[i];
+						s_acc[d] = 0.0f;
+						s_mask8[mask_byte(d)] = 0;
+					}
+				}
+			}
+		}
+		if (full_scan) {
+			/* dense tile: ordered scan, DESCENDING doc (results.c:143-147) */
+			for (int s = TILE_W / 256 - 1; s >= 0; s--) {
+				const uint32_t mw = s_mask32[s * WAVE + lane];
+				if (__ballot(mw != 0) == 0) {
+					continue;
+				}
+				if (mw) {
+					s_mask32[s * WAVE + lane] = 0;
+				}
+				for (int j = 3; j >= 0; j--) {
+					const uint32_t m = (mw >> (8 * j)) & 0xff;
+					if (__ballot(m != 0) == 0) {
+						continue;
+					}
+					const uint32_t d = s * 256 + j * 64 + lane;
+					float sc = 0.0f;
+					if (m) {
+						sc = s_acc[d];
+						s_acc[d] = 0.0f;
+					}
+					if (MODE == MODE_COUNT) {
+						const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
+						n_out += __popcll(__ballot(match));
+						continue;
+					}
+					const bool pre = m && (sc > thr);
+					if (__ballot(pre) == 0) {
+						continue;
+					}
+					const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					uint64_t bal = __ballot(cand);
+					if (!bal) {
+						continue;
+					}
+					const uint32_t ne = __popcll(bal);
+					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+						ovf = true;
+					} else {
+						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+						if (cand) {
+							const uint64_t o = out_base + n_out + __popcll(above);
+							A.cand_doc[o] = base + d;
+							A.cand_sc[o] = sc;
+						}
+					}
+					n_out += ne;
+					if (track) {
+						while (bal) {
+							const int L = 63 - __clzll(bal);
+							bal &= ~(1ull << L);
+							const float v = __shfl(sc, L);
+							if (v > thr) {
+								const uint32_t pos = __popcll(__ballot(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = __shfl(top, kidx);
+							}
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ */
 /* k_replay: the reference's heap, replayed exactly                     */
 /* ------------------------------------------------------------------ */
@@ -1283,13 +1616,29 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
 
 template <int MODE>
 static void
-launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t nq, bool wide)
+launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t nq, uint32_t max_nt)
 {
 	const dim3 grid(a.n_groups, nq), block(WAVE);
+	const bool wide = max_nt > 8;
 	if (wide) {
 		hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
 	} else {
-		hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
+		if (ix->n_docs < (1ull << 31) && !getenv("NXS_GPU_OLDSCAN")) {
+			/* NT = compile-time bound of the per-term register state */
+			if (max_nt <= 1) {
+				hipLaunchKernelGGL((k_scan8<MODE, 1>), grid, block, 0, ix->stream, a);
+			} else if (max_nt <= 2) {
+				hipLaunchKernelGGL((k_scan8<MODE, 2>), grid, block, 0, ix->stream, a);
+			} else if (max_nt <= 3) {
+				hipLaunchKernelGGL((k_scan8<MODE, 3>), grid, block, 0, ix->stream, a);
+			} else if (max_nt <= 5) {
+				hipLaunchKernelGGL((k_scan8<MODE, 5>), grid, block, 0, ix->stream, a);
+			} else {
+				hipLaunchKernelGGL((k_scan8<MODE, 8>), grid, block, 0, ix->stream, a);
+			}
+		} else {
+			hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
+		}
 	}
 }
 
@@ -1298,7 +1647,7 @@ pick_groups(const nxsgpu_index_t *ix, uint32_t nq, uint32_t *group_docs)
 {
 	const uint64_t tiles = (ix->n_docs + TILE_W - 1) / TILE_W;
 	const char *env = getenv("NXS_GPU_WAVES");
-	const uint64_t target = env ? strtoull(env, NULL, 10) : 16384;
+	const uint64_t target = env ? strtoull(env, NULL, 10) : 65536;
 	uint64_t g = std::max<uint64_t>(1, target / std::max<uint32_t>(nq, 1));
 
 	g = std::min<uint64_t>(g, std::max<uint64_t>(tiles, 1));
@@ -1327,7 +1676,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	const uint64_t nseg = (uint64_t)nq * G;
 	std::vector<dev_query_t> hq(nq);
 	std::vector<uint32_t> h_ovf, h_cnt;
-	bool wide = false;
+	uint32_t max_nt = 0;
 	uint64_t total_post = 0;
 	uint8_t *p;
 	dev_query_t *d_q;
@@ -1381,9 +1730,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			d.pend[t] = ix->h_post_off[tid + 1];
 			total_post += d.pend[t] - d.pbeg[t];
 		}
-		if (d.nt > 8) {
-			wide = true;
-		}
+		max_nt = std::max(max_nt, d.nt);
 	}
 
 	/* workspace: queries | seg_count | overflow | fast candidates | fast outputs */
@@ -1428,7 +1775,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	h_ovf.assign(nq, 0);
 	if (fast) {
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
-		launch_scan<MODE_TOPK>(ix, sa, nq, wide);
+		launch_scan<MODE_TOPK>(ix, sa, nq, max_nt);
 		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
 
 		memset(&ra, 0, sizeof(ra));
@@ -1528,15 +1875,13 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
 		void *xws = NULL;
 		uint8_t *xp;
-		bool xwide = false;
+		uint32_t xmax_nt = 0;
 		size_t xneed;
 		int rc = -1;
 
 		for (uint32_t j = 0; j < nx; j++) {
 			xhq[j] = hq[xq[j]];
-			if (xhq[j].nt > 8) {
-				xwide = true;
-			}
+			xmax_nt = std::max(xmax_nt, xhq[j].nt);
 		}
 		/* pass 1: count */
 		if (hipMemcpyAsync(d_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
@@ -1544,7 +1889,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			return -1;
 		}
 		sa.k = 0xffffffffu;
-		launch_scan<MODE_COUNT>(ix, sa, nx, xwide);
+		launch_scan<MODE_COUNT>(ix, sa, nx, xmax_nt);
 		if (hipMemcpyAsync(sc_cnt.data(), d_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {
 			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1593,7 +1938,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			sb.seg_off = dx_seg_off;
 			sb.cand_doc = dx_cdoc;
 			sb.cand_sc = dx_csc;
-			launch_scan<MODE_ALL>(ix, sb, nx, xwide);
+			launch_scan<MODE_ALL>(ix, sb, nx, xmax_nt);
 			memset(&ra, 0, sizeof(ra));
 			ra.n_groups = G;
 			ra.seg_cap = 0;

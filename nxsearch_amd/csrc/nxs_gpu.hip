@@ -264,16 +264,21 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 
 enum { MODE_TOPK = 0, MODE_COUNT = 1, MODE_ALL = 2 };
 
+/* a query's doc space is cut into n_groups ranges of group_docs docs; one
+ * wavefront (work item) per range; its candidates go to segment seg_first+g */
+struct qmeta_t { uint32_t seg_first, n_groups, group_docs, pad; };
+struct item_t { uint32_t q, g; };
+
 struct scan_args_t {
 	const posting_t *	post;
 	const dev_query_t *	queries;
 	uint64_t		n_docs;
-	uint32_t		n_groups;
-	uint32_t		group_docs;	/* multiple of TILE_W */
+	const qmeta_t *		qmeta;		/* [Q] */
+	const item_t *		items;		/* [grid] (query, group) work items */
 	uint32_t		k;		/* limit (<= 64 in MODE_TOPK) */
 	uint32_t		seg_cap;
-	uint32_t *		seg_count;	/* [Q*G] */
-	const uint64_t *	seg_off;	/* [Q*G+1] (MODE_ALL) */
+	uint32_t *		seg_count;	/* [segments] */
+	const uint64_t *	seg_off;	/* [segments+1] (MODE_ALL) */
 	uint32_t *		cand_doc;
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
@@ -334,20 +339,15 @@ k_scan(const scan_args_t A)
 	__shared__ uint8_t s_prog[NXSGPU_MAX_PROG];
 
 	const unsigned lane = threadIdx.x;
-	const uint32_t q = blockIdx.y, g = blockIdx.x;
+	const item_t item = A.items[blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];
 	const uint32_t nt = Q->nt;
 	const posting_t *__restrict__ post = A.post;
-	const uint64_t seg = (uint64_t)q * A.n_groups + g;
-	const uint64_t dlo = (uint64_t)g * A.group_docs;
-	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)A.group_docs);
-
-	if (dlo >= A.n_docs) {
-		if (lane == 0 && MODE != MODE_ALL) {
-			A.seg_count[seg] = 0;
-		}
-		return;
-	}
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
 
 	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 		s_acc[i] = 0.0f;
@@ -575,10 +575,10 @@ k_scan(const scan_args_t A)
  *    postings below its cursor) plus a prefetched window B, so each posting
  *    is loaded from memory exactly once and every term always has a load in
  *    flight (no per-tile binary search, no re-loading of windows);
- *  - LDS updates are single DS atomics (ds_add_f32 / ds_or_rtn_b32), issued
- *    in token order: one wavefront's DS operations execute in issue order and
- *    a doc occurs once per term, so the f32 sum order is the reference's;
- *  - the returned old mask tells a doc's FIRST touch in the tile; first-touched
+ *  - LDS updates are plain read-add-write in token order: one wavefront's DS
+ *    operations execute in issue order and a doc occurs once per term, so the
+ *    f32 sum order is the reference's (DS atomics were measured 10x slower);
+ *  - the old mask byte tells a doc's FIRST touch in the tile; first-touched
  *    docs go to a small LDS list, and a tile with few touched docs is scanned
  *    through that list (cost ~ touched docs, not tile width).  Its candidates
  *    are rank-sorted by doc before they are appended, so a segment still is in
@@ -602,20 +602,15 @@ k_scan8(const scan_args_t A)
 
 	const unsigned lane = threadIdx.x;
 	const uint64_t lane_lt = (1ull << lane) - 1;
-	const uint32_t q = blockIdx.y, g = blockIdx.x;
+	const item_t item = A.items[blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];
 	const uint32_t nt = Q->nt;
-	const uint64_t seg = (uint64_t)q * A.n_groups + g;
-	const uint64_t dlo = (uint64_t)g * A.group_docs;
-	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)A.group_docs);
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
 	uint8_t *s_mask8 = (uint8_t *)s_mask32;
-
-	if (dlo >= A.n_docs) {
-		if (lane == 0 && MODE != MODE_ALL) {
-			A.seg_count[seg] = 0;
-		}
-		return;
-	}
 	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 		s_acc[i] = 0.0f;
 	}
@@ -642,34 +637,38 @@ k_scan8(const scan_args_t A)
 	 * of term t covers the 64-aligned slice of its list holding posting
 	 * hi-1: lanes with index in [lo, hi) are unconsumed.
 	 */
+	/* prefetch depth: fewer terms leave registers for more windows in flight */
+	constexpr int PF = NT <= 1 ? 6 : NT <= 2 ? 4 : NT <= 3 ? 3 : NT <= 5 ? 2 : 1;
 	const posting_t *pt[NT];
 	int32_t hi[NT], lo[NT], pdoc[NT];
-	uint32_t Ad[NT], Bd[NT];
-	float Ai[NT], Bi[NT];
+	uint32_t Wd[NT][PF + 1];	/* [0] = window A, [1..PF] = prefetched */
+	float Wi[NT][PF + 1];
 
 #pragma unroll
 	for (int t = 0; t < NT; t++) {
 		pt[t] = A.post;
 		hi[t] = lo[t] = 0;
 		pdoc[t] = -1;
-		Ad[t] = Bd[t] = 0;
-		Ai[t] = Bi[t] = 0.0f;
+#pragma unroll
+		for (int j = 0; j <= PF; j++) {
+			Wd[t][j] = 0;
+			Wi[t][j] = 0.0f;
+		}
 		if (t < (int)nt) {
 			pt[t] = A.post + Q->pbeg[t];
 			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
 			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
 			if (hi[t] > lo[t]) {
 				const int32_t ab = ((hi[t] - 1) >> 6) << 6;
-				const int32_t ia = ab + (int32_t)lane, ib = ia - WAVE;
-				if (ia >= lo[t] && ia < hi[t]) {
-					const posting_t p = pt[t][ia];
-					Ad[t] = p.doc; Ai[t] = p.imp;
+#pragma unroll
+				for (int j = 0; j <= PF; j++) {
+					const int32_t ix = ab - j * WAVE + (int32_t)lane;
+					if (ix >= lo[t] && ix < hi[t]) {
+						const posting_t p = pt[t][ix];
+						Wd[t][j] = p.doc; Wi[t][j] = p.imp;
+					}
 				}
-				if (ib >= lo[t]) {
-					const posting_t p = pt[t][ib];
-					Bd[t] = p.doc; Bi[t] = p.imp;
-				}
-				pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t], (hi[t] - 1) & 63);
+				pdoc[t] = __builtin_amdgcn_readlane((int)Wd[t][0], (hi[t] - 1) & 63);
 			}
 		}
 	}
@@ -700,33 +699,46 @@ k_scan8(const scan_args_t A)
 				for (;;) {
 					const int32_t ab = ((hi[t] - 1) >> 6) << 6;
 					const int32_t idx = ab + (int32_t)lane;
-					const bool in = idx >= lo[t] && idx < hi[t] && Ad[t] >= base;
+					const bool in = idx >= lo[t] && idx < hi[t] && Wd[t][0] >= base;
 					const uint32_t c = __popcll(__ballot(in));
-					const uint32_t d = Ad[t] - base;
+					const uint32_t d = Wd[t][0] - base;
+					/* plain read-modify-write: a doc occurs once per term, so
+					 * no two lanes share an accumulator, and one wavefront's DS
+					 * operations execute in issue order (LDS atomics would
+					 * serialise the lanes: measured 200 LDS cycles/window) */
 					bool first = false;
 					if (in) {
-						const uint32_t mb = mask_byte(d), sh = 8 * (mb & 3);
-						atomicAdd(&s_acc[d], Ai[t]);
-						const uint32_t old = atomicOr(&s_mask32[mb >> 2], (1u << t) << sh);
-						first = ((old >> sh) & 0xff) == 0;
+						const uint32_t mb = mask_byte(d);
+						const float a0 = s_acc[d];
+						const uint32_t m0 = s_mask8[mb];
+						s_acc[d] = a0 + Wi[t][0];
+						s_mask8[mb] = (uint8_t)(m0 | (1u << t));
+						first = m0 == 0;
 					}
-					const uint64_t fb = __ballot(first);
-					if (fb) {
-						const uint32_t nf = __popcll(fb);
-						if (n_list + nf <= LIST_CAP && first) {
-							s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)d;
+					if (n_list <= LIST_CAP) {
+						const uint64_t fb = __ballot(first);
+						if (fb) {
+							const uint32_t nf = __popcll(fb);
+							if (n_list + nf <= LIST_CAP && first) {
+								s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)d;
+							}
+							n_list += nf;
 						}
-						n_list += nf;
 					}
 					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)c);
 					if (hi[t] == ab && hi[t] > lo[t]) {
-						/* window drained: rotate in the prefetched one */
-						Ad[t] = Bd[t]; Ai[t] = Bi[t];
-						const int32_t ib = ab - 2 * WAVE + (int32_t)lane;
-						Bd[t] = 0; Bi[t] = 0.0f;
+						/* window drained: shift the prefetched ones down,
+						 * issue the next load at the far end */
+#pragma unroll
+						for (int j = 0; j < PF; j++) {
+							Wd[t][j] = Wd[t][j + 1];
+							Wi[t][j] = Wi[t][j + 1];
+						}
+						const int32_t ib = ab - (PF + 1) * WAVE + (int32_t)lane;
+						Wd[t][PF] = 0; Wi[t][PF] = 0.0f;
 						if (ib >= lo[t]) {
 							const posting_t p = pt[t][ib];
-							Bd[t] = p.doc; Bi[t] = p.imp;
+							Wd[t][PF] = p.doc; Wi[t][PF] = p.imp;
 						}
 						continue;
 					}
@@ -734,7 +746,7 @@ k_scan8(const scan_args_t A)
 				}
 				pdoc[t] = -1;
 				if (hi[t] > lo[t]) {
-					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t], (hi[t] - 1) & 63);
+					pdoc[t] = __builtin_amdgcn_readlane((int)Wd[t][0], (hi[t] - 1) & 63);
 				}
 			}
 		}
@@ -970,7 +982,7 @@ heap_add(float *hs, uint32_t *hd, uint32_t *nitems, uint32_t cap, float s, uint3
 }
 
 struct replay_args_t {
-	uint32_t		n_groups;
+	const qmeta_t *		qmeta;
 	uint32_t		seg_cap;	/* 0 => segments addressed by seg_off */
 	const uint32_t *	seg_count;
 	const uint64_t *	seg_off;
@@ -1023,8 +1035,9 @@ k_replay(const replay_args_t A)
 	__syncthreads();
 
 	/* candidates: groups in descending doc range, each already descending */
-	for (int g = (int)A.n_groups - 1; g >= 0 && cap; g--) {
-		const uint64_t seg = (uint64_t)q * A.n_groups + g;
+	const qmeta_t qm = A.qmeta[q];
+	for (int g = (int)qm.n_groups - 1; g >= 0 && cap; g--) {
+		const uint64_t seg = (uint64_t)qm.seg_first + g;
 		const uint64_t sb = A.seg_cap ? seg * A.seg_cap : A.seg_off[seg];
 		const uint32_t n = A.seg_cap ? A.seg_count[seg]
 		    : (uint32_t)(A.seg_off[seg + 1] - A.seg_off[seg]);
@@ -1616,10 +1629,14 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
 
 template <int MODE>
 static void
-launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t nq, uint32_t max_nt)
+launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t n_items, uint32_t max_nt)
 {
-	const dim3 grid(a.n_groups, nq), block(WAVE);
+	const dim3 grid(n_items), block(WAVE);
 	const bool wide = max_nt > 8;
+
+	if (n_items == 0) {
+		return;
+	}
 	if (wide) {
 		hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
 	} else {
@@ -1642,20 +1659,77 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t nq, uint32_t max_
 	}
 }
 
-static uint32_t
-pick_groups(const nxsgpu_index_t *ix, uint32_t nq, uint32_t *group_docs)
+/*
+ * Work decomposition: every query's doc space is cut into n_groups equal
+ * ranges (multiples of TILE_W), one wavefront each.  The number of ranges is
+ * proportional to the query's share of the batch's postings, so a query with
+ * long lists gets many wavefronts and a sparse one a single one (whose fixed
+ * costs -- cursor searches, warm-up of the candidate threshold -- are then
+ * paid once).  Items are emitted heaviest query first.
+ */
+struct worklist_t {
+	std::vector<qmeta_t>	qmeta;
+	std::vector<item_t>	items;
+	uint32_t		n_segs;
+};
+
+static void
+build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, worklist_t &wl)
 {
-	const uint64_t tiles = (ix->n_docs + TILE_W - 1) / TILE_W;
+	const uint32_t nq = (uint32_t)hq.size();
+	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
 	const char *env = getenv("NXS_GPU_WAVES");
 	const uint64_t target = env ? strtoull(env, NULL, 10) : 65536;
-	uint64_t g = std::max<uint64_t>(1, target / std::max<uint32_t>(nq, 1));
+	const char *env2 = getenv("NXS_GPU_MINPOST");
+	const uint64_t min_post = env2 ? strtoull(env2, NULL, 10) : 8192;
+	std::vector<uint64_t> work(nq);
+	std::vector<uint32_t> order(nq);
+	uint64_t total = 0;
 
-	g = std::min<uint64_t>(g, std::max<uint64_t>(tiles, 1));
-	g = std::min<uint64_t>(g, 65535);
-	uint64_t tiles_per = (std::max<uint64_t>(tiles, 1) + g - 1) / g;
-	g = (std::max<uint64_t>(tiles, 1) + tiles_per - 1) / tiles_per;
-	*group_docs = (uint32_t)(tiles_per * TILE_W);
-	return (uint32_t)g;
+	for (uint32_t i = 0; i < nq; i++) {
+		uint64_t w = 0;
+		for (uint32_t t = 0; t < hq[i].nt; t++) {
+			w += hq[i].pend[t] - hq[i].pbeg[t];
+		}
+		work[i] = w;
+		total += w;
+		order[i] = i;
+	}
+	/* postings per wavefront: the batch spread over `target` wavefronts, but
+	 * not so few that the fixed per-wavefront cost dominates */
+	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
+	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+		return work[x] != work[y] ? work[x] > work[y] : x < y;
+	});
+	wl.qmeta.assign(nq, qmeta_t());
+	wl.items.clear();
+	wl.n_segs = 0;
+	for (uint32_t i = 0; i < nq; i++) {
+		uint64_t g = std::max<uint64_t>(1, (work[i] + per_wave - 1) / per_wave);
+		g = std::min<uint64_t>(g, tiles);
+		g = std::min<uint64_t>(g, 65535);
+		const uint64_t tiles_per = (tiles + g - 1) / g;
+		g = (tiles + tiles_per - 1) / tiles_per;
+		qmeta_t &m = wl.qmeta[i];
+		m.n_groups = (uint32_t)g;
+		m.group_docs = (uint32_t)std::min<uint64_t>(tiles_per * TILE_W, 0xffffffffu & ~(uint64_t)(TILE_W - 1));
+		m.pad = 0;
+	}
+	for (uint32_t i = 0; i < nq; i++) {
+		wl.qmeta[i].seg_first = wl.n_segs;
+		wl.n_segs += wl.qmeta[i].n_groups;
+	}
+	wl.items.reserve(wl.n_segs);
+	for (uint32_t oi = 0; oi < nq; oi++) {
+		const uint32_t i = order[oi];
+		/* descending ranges first: they are replayed first */
+		for (uint32_t g = wl.qmeta[i].n_groups; g-- > 0; ) {
+			item_t it;
+			it.q = i;
+			it.g = g;
+			wl.items.push_back(it);
+		}
+	}
 }
 
 /*
@@ -1671,17 +1745,17 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
 	const bool fast = limit <= NXSGPU_FAST_K;
 	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
-	uint32_t group_docs = 0;
-	const uint32_t G = pick_groups(ix, nq, &group_docs);
-	const uint64_t nseg = (uint64_t)nq * G;
 	std::vector<dev_query_t> hq(nq);
 	std::vector<uint32_t> h_ovf, h_cnt;
+	worklist_t wl;
 	uint32_t max_nt = 0;
 	uint64_t total_post = 0;
 	uint8_t *p;
 	dev_query_t *d_q;
+	qmeta_t *d_qmeta;
+	item_t *d_items;
 	uint32_t *d_seg_count, *d_cand_doc, *d_ovf, *d_cnt;
-	uint64_t *d_seg_off, *d_ids;
+	uint64_t *d_ids;
 	float *d_cand_sc, *d_sc;
 	scan_args_t sa;
 	replay_args_t ra;
@@ -1732,10 +1806,13 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		}
 		max_nt = std::max(max_nt, d.nt);
 	}
+	build_worklist(ix, hq, wl);
+	const uint64_t nseg = wl.n_segs;
 
-	/* workspace: queries | seg_count | overflow | fast candidates | fast outputs */
+	/* workspace: queries | meta | items | seg_count | overflow | candidates | outputs */
 	{
-		size_t need = 4096 + nq * sizeof(dev_query_t) + nseg * 4 + (nseg + 1) * 8 + nq * 4
+		size_t need = 8192 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
+		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
 		if (!ensure_ws(ix, need)) {
 			return -1;
@@ -1743,8 +1820,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	}
 	p = (uint8_t *)ix->ws;
 	d_q = carve<dev_query_t>(p, nq);
+	d_qmeta = carve<qmeta_t>(p, nq);
+	d_items = carve<item_t>(p, nseg);
 	d_seg_count = carve<uint32_t>(p, nseg);
-	d_seg_off = carve<uint64_t>(p, nseg + 1);
 	d_ovf = carve<uint32_t>(p, nq);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
@@ -1753,6 +1831,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	d_cnt = dev_out ? d_out_cnt : carve<uint32_t>(p, nq);
 
 	if (hipMemcpyAsync(d_q, hq.data(), nq * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+	    hipMemcpyAsync(d_items, wl.items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
@@ -1762,12 +1842,12 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.post = ix->d_post[algo];
 	sa.queries = d_q;
 	sa.n_docs = ix->n_docs;
-	sa.n_groups = G;
-	sa.group_docs = group_docs;
+	sa.qmeta = d_qmeta;
+	sa.items = d_items;
 	sa.k = kfast;
 	sa.seg_cap = seg_cap;
 	sa.seg_count = d_seg_count;
-	sa.seg_off = d_seg_off;
+	sa.seg_off = NULL;
 	sa.cand_doc = d_cand_doc;
 	sa.cand_sc = d_cand_sc;
 	sa.overflow = d_ovf;
@@ -1775,11 +1855,11 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	h_ovf.assign(nq, 0);
 	if (fast) {
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
-		launch_scan<MODE_TOPK>(ix, sa, nq, max_nt);
+		launch_scan<MODE_TOPK>(ix, sa, (uint32_t)nseg, max_nt);
 		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
 
 		memset(&ra, 0, sizeof(ra));
-		ra.n_groups = G;
+		ra.qmeta = d_qmeta;
 		ra.seg_cap = seg_cap;
 		ra.seg_count = d_seg_count;
 		ra.cand_doc = d_cand_doc;
@@ -1869,10 +1949,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	std::vector<float> x_sc;
 	if (!xq.empty()) {
 		const uint32_t nx = (uint32_t)xq.size();
-		const uint64_t xseg = (uint64_t)nx * G;
 		std::vector<dev_query_t> xhq(nx);
-		std::vector<uint32_t> sc_cnt(xseg);
-		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
+		worklist_t xwl;
 		void *xws = NULL;
 		uint8_t *xp;
 		uint32_t xmax_nt = 0;
@@ -1883,23 +1961,53 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			xhq[j] = hq[xq[j]];
 			xmax_nt = std::max(xmax_nt, xhq[j].nt);
 		}
+		build_worklist(ix, xhq, xwl);
+		const uint64_t xseg = xwl.n_segs;
+		std::vector<uint32_t> sc_cnt(xseg);
+		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
+
+		/* device copies of the subset's queries / work list */
+		void *xmeta = NULL;
+		{
+			const size_t mneed = 4096 + nx * sizeof(dev_query_t) + nx * sizeof(qmeta_t)
+			    + xseg * sizeof(item_t) + xseg * 4;
+			if (hipMalloc(&xmeta, mneed) != hipSuccess) {
+				set_error("hipMalloc(%zu) for the exact pass failed", mneed);
+				return -1;
+			}
+		}
+		uint8_t *mp = (uint8_t *)xmeta;
+		dev_query_t *dx_q = carve<dev_query_t>(mp, nx);
+		qmeta_t *dx_qmeta = carve<qmeta_t>(mp, nx);
+		item_t *dx_items = carve<item_t>(mp, xseg);
+		uint32_t *dx_seg_count = carve<uint32_t>(mp, xseg);
+
 		/* pass 1: count */
-		if (hipMemcpyAsync(d_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+		if (hipMemcpyAsync(dx_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_qmeta, xwl.qmeta.data(), nx * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
 			set_error("query upload failed");
+			(void)hipFree(xmeta);
 			return -1;
 		}
+		sa.queries = dx_q;
+		sa.qmeta = dx_qmeta;
+		sa.items = dx_items;
+		sa.seg_count = dx_seg_count;
 		sa.k = 0xffffffffu;
-		launch_scan<MODE_COUNT>(ix, sa, nx, xmax_nt);
-		if (hipMemcpyAsync(sc_cnt.data(), d_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		launch_scan<MODE_COUNT>(ix, sa, (uint32_t)xseg, xmax_nt);
+		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {
 			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
+			(void)hipFree(xmeta);
 			return -1;
 		}
-		for (uint64_t s = 0; s < xseg; s++) {
-			sc_off[s + 1] = sc_off[s] + sc_cnt[s];
+		for (uint64_t sgi = 0; sgi < xseg; sgi++) {
+			sc_off[sgi + 1] = sc_off[sgi] + sc_cnt[sgi];
 		}
 		for (uint32_t j = 0; j < nx; j++) {
-			const uint64_t matched = sc_off[(uint64_t)(j + 1) * G] - sc_off[(uint64_t)j * G];
+			const qmeta_t &m = xwl.qmeta[j];
+			const uint64_t matched = sc_off[(uint64_t)m.seg_first + m.n_groups] - sc_off[m.seg_first];
 			const uint64_t hcap = std::min<uint64_t>(limit, matched);
 			hp_off[j + 1] = hp_off[j] + hcap;
 			o_off[j + 1] = o_off[j] + hcap;
@@ -1908,6 +2016,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		xneed = 8192 + (xseg + 1) * 8 + tot_c * 8 + tot_o * 8 * 2 + tot_o * 12 + (nx + 1) * 16 + nx * 4;
 		if (hipMalloc(&xws, xneed) != hipSuccess) {
 			set_error("hipMalloc(%zu) for the exact pass failed", xneed);
+			(void)hipFree(xmeta);
 			return -1;
 		}
 		xp = (uint8_t *)xws;
@@ -1938,9 +2047,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			sb.seg_off = dx_seg_off;
 			sb.cand_doc = dx_cdoc;
 			sb.cand_sc = dx_csc;
-			launch_scan<MODE_ALL>(ix, sb, nx, xmax_nt);
+			launch_scan<MODE_ALL>(ix, sb, (uint32_t)xseg, xmax_nt);
 			memset(&ra, 0, sizeof(ra));
-			ra.n_groups = G;
+			ra.qmeta = dx_qmeta;
 			ra.seg_cap = 0;
 			ra.seg_off = dx_seg_off;
 			ra.cand_doc = dx_cdoc;
@@ -1969,6 +2078,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			rc = 0;
 		} while (0);
 		(void)hipFree(xws);
+		(void)hipFree(xmeta);
 		if (rc != 0) {
 			return -1;
 		}

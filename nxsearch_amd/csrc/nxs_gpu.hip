@@ -282,6 +282,7 @@ struct scan_args_t {
 	uint32_t *		cand_doc;
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
+	uint32_t		ablate;		/* timing experiments only (NXS_GPU_ABLATE) */
 };
 
 /* lower bound of `doc` in post[lo, hi) by doc ordinal */
@@ -637,12 +638,19 @@ k_scan8(const scan_args_t A)
 	 * of term t covers the 64-aligned slice of its list holding posting
 	 * hi-1: lanes with index in [lo, hi) are unconsumed.
 	 */
-	/* prefetch depth: fewer terms leave registers for more windows in flight */
-	constexpr int PF = NT <= 1 ? 6 : NT <= 2 ? 4 : NT <= 3 ? 3 : NT <= 5 ? 2 : 1;
+	/*
+	 * Each term streams its list through two register sets of K 64-posting
+	 * windows: set A (the 64K-aligned slice holding posting hi-1, being
+	 * consumed) and set B (the slice below it, K loads in flight).  Fewer
+	 * terms leave registers for deeper sets.
+	 */
+	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : NT <= 5 ? 1 : 0;
+	constexpr int K = 1 << KSH;
+	constexpr int SW = WAVE * K;
 	const posting_t *pt[NT];
 	int32_t hi[NT], lo[NT], pdoc[NT];
-	uint32_t Wd[NT][PF + 1];	/* [0] = window A, [1..PF] = prefetched */
-	float Wi[NT][PF + 1];
+	uint32_t Ad[NT][K], Bd[NT][K];
+	float Ai[NT][K], Bi[NT][K];
 
 #pragma unroll
 	for (int t = 0; t < NT; t++) {
@@ -650,25 +658,35 @@ k_scan8(const scan_args_t A)
 		hi[t] = lo[t] = 0;
 		pdoc[t] = -1;
 #pragma unroll
-		for (int j = 0; j <= PF; j++) {
-			Wd[t][j] = 0;
-			Wi[t][j] = 0.0f;
+		for (int k = 0; k < K; k++) {
+			Ad[t][k] = Bd[t][k] = 0;
+			Ai[t][k] = Bi[t][k] = 0.0f;
 		}
 		if (t < (int)nt) {
 			pt[t] = A.post + Q->pbeg[t];
 			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
 			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
 			if (hi[t] > lo[t]) {
-				const int32_t ab = ((hi[t] - 1) >> 6) << 6;
+				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
 #pragma unroll
-				for (int j = 0; j <= PF; j++) {
-					const int32_t ix = ab - j * WAVE + (int32_t)lane;
-					if (ix >= lo[t] && ix < hi[t]) {
-						const posting_t p = pt[t][ix];
-						Wd[t][j] = p.doc; Wi[t][j] = p.imp;
+				for (int k = 0; k < K; k++) {
+					const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
+					if (ia >= lo[t] && ia < hi[t]) {
+						const posting_t p = pt[t][ia];
+						Ad[t][k] = p.doc; Ai[t][k] = p.imp;
+					}
+					if (ib >= lo[t]) {
+						const posting_t p = pt[t][ib];
+						Bd[t][k] = p.doc; Bi[t][k] = p.imp;
 					}
 				}
-				pdoc[t] = __builtin_amdgcn_readlane((int)Wd[t][0], (hi[t] - 1) & 63);
+				const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+				for (int k = 0; k < K; k++) {
+					if (k == kt) {
+						pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+					}
+				}
 			}
 		}
 	}
@@ -691,54 +709,87 @@ k_scan8(const scan_args_t A)
 		}
 		const uint32_t base = ((uint32_t)md / TILE_W) * TILE_W;
 		uint32_t n_list = 0;
+		float tmax = -INFINITY;		/* largest accumulator value written in this tile */
 
 		/* accumulate, tokens strictly in token-list order (results.c:134-136) */
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
 				for (;;) {
-					const int32_t ab = ((hi[t] - 1) >> 6) << 6;
-					const int32_t idx = ab + (int32_t)lane;
-					const bool in = idx >= lo[t] && idx < hi[t] && Wd[t][0] >= base;
-					const uint32_t c = __popcll(__ballot(in));
-					const uint32_t d = Wd[t][0] - base;
-					/* plain read-modify-write: a doc occurs once per term, so
-					 * no two lanes share an accumulator, and one wavefront's DS
-					 * operations execute in issue order (LDS atomics would
-					 * serialise the lanes: measured 200 LDS cycles/window) */
-					bool first = false;
-					if (in) {
-						const uint32_t mb = mask_byte(d);
-						const float a0 = s_acc[d];
-						const uint32_t m0 = s_mask8[mb];
-						s_acc[d] = a0 + Wi[t][0];
-						s_mask8[mb] = (uint8_t)(m0 | (1u << t));
-						first = m0 == 0;
-					}
-					if (n_list <= LIST_CAP) {
-						const uint64_t fb = __ballot(first);
-						if (fb) {
-							const uint32_t nf = __popcll(fb);
-							if (n_list + nf <= LIST_CAP && first) {
-								s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)d;
-							}
-							n_list += nf;
-						}
-					}
-					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)c);
-					if (hi[t] == ab && hi[t] > lo[t]) {
-						/* window drained: shift the prefetched ones down,
-						 * issue the next load at the far end */
+					const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+					bool in[K];
+					float a0[K];
+					uint32_t m0[K], dd[K];
+					uint32_t ctot = 0, act = 0;	/* act: windows with in-tile postings (uniform) */
+					bool more = true;	/* windows below may still be in the tile */
+
+					/*
+					 * Read phase, top window first.  A doc occurs once per
+					 * term, so the K windows touch distinct accumulators and
+					 * their LDS reads can all be in flight together.
+					 */
 #pragma unroll
-						for (int j = 0; j < PF; j++) {
-							Wd[t][j] = Wd[t][j + 1];
-							Wi[t][j] = Wi[t][j + 1];
+					for (int k = K - 1; k >= 0; k--) {
+						if (more && hi[t] > ab + k * WAVE) {
+							const int32_t idx = ab + k * WAVE + (int32_t)lane;
+							in[k] = idx >= lo[t] && idx < hi[t] && Ad[t][k] >= base;
+							const uint32_t c = __popcll(__ballot(in[k]));
+							const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
+							const int32_t bot_ = max(lo[t], ab + k * WAVE);
+							ctot += c;
+							if ((int32_t)c < top_ - bot_) {
+								more = false;	/* tile boundary inside this window */
+							}
+							if (c) {
+								act |= 1u << k;
+								dd[k] = Ad[t][k] - base;
+								if (in[k] && !(A.ablate & 2)) {
+									a0[k] = s_acc[dd[k]];
+									m0[k] = s_mask8[dd[k]];
+								}
+							}
 						}
-						const int32_t ib = ab - (PF + 1) * WAVE + (int32_t)lane;
-						Wd[t][PF] = 0; Wi[t][PF] = 0.0f;
-						if (ib >= lo[t]) {
-							const posting_t p = pt[t][ib];
-							Wd[t][PF] = p.doc; Wi[t][PF] = p.imp;
+					}
+					/* write phase: plain read-add-write (DS atomics serialise
+					 * the lanes: measured ~200 LDS cycles per window) */
+#pragma unroll
+					for (int k = K - 1; k >= 0; k--) {
+						if (act & (1u << k)) {
+							bool first = false;
+							if (in[k] && !(A.ablate & 2)) {
+								const float v = a0[k] + Ai[t][k];
+								s_acc[dd[k]] = v;
+								s_mask8[dd[k]] = (uint8_t)(m0[k] | (1u << t));
+								first = m0[k] == 0;
+								tmax = fmaxf(tmax, v);
+							}
+							if (n_list <= LIST_CAP) {
+								const uint64_t fb = __ballot(first);
+								const uint32_t nf = __popcll(fb);
+								if (n_list + nf <= LIST_CAP && first) {
+									s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)dd[k];
+								}
+								n_list += nf;
+							}
+						}
+					}
+					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
+					if (hi[t] == ab && hi[t] > lo[t]) {
+						/* set A drained: take over set B (loaded one whole set
+						 * ago) and put K new loads in flight */
+#pragma unroll
+						for (int k = 0; k < K; k++) {
+							Ad[t][k] = Bd[t][k];
+							Ai[t][k] = Bi[t][k];
+						}
+#pragma unroll
+						for (int k = 0; k < K; k++) {
+							const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
+							Bd[t][k] = 0; Bi[t][k] = 0.0f;
+							if (ib >= lo[t]) {
+								const posting_t p = pt[t][ib];
+								Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+							}
 						}
 						continue;
 					}
@@ -746,13 +797,49 @@ k_scan8(const scan_args_t A)
 				}
 				pdoc[t] = -1;
 				if (hi[t] > lo[t]) {
-					pdoc[t] = __builtin_amdgcn_readlane((int)Wd[t][0], (hi[t] - 1) & 63);
+					const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						if (k == kt) {
+							pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+						}
+					}
 				}
 			}
 		}
 		__syncthreads();
 
 		bool full_scan = n_list > LIST_CAP;
+		if (A.ablate & 1) {
+			continue;
+		}
+		/*
+		 * Scores only grow while a tile is accumulated (all impacts are
+		 * positive), so a doc's final score is one of the values written.
+		 * If none of them beats the threshold no doc of the tile can be a
+		 * candidate: just wipe the accumulators.
+		 */
+		if (MODE == MODE_TOPK && __ballot(tmax > thr) == 0) {
+			if (full_scan) {
+				for (uint32_t i = lane; i < TILE_W; i += WAVE) {
+					s_acc[i] = 0.0f;
+				}
+				for (uint32_t i = lane; i < TILE_W / 4; i += WAVE) {
+					s_mask32[i] = 0;
+				}
+			} else {
+				for (uint32_t off = 0; off < n_list; off += WAVE) {
+					const uint32_t i = off + lane;
+					if (i < n_list) {
+						const uint32_t d = s_list[i];
+						s_acc[d] = 0.0f;
+						s_mask8[d] = 0;
+					}
+				}
+			}
+			__syncthreads();
+			continue;
+		}
 		if (!full_scan) {
 			/* sparse tile: visit only the touched docs */
 			uint32_t ncand = 0;
@@ -763,7 +850,7 @@ k_scan8(const scan_args_t A)
 				float sc = 0.0f;
 				if (valid) {
 					d = s_list[i];
-					m = s_mask8[mask_byte(d)];
+					m = s_mask8[d];
 					sc = s_acc[d];
 				}
 				if (MODE == MODE_COUNT) {
@@ -832,69 +919,61 @@ k_scan8(const scan_args_t A)
 					if (i < n_list) {
 						const uint32_t d = s_list[i];
 						s_acc[d] = 0.0f;
-						s_mask8[mask_byte(d)] = 0;
+						s_mask8[d] = 0;
 					}
 				}
 			}
 		}
 		if (full_scan) {
 			/* dense tile: ordered scan, DESCENDING doc (results.c:143-147) */
-			for (int s = TILE_W / 256 - 1; s >= 0; s--) {
-				const uint32_t mw = s_mask32[s * WAVE + lane];
-				if (__ballot(mw != 0) == 0) {
+			for (int sidx = TILE_W / WAVE - 1; sidx >= 0; sidx--) {
+				const uint32_t d = sidx * WAVE + lane;
+				const uint32_t m = s_mask8[d];
+				if (__ballot(m != 0) == 0) {
 					continue;
 				}
-				if (mw) {
-					s_mask32[s * WAVE + lane] = 0;
+				float sc = 0.0f;
+				if (m) {
+					sc = s_acc[d];
+					s_acc[d] = 0.0f;
+					s_mask8[d] = 0;
 				}
-				for (int j = 3; j >= 0; j--) {
-					const uint32_t m = (mw >> (8 * j)) & 0xff;
-					if (__ballot(m != 0) == 0) {
-						continue;
+				if (MODE == MODE_COUNT) {
+					const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					n_out += __popcll(__ballot(match));
+					continue;
+				}
+				const bool pre = m && (sc > thr);
+				if (__ballot(pre) == 0) {
+					continue;
+				}
+				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				uint64_t bal = __ballot(cand);
+				if (!bal) {
+					continue;
+				}
+				const uint32_t ne = __popcll(bal);
+				if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+					ovf = true;
+				} else {
+					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+					if (cand) {
+						const uint64_t o = out_base + n_out + __popcll(above);
+						A.cand_doc[o] = base + d;
+						A.cand_sc[o] = sc;
 					}
-					const uint32_t d = s * 256 + j * 64 + lane;
-					float sc = 0.0f;
-					if (m) {
-						sc = s_acc[d];
-						s_acc[d] = 0.0f;
-					}
-					if (MODE == MODE_COUNT) {
-						const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
-						n_out += __popcll(__ballot(match));
-						continue;
-					}
-					const bool pre = m && (sc > thr);
-					if (__ballot(pre) == 0) {
-						continue;
-					}
-					const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
-					uint64_t bal = __ballot(cand);
-					if (!bal) {
-						continue;
-					}
-					const uint32_t ne = __popcll(bal);
-					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
-						ovf = true;
-					} else {
-						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
-						if (cand) {
-							const uint64_t o = out_base + n_out + __popcll(above);
-							A.cand_doc[o] = base + d;
-							A.cand_sc[o] = sc;
-						}
-					}
-					n_out += ne;
-					if (track) {
-						while (bal) {
-							const int L = 63 - __clzll(bal);
-							bal &= ~(1ull << L);
-							const float v = __shfl(sc, L);
-							if (v > thr) {
-								const uint32_t pos = __popcll(__ballot(top >= v));
-								const float up = __shfl_up(top, 1);
-								top = (lane < pos) ? top : (lane == pos ? v : up);
-								thr = __shfl(top, kidx);
-							}
+				}
+				n_out += ne;
+				if (track) {
+					while (bal) {
+						const int L = 63 - __clzll(bal);
+						bal &= ~(1ull << L);
+						const float v = __shfl(sc, L);
+						if (v > thr) {
+							const uint32_t pos = __popcll(__ballot(top >= v));
+							const float up = __shfl_up(top, 1);
+							top = (lane < pos) ? top : (lane == pos ? v : up);
+							thr = __shfl(top, kidx);
 						}
 					}
 				}
@@ -1851,6 +1930,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.cand_doc = d_cand_doc;
 	sa.cand_sc = d_cand_sc;
 	sa.overflow = d_ovf;
+	sa.ablate = getenv("NXS_GPU_ABLATE") ? (uint32_t)atoi(getenv("NXS_GPU_ABLATE")) : 0;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {

@@ -16,7 +16,7 @@ __all__ = ["Nxs", "Index", "NxsError", "lib", "build", "LIB_PATH"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libnxsearch_gpu.so")
+LIB_PATH = os.environ.get("NXS_GPU_LIB") or os.path.join(CSRC, "libnxsearch_gpu.so")
 SYNTH_PATH = os.path.join(CSRC, "libnxssynth.so")
 
 MAX_TOKENS, MAX_PROG, FAST_K = 32, 256, 64

@@ -34,6 +34,7 @@
 #include <cstdarg>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -100,6 +101,8 @@ struct dev_query_t {
 	uint64_t	pbeg[NXSGPU_MAX_TOKENS];
 	uint64_t	pend[NXSGPU_MAX_TOKENS];
 	uint32_t	truth[8];
+	uint32_t	req;		/* tokens present in every matching mask */
+	uint32_t	pad0;
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
@@ -274,7 +277,8 @@ struct scan_args_t {
 	const dev_query_t *	queries;
 	uint64_t		n_docs;
 	const qmeta_t *		qmeta;		/* [Q] */
-	const item_t *		items;		/* [grid] (query, group) work items */
+	const item_t *		items;		/* (query, group) work items */
+	uint32_t		item_base;	/* first item of this launch */
 	uint32_t		k;		/* limit (<= 64 in MODE_TOPK) */
 	uint32_t		seg_cap;
 	uint32_t *		seg_count;	/* [segments] */
@@ -294,6 +298,65 @@ post_lower_bound(const posting_t *__restrict__ post, uint64_t lo, uint64_t hi, u
 		if (post[mid].doc < doc) lo = mid + 1; else hi = mid;
 	}
 	return lo;
+}
+
+/* compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>) */
+template <int I, int N, typename F>
+__device__ __forceinline__ void
+static_for_impl(F &&f)
+{
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		static_for_impl<I + 1, N>(f);
+	}
+}
+template <int N, typename F>
+__device__ __forceinline__ void
+static_for(F &&f)
+{
+	static_for_impl<0, N>(f);
+}
+
+/*
+ * Wave-cooperative lower bound: first index in [lo, hi) (relative to pt) whose
+ * doc is >= bound, or hi.  64-ary: each round the 64 lanes probe 64 evenly
+ * spaced postings, so a 10M-entry list needs 4 dependent loads, not 24.
+ * All arguments and the result are wave-uniform.
+ */
+__device__ static inline int32_t
+wave_lower_bound(const posting_t *__restrict__ pt, int32_t lo, int32_t hi, uint32_t bound)
+{
+	const int32_t lane = (int32_t)(threadIdx.x & 63);
+
+	while (hi - lo > WAVE) {
+		const int32_t step = (hi - lo + WAVE - 1) / WAVE;
+		const int32_t idx = lo + lane * step;
+		const bool valid = idx < hi;
+		uint32_t v = 0xffffffffu;
+		if (valid) {
+			v = pt[idx].doc;
+		}
+		/* lanes are monotone: the first lane whose probe is >= bound */
+		const uint64_t m = __ballot(!valid || v >= bound);
+		const int32_t L = m ? (int32_t)__ffsll((long long)m) - 1 : WAVE;
+		if (L == 0) {
+			return lo;
+		}
+		const int32_t nlo = lo + (L - 1) * step + 1;
+		const int32_t nhi = (L < WAVE && lo + L * step < hi) ? lo + L * step : hi;
+		lo = nlo;
+		hi = nhi;
+	}
+	{
+		const int32_t idx = lo + lane;
+		const bool valid = idx < hi;
+		uint32_t v = 0;
+		if (valid) {
+			v = pt[idx].doc;
+		}
+		const uint64_t m = __ballot(valid && v >= bound);
+		return m ? lo + (int32_t)__ffsll((long long)m) - 1 : hi;
+	}
 }
 
 /* byte index of doc d's mask inside a tile: a u32 read at word (s*64+lane)
@@ -340,7 +403,7 @@ k_scan(const scan_args_t A)
 	__shared__ uint8_t s_prog[NXSGPU_MAX_PROG];
 
 	const unsigned lane = threadIdx.x;
-	const item_t item = A.items[blockIdx.x];
+	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];
@@ -570,12 +633,12 @@ k_scan(const scan_args_t A)
 }
 
 /*
- * k_scan8: the <= 8 token fast path.  Same contract as k_scan, restructured
- * for memory-level parallelism and for sparse tiles:
- *  - every term keeps a 64-posting register window A (the next unconsumed
- *    postings below its cursor) plus a prefetched window B, so each posting
- *    is loaded from memory exactly once and every term always has a load in
- *    flight (no per-tile binary search, no re-loading of windows);
+ * k_scan8: the <= 8 token tile path.  Same contract as k_scan, restructured
+ * for memory-level parallelism, sparse tiles and conjunctive queries:
+ *  - every term streams its list through two register sets of K 64-posting
+ *    windows: set A (the 64K-aligned slice holding posting hi-1, being
+ *    consumed) and set B (the slice below it, K loads in flight).  Each
+ *    posting is loaded from memory exactly once; there is no per-tile search;
  *  - LDS updates are plain read-add-write in token order: one wavefront's DS
  *    operations execute in issue order and a doc occurs once per term, so the
  *    f32 sum order is the reference's (DS atomics were measured 10x slower);
@@ -584,7 +647,15 @@ k_scan(const scan_args_t A)
  *    through that list (cost ~ touched docs, not tile width).  Its candidates
  *    are rank-sorted by doc before they are appended, so a segment still is in
  *    descending doc order.  Dense tiles (list overflow) and tiles with more
- *    than 64 candidates take the ordered full scan.
+ *    than 64 candidates take the ordered full scan;
+ *  - scores only grow while a tile is accumulated, so if no value written in
+ *    the tile beat the candidate threshold the tile is just wiped;
+ *  - terms that every matching doc must contain (`req`, from the truth table)
+ *    drive the tile choice: the next tile is that of the LOWEST of their
+ *    highest remaining docs, everything above it is skipped with a 64-ary
+ *    search instead of being streamed, and the wavefront stops as soon as one
+ *    of them is exhausted -- the device analogue of intersecting the bitmaps
+ *    before scoring (search.c:118-174).
  */
 #define	LIST_CAP	512
 #define	TCAND_CAP	64
@@ -594,24 +665,29 @@ __global__ void __launch_bounds__(WAVE)
 k_scan8(const scan_args_t A)
 {
 	__shared__ float s_acc[TILE_W];
-	__shared__ uint32_t s_mask32[TILE_W / 4];
+	__shared__ uint8_t s_mask8[TILE_W];
 	__shared__ uint16_t s_list[LIST_CAP];
 	__shared__ uint32_t s_cd[TCAND_CAP];
 	__shared__ float s_cs[TCAND_CAP];
 	__shared__ uint32_t s_truth[8];
-	__shared__ int64_t s_init[16];
+
+	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : NT <= 5 ? 1 : 0;
+	constexpr int K = 1 << KSH;
+	constexpr int SW = WAVE * K;
 
 	const unsigned lane = threadIdx.x;
 	const uint64_t lane_lt = (1ull << lane) - 1;
-	const item_t item = A.items[blockIdx.x];
+	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];
 	const uint32_t nt = Q->nt;
+	const uint32_t req = (MODE == MODE_TOPK || MODE == MODE_COUNT || MODE == MODE_ALL) ? Q->req : 0;
 	const uint64_t seg = (uint64_t)qm.seg_first + g;
 	const uint64_t dlo = (uint64_t)g * qm.group_docs;
 	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
-	uint8_t *s_mask8 = (uint8_t *)s_mask32;
+	uint32_t *s_mask32 = (uint32_t *)s_mask8;
+
 	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 		s_acc[i] = 0.0f;
 	}
@@ -621,75 +697,92 @@ k_scan8(const scan_args_t A)
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
 	}
-	/* cursors of this group's doc range, relative to the term's list */
-	if (lane < 16) {
-		const uint32_t t = lane & 7;
-		int64_t v = 0;
-		if (t < nt) {
-			const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
-			v = (int64_t)(post_lower_bound(A.post, pb, pe, lane < 8 ? dhi : dlo) - pb);
-		}
-		s_init[lane] = v;
-	}
 	__syncthreads();
 
-	/*
-	 * Wave-uniform per-term state (readfirstlane keeps it scalar).  Window A
-	 * of term t covers the 64-aligned slice of its list holding posting
-	 * hi-1: lanes with index in [lo, hi) are unconsumed.
-	 */
-	/*
-	 * Each term streams its list through two register sets of K 64-posting
-	 * windows: set A (the 64K-aligned slice holding posting hi-1, being
-	 * consumed) and set B (the slice below it, K loads in flight).  Fewer
-	 * terms leave registers for deeper sets.
-	 */
-	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : NT <= 5 ? 1 : 0;
-	constexpr int K = 1 << KSH;
-	constexpr int SW = WAVE * K;
+	/* wave-uniform per-term state (readfirstlane keeps it scalar) */
 	const posting_t *pt[NT];
 	int32_t hi[NT], lo[NT], pdoc[NT];
 	uint32_t Ad[NT][K], Bd[NT][K];
 	float Ai[NT][K], Bi[NT][K];
 
-#pragma unroll
-	for (int t = 0; t < NT; t++) {
-		pt[t] = A.post;
-		hi[t] = lo[t] = 0;
+	/* (re)load both register sets of term t for cursor hi[t]; sets pdoc */
+	auto load_sets = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
 		pdoc[t] = -1;
 #pragma unroll
 		for (int k = 0; k < K; k++) {
 			Ad[t][k] = Bd[t][k] = 0;
 			Ai[t][k] = Bi[t][k] = 0.0f;
 		}
-		if (t < (int)nt) {
-			pt[t] = A.post + Q->pbeg[t];
-			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
-			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
-			if (hi[t] > lo[t]) {
-				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+		if (hi[t] > lo[t]) {
+			const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
 #pragma unroll
-				for (int k = 0; k < K; k++) {
-					const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
-					if (ia >= lo[t] && ia < hi[t]) {
-						const posting_t p = pt[t][ia];
-						Ad[t][k] = p.doc; Ai[t][k] = p.imp;
-					}
-					if (ib >= lo[t]) {
-						const posting_t p = pt[t][ib];
-						Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-					}
+			for (int k = 0; k < K; k++) {
+				const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
+				if (ia >= lo[t] && ia < hi[t]) {
+					const posting_t p = pt[t][ia];
+					Ad[t][k] = p.doc; Ai[t][k] = p.imp;
 				}
-				const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+				if (ib >= lo[t]) {
+					const posting_t p = pt[t][ib];
+					Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+				}
+			}
+			const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
 #pragma unroll
-				for (int k = 0; k < K; k++) {
-					if (k == kt) {
-						pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-					}
+			for (int k = 0; k < K; k++) {
+				if (k == kt) {
+					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
 				}
 			}
 		}
-	}
+	};
+	/* doc of the highest unconsumed posting of term t (or -1) */
+	auto refresh_pdoc = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = -1;
+		if (hi[t] > lo[t]) {
+			const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+			for (int k = 0; k < K; k++) {
+				if (k == kt) {
+					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+				}
+			}
+		}
+	};
+	/* set A drained: take over set B, put K new loads in flight */
+	auto rotate_sets = [&](auto tc, int32_t ab) {
+		constexpr int t = decltype(tc)::value;
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			Ad[t][k] = Bd[t][k];
+			Ai[t][k] = Bi[t][k];
+		}
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
+			Bd[t][k] = 0; Bi[t][k] = 0.0f;
+			if (ib >= lo[t]) {
+				const posting_t p = pt[t][ib];
+				Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+			}
+		}
+	};
+
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pt[t] = A.post;
+		hi[t] = lo[t] = 0;
+		if (t < (int)nt) {
+			const int32_t n = (int32_t)(Q->pend[t] - Q->pbeg[t]);
+			pt[t] = A.post + Q->pbeg[t];
+			/* cursors of this wavefront's doc range [dlo, dhi) */
+			lo[t] = dlo ? wave_lower_bound(pt[t], 0, n, (uint32_t)dlo) : 0;
+			hi[t] = dhi >= A.n_docs ? n : wave_lower_bound(pt[t], lo[t], n, (uint32_t)dhi);
+		}
+		load_sets(tc);
+	});
 
 	float top = -INFINITY, thr = -INFINITY;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
@@ -699,28 +792,80 @@ k_scan8(const scan_args_t A)
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
 
 	for (;;) {
-		int32_t md = -1;
+		int32_t md = -1, rq = 0x7fffffff;
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			md = max(md, pdoc[t]);
+			if (t < (int)nt && ((req >> t) & 1)) {
+				rq = min(rq, pdoc[t]);
+			}
 		}
-		if (md < 0) {
-			break;
+		if (md < 0 || rq < 0) {
+			break;		/* all consumed, or a required term ran out */
 		}
-		const uint32_t base = ((uint32_t)md / TILE_W) * TILE_W;
+		const uint32_t base = ((uint32_t)(req ? rq : md) / TILE_W) * TILE_W;
+
+		if (req && md >= (int32_t)(base + TILE_W)) {
+			/* skip, unscored, everything above this tile: none of it can
+			 * match (a required term has nothing up there) */
+			const uint32_t bound = base + TILE_W;
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				if (t < (int)nt && pdoc[t] >= (int32_t)bound) {
+					const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+					const int32_t li = max(lo[t], ab);
+					const int32_t kl = (li >> 6) & (K - 1);
+					int32_t lowd = 0;
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						if (k == kl) {
+							lowd = __builtin_amdgcn_readlane((int)Ad[t][k], li & 63);
+						}
+					}
+					if (lowd < (int32_t)bound) {
+						/* the boundary is inside set A */
+						uint32_t cnt = 0;
+#pragma unroll
+						for (int k = 0; k < K; k++) {
+							const int32_t idx = ab + k * WAVE + (int32_t)lane;
+							cnt += __popcll(__ballot(idx >= lo[t] && idx < hi[t] && Ad[t][k] >= bound));
+						}
+						hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)cnt);
+						refresh_pdoc(tc);
+					} else {
+						/* the whole set is above it: jump */
+						hi[t] = li > lo[t] ? wave_lower_bound(pt[t], lo[t], li, bound) : lo[t];
+						load_sets(tc);
+					}
+				}
+			});
+			/* the tile is worth scoring only if every required term
+			 * still reaches it */
+			bool reach = true;
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				if (t < (int)nt && ((req >> t) & 1) && pdoc[t] < (int32_t)base) {
+					reach = false;
+				}
+			}
+			if (!reach) {
+				continue;
+			}
+		}
+
 		uint32_t n_list = 0;
 		float tmax = -INFINITY;		/* largest accumulator value written in this tile */
 
 		/* accumulate, tokens strictly in token-list order (results.c:134-136) */
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
 			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
 				for (;;) {
 					const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
 					bool in[K];
 					float a0[K];
 					uint32_t m0[K], dd[K];
-					uint32_t ctot = 0, act = 0;	/* act: windows with in-tile postings (uniform) */
+					uint32_t ctot = 0, act = 0;	/* act: windows with in-tile postings */
 					bool more = true;	/* windows below may still be in the tile */
 
 					/*
@@ -750,8 +895,7 @@ k_scan8(const scan_args_t A)
 							}
 						}
 					}
-					/* write phase: plain read-add-write (DS atomics serialise
-					 * the lanes: measured ~200 LDS cycles per window) */
+					/* write phase */
 #pragma unroll
 					for (int k = K - 1; k >= 0; k--) {
 						if (act & (1u << k)) {
@@ -775,38 +919,14 @@ k_scan8(const scan_args_t A)
 					}
 					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
 					if (hi[t] == ab && hi[t] > lo[t]) {
-						/* set A drained: take over set B (loaded one whole set
-						 * ago) and put K new loads in flight */
-#pragma unroll
-						for (int k = 0; k < K; k++) {
-							Ad[t][k] = Bd[t][k];
-							Ai[t][k] = Bi[t][k];
-						}
-#pragma unroll
-						for (int k = 0; k < K; k++) {
-							const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
-							Bd[t][k] = 0; Bi[t][k] = 0.0f;
-							if (ib >= lo[t]) {
-								const posting_t p = pt[t][ib];
-								Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-							}
-						}
+						rotate_sets(tc, ab);
 						continue;
 					}
 					break;
 				}
-				pdoc[t] = -1;
-				if (hi[t] > lo[t]) {
-					const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
-#pragma unroll
-					for (int k = 0; k < K; k++) {
-						if (k == kt) {
-							pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-						}
-					}
-				}
+				refresh_pdoc(tc);
 			}
-		}
+		});
 		__syncthreads();
 
 		bool full_scan = n_list > LIST_CAP;
@@ -977,6 +1097,438 @@ k_scan8(const scan_args_t A)
 						}
 					}
 				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/*
+ * k_scan1: single-token queries.  A doc's score is the posting's own impact
+ * and it matches iff the one-token mask satisfies the expression, so nothing
+ * is accumulated: the wavefront streams its slice of the list downwards, U
+ * windows (U x 512 B) in flight, and compares impacts with the running
+ * threshold in registers.  No LDS: full occupancy.
+ */
+template <int MODE>
+__global__ void __launch_bounds__(WAVE)
+k_scan1(const scan_args_t A)
+{
+	constexpr int U = 4;
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
+	const bool matches = Q->nt == 1 && ((Q->truth[0] >> 1) & 1);
+	const posting_t *__restrict__ pt = A.post + Q->pbeg[0];
+	const int32_t n = Q->nt ? (int32_t)(Q->pend[0] - Q->pbeg[0]) : 0;
+	int32_t lo = 0, hi = 0;
+	uint32_t n_out = 0;
+	bool ovf = false;
+
+	if (matches) {
+		lo = dlo ? wave_lower_bound(pt, 0, n, (uint32_t)dlo) : 0;
+		hi = dhi >= A.n_docs ? n : wave_lower_bound(pt, lo, n, (uint32_t)dhi);
+	}
+	if (MODE == MODE_COUNT) {
+		if (lane == 0) {
+			A.seg_count[seg] = (uint32_t)(hi - lo);
+		}
+		return;
+	}
+
+	float top = -INFINITY, thr = -INFINITY;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	while (hi > lo) {
+		uint32_t dv[U];
+		float iv[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int32_t idx = hi - (u + 1) * WAVE + (int32_t)lane;
+			dv[u] = 0;
+			iv[u] = -INFINITY;
+			if (idx >= lo) {
+				const posting_t p = pt[idx];
+				dv[u] = p.doc;
+				iv[u] = p.imp;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			/* window u: descending doc = descending lane */
+			const bool cand = iv[u] > thr;
+			uint64_t bal = __ballot(cand);
+			if (!bal) {
+				continue;
+			}
+			const uint32_t ne = __popcll(bal);
+			if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+				ovf = true;
+			} else {
+				const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+				if (cand) {
+					const uint64_t o = out_base + n_out + __popcll(above);
+					A.cand_doc[o] = dv[u];
+					A.cand_sc[o] = iv[u];
+				}
+			}
+			n_out += ne;
+			if (track) {
+				while (bal) {
+					const int L = 63 - __clzll(bal);
+					bal &= ~(1ull << L);
+					const float v = __shfl(iv[u], L);
+					if (v > thr) {
+						const uint32_t pos = __popcll(__ballot(top >= v));
+						const float up = __shfl_up(top, 1);
+						top = (lane < pos) ? top : (lane == pos ? v : up);
+						thr = __shfl(top, kidx);
+					}
+				}
+			}
+		}
+		hi -= U * WAVE;
+	}
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/*
+ * k_scanh: the posting-step path for queries without a very dense term.
+ *
+ * Every term streams its list through register sets as in k_scan8.  A STEP
+ * picks base = the largest, over the terms, of the lowest doc still held in
+ * the term's set A.  All unconsumed postings with doc >= base are then in
+ * registers, for every term: the term that defines base drains its whole set
+ * (so a query needs at most sum_t ceil(df_t / 64K) steps, however sparse it
+ * is), the others contribute the part of their set above base.  The docs of a
+ * step can span far more than an LDS tile, so scores accumulate in a small
+ * LDS hash table keyed by doc (slot = low doc bits, linear probing, claims are
+ * written then verified -- no atomics).  Terms are applied in token order, so
+ * a doc's f32 sum order is the reference's (results.c:134-136).  Claimed slots
+ * go to a list: the table is scanned and wiped through it.  Steps run in
+ * descending doc ranges and a step's candidates are rank-sorted by doc, so the
+ * segment is in descending doc order like k_scan8's.
+ */
+template <int MODE, int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scanh(const scan_args_t A)
+{
+	constexpr int KSH = NT <= 2 ? 2 : NT <= 3 ? 1 : 0;
+	constexpr int K = 1 << KSH;
+	constexpr int SW = WAVE * K;
+	constexpr int MAXE = WAVE * K * NT;		/* table entries per step */
+	constexpr int TAB = MAXE <= 256 ? 512 : 1024;	/* load factor <= 1/2 */
+	constexpr uint32_t EMPTY = 0xffffffffu;
+
+	__shared__ uint32_t s_key[TAB];
+	__shared__ float s_val[TAB];
+	__shared__ uint8_t s_msk[TAB];
+	__shared__ uint16_t s_list[MAXE];
+	__shared__ uint32_t s_cd[MAXE];
+	__shared__ float s_cs[MAXE];
+	__shared__ uint32_t s_truth[8];
+	__shared__ int64_t s_init[16];
+
+	const unsigned lane = threadIdx.x;
+	const uint64_t lane_lt = (1ull << lane) - 1;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
+
+	for (uint32_t i = lane; i < TAB; i += WAVE) {
+		s_key[i] = EMPTY;
+		s_val[i] = 0.0f;
+		s_msk[i] = 0;
+	}
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	if (lane < 16) {
+		const uint32_t t = lane & 7;
+		int64_t v = 0;
+		if (t < nt) {
+			const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+			v = (int64_t)(post_lower_bound(A.post, pb, pe, lane < 8 ? dhi : dlo) - pb);
+		}
+		s_init[lane] = v;
+	}
+	__syncthreads();
+
+	/* wave-uniform per-term state */
+	const posting_t *pt[NT];
+	int32_t hi[NT], lo[NT], pdoc[NT], lowdoc[NT];
+	uint32_t Ad[NT][K], Bd[NT][K];
+	float Ai[NT][K], Bi[NT][K];
+
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		pt[t] = A.post;
+		hi[t] = lo[t] = 0;
+		pdoc[t] = lowdoc[t] = -1;
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			Ad[t][k] = Bd[t][k] = 0;
+			Ai[t][k] = Bi[t][k] = 0.0f;
+		}
+		if (t < (int)nt) {
+			pt[t] = A.post + Q->pbeg[t];
+			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
+			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
+			if (hi[t] > lo[t]) {
+				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+#pragma unroll
+				for (int k = 0; k < K; k++) {
+					const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
+					if (ia >= lo[t] && ia < hi[t]) {
+						const posting_t p = pt[t][ia];
+						Ad[t][k] = p.doc; Ai[t][k] = p.imp;
+					}
+					if (ib >= lo[t]) {
+						const posting_t p = pt[t][ib];
+						Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+					}
+				}
+				const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+				for (int k = 0; k < K; k++) {
+					if (k == kt) {
+						pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+					}
+				}
+				/* lowest doc held in set A, or -1 if the set reaches the
+				 * start of this range's postings */
+				if (ab > lo[t]) {
+					lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
+				}
+			}
+		}
+	}
+
+	float top = -INFINITY, thr = -INFINITY;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	for (;;) {
+		int32_t md = -1, bs = -1;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			md = max(md, pdoc[t]);
+			bs = max(bs, lowdoc[t]);
+		}
+		if (md < 0) {
+			break;		/* every list is consumed */
+		}
+		const uint32_t base = bs < 0 ? 0u : (uint32_t)bs;
+		uint32_t n_list = 0;
+		float tmax = -INFINITY;
+
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
+				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+				uint32_t ctot = 0;
+				bool more = true;
+#pragma unroll
+				for (int k = K - 1; k >= 0; k--) {
+					if (more && hi[t] > ab + k * WAVE) {
+						const int32_t idx = ab + k * WAVE + (int32_t)lane;
+						const uint32_t doc = Ad[t][k];
+						const bool in = idx >= lo[t] && idx < hi[t] && doc >= base;
+						const uint32_t c = __popcll(__ballot(in));
+						const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
+						const int32_t bot_ = max(lo[t], ab + k * WAVE);
+						ctot += c;
+						if ((int32_t)c < top_ - bot_) {
+							more = false;
+						}
+						if (c) {
+							/* find or claim the doc's slot */
+							/* volatile: the claim must really be re-read, not
+							 * forwarded from this lane's own store */
+							volatile uint32_t *vkey = s_key;
+							uint32_t slot = doc & (TAB - 1);
+							bool pending = in, isnew = false;
+							while (__ballot(pending)) {
+								uint32_t kk = 0;
+								if (pending) {
+									kk = vkey[slot];
+									if (kk == EMPTY) {
+										vkey[slot] = doc;
+									}
+								}
+								if (pending) {
+									if (kk == doc) {
+										pending = false;
+									} else if (kk == EMPTY) {
+										/* several lanes may have written
+										 * this slot: one value landed */
+										if (vkey[slot] == doc) {
+											pending = false;
+											isnew = true;
+										}
+									} else {
+										slot = (slot + 1) & (TAB - 1);
+									}
+								}
+							}
+							if (in) {
+								const float v = s_val[slot] + Ai[t][k];
+								s_val[slot] = v;
+								s_msk[slot] = (uint8_t)(s_msk[slot] | (1u << t));
+								tmax = fmaxf(tmax, v);
+							}
+							const uint64_t fb = __ballot(isnew);
+							if (isnew) {
+								s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)slot;
+							}
+							n_list += __popcll(fb);
+						}
+					}
+				}
+				hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
+				pdoc[t] = -1;
+				if (hi[t] <= lo[t]) {
+					lowdoc[t] = -1;
+				} else if (hi[t] == ab) {
+					/* set A drained: take over set B, K new loads in flight */
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						Ad[t][k] = Bd[t][k];
+						Ai[t][k] = Bi[t][k];
+					}
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
+						Bd[t][k] = 0; Bi[t][k] = 0.0f;
+						if (ib >= lo[t]) {
+							const posting_t p = pt[t][ib];
+							Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+						}
+					}
+					lowdoc[t] = -1;
+					if (ab - SW > lo[t]) {
+						lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
+					}
+					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][K - 1], WAVE - 1);
+				} else {
+					const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						if (k == kt) {
+							pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+
+		/* candidates of this step (skipped when nothing beat the threshold:
+		 * scores only grow within a step, see k_scan8) */
+		if (MODE == MODE_COUNT || __ballot(tmax > thr) != 0) {
+			uint32_t ncand = 0;
+			for (uint32_t off = 0; off < n_list; off += WAVE) {
+				const uint32_t i = off + lane;
+				const bool valid = i < n_list;
+				uint32_t d = 0, m = 0;
+				float sc = 0.0f;
+				if (valid) {
+					const uint32_t slot = s_list[i];
+					d = s_key[slot];
+					m = s_msk[slot];
+					sc = s_val[slot];
+				}
+				if (MODE == MODE_COUNT) {
+					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					n_out += __popcll(__ballot(match));
+					continue;
+				}
+				const bool pre = valid && (sc > thr);
+				if (__ballot(pre) == 0) {
+					continue;
+				}
+				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				const uint64_t bal = __ballot(cand);
+				if (cand) {
+					const uint32_t j = ncand + __popcll(bal & lane_lt);
+					s_cd[j] = d;
+					s_cs[j] = sc;
+				}
+				ncand += __popcll(bal);
+			}
+			if (MODE != MODE_COUNT && ncand) {
+				__syncthreads();
+				if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
+					ovf = true;
+				} else {
+					/* rank by doc, descending: docs are distinct */
+					for (uint32_t i0 = 0; i0 < ncand; i0 += WAVE) {
+						const uint32_t i = i0 + lane;
+						const uint32_t cd = i < ncand ? s_cd[i] : 0;
+						uint32_t rank = 0;
+						for (uint32_t j = 0; j < ncand; j++) {
+							rank += s_cd[j] > cd;
+						}
+						if (i < ncand) {
+							const uint64_t o = out_base + n_out + rank;
+							A.cand_doc[o] = cd;
+							A.cand_sc[o] = s_cs[i];
+						}
+					}
+				}
+				n_out += ncand;
+				if (track) {
+					for (uint32_t j = 0; j < ncand; j++) {
+						const float v = s_cs[j];
+						if (v > thr) {
+							const uint32_t pos = __popcll(__ballot(top >= v));
+							const float up = __shfl_up(top, 1);
+							top = (lane < pos) ? top : (lane == pos ? v : up);
+							thr = __shfl(top, kidx);
+						}
+					}
+				}
+			}
+		}
+		/* wipe the table through the list */
+		for (uint32_t off = 0; off < n_list; off += WAVE) {
+			const uint32_t i = off + lane;
+			if (i < n_list) {
+				const uint32_t slot = s_list[i];
+				s_key[slot] = EMPTY;
+				s_val[slot] = 0.0f;
+				s_msk[slot] = 0;
 			}
 		}
 		__syncthreads();
@@ -1706,51 +2258,29 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
 
 /* ---- search --------------------------------------------------------- */
 
-template <int MODE>
-static void
-launch_scan(nxsgpu_index_t *ix, const scan_args_t &a, uint32_t n_items, uint32_t max_nt)
-{
-	const dim3 grid(n_items), block(WAVE);
-	const bool wide = max_nt > 8;
-
-	if (n_items == 0) {
-		return;
-	}
-	if (wide) {
-		hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
-	} else {
-		if (ix->n_docs < (1ull << 31) && !getenv("NXS_GPU_OLDSCAN")) {
-			/* NT = compile-time bound of the per-term register state */
-			if (max_nt <= 1) {
-				hipLaunchKernelGGL((k_scan8<MODE, 1>), grid, block, 0, ix->stream, a);
-			} else if (max_nt <= 2) {
-				hipLaunchKernelGGL((k_scan8<MODE, 2>), grid, block, 0, ix->stream, a);
-			} else if (max_nt <= 3) {
-				hipLaunchKernelGGL((k_scan8<MODE, 3>), grid, block, 0, ix->stream, a);
-			} else if (max_nt <= 5) {
-				hipLaunchKernelGGL((k_scan8<MODE, 5>), grid, block, 0, ix->stream, a);
-			} else {
-				hipLaunchKernelGGL((k_scan8<MODE, 8>), grid, block, 0, ix->stream, a);
-			}
-		} else {
-			hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
-		}
-	}
-}
-
 /*
  * Work decomposition: every query's doc space is cut into n_groups equal
  * ranges (multiples of TILE_W), one wavefront each.  The number of ranges is
  * proportional to the query's share of the batch's postings, so a query with
  * long lists gets many wavefronts and a sparse one a single one (whose fixed
  * costs -- cursor searches, warm-up of the candidate threshold -- are then
- * paid once).  Items are emitted heaviest query first.
+ * paid once).  Items are grouped by kernel class (token-count bucket x
+ * tile/step path) and emitted heaviest query first inside a class.
  */
+struct launch_t { uint32_t first, count, nt_bucket, kind; };	/* kind: 0 wide, 1 tile, 2 step */
+
 struct worklist_t {
 	std::vector<qmeta_t>	qmeta;
 	std::vector<item_t>	items;
+	std::vector<launch_t>	launches;
 	uint32_t		n_segs;
 };
+
+static uint32_t
+nt_bucket(uint32_t nt)
+{
+	return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 3 ? 3 : nt <= 5 ? 5 : 8;
+}
 
 static void
 build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, worklist_t &wl)
@@ -1760,28 +2290,41 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 	const char *env = getenv("NXS_GPU_WAVES");
 	const uint64_t target = env ? strtoull(env, NULL, 10) : 65536;
 	const char *env2 = getenv("NXS_GPU_MINPOST");
-	const uint64_t min_post = env2 ? strtoull(env2, NULL, 10) : 8192;
+	const uint64_t min_post = env2 ? strtoull(env2, NULL, 10) : 4096;
+	/* densest term has >= this many postings per tile => tile path */
+	const char *env3 = getenv("NXS_GPU_DENSE");
+	const double dense_thr = env3 ? atof(env3) : 32.0;
 	std::vector<uint64_t> work(nq);
-	std::vector<uint32_t> order(nq);
+	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
 
 	for (uint32_t i = 0; i < nq; i++) {
-		uint64_t w = 0;
+		uint64_t w = 0, wmax = 0;
 		for (uint32_t t = 0; t < hq[i].nt; t++) {
-			w += hq[i].pend[t] - hq[i].pbeg[t];
+			const uint64_t df = hq[i].pend[t] - hq[i].pbeg[t];
+			w += df;
+			wmax = std::max(wmax, df);
 		}
 		work[i] = w;
 		total += w;
 		order[i] = i;
+		if (hq[i].nt > 8) {
+			cls[i] = 0;
+		} else {
+			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
+			const bool tile = per_tile >= dense_thr || hq[i].nt <= 1 ||
+			    ix->n_docs >= (1ull << 31) || getenv("NXS_GPU_NOSTEP");
+			cls[i] = (tile ? 1u : 2u) * 16 + nt_bucket(hq[i].nt);
+		}
 	}
-	/* postings per wavefront: the batch spread over `target` wavefronts, but
-	 * not so few that the fixed per-wavefront cost dominates */
 	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+		if (cls[x] != cls[y]) return cls[x] < cls[y];
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
 	});
 	wl.qmeta.assign(nq, qmeta_t());
 	wl.items.clear();
+	wl.launches.clear();
 	wl.n_segs = 0;
 	for (uint32_t i = 0; i < nq; i++) {
 		uint64_t g = std::max<uint64_t>(1, (work[i] + per_wave - 1) / per_wave);
@@ -1801,12 +2344,62 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 	wl.items.reserve(wl.n_segs);
 	for (uint32_t oi = 0; oi < nq; oi++) {
 		const uint32_t i = order[oi];
+		if (oi == 0 || cls[i] != cls[order[oi - 1]]) {
+			launch_t l;
+			l.first = (uint32_t)wl.items.size();
+			l.count = 0;
+			l.nt_bucket = cls[i] & 15;
+			l.kind = cls[i] >> 4;
+			wl.launches.push_back(l);
+		}
 		/* descending ranges first: they are replayed first */
 		for (uint32_t g = wl.qmeta[i].n_groups; g-- > 0; ) {
 			item_t it;
 			it.q = i;
 			it.g = g;
 			wl.items.push_back(it);
+		}
+		wl.launches.back().count = (uint32_t)wl.items.size() - wl.launches.back().first;
+	}
+}
+
+template <int MODE>
+static void
+launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
+{
+	for (const launch_t &l : wl.launches) {
+		scan_args_t a = a0;
+		const dim3 grid(l.count), block(WAVE);
+
+		if (l.count == 0) {
+			continue;
+		}
+		a.item_base = l.first;
+		if (l.kind == 0) {
+			hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
+		} else if (getenv("NXS_GPU_OLDSCAN") || ix->n_docs >= (1ull << 31)) {
+			hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
+		} else if (l.kind == 1) {
+			switch (l.nt_bucket) {
+			case 1:
+				if (getenv("NXS_GPU_NOSCAN1")) {
+					hipLaunchKernelGGL((k_scan8<MODE, 1>), grid, block, 0, ix->stream, a);
+				} else {
+					hipLaunchKernelGGL((k_scan1<MODE>), grid, block, 0, ix->stream, a);
+				}
+				break;
+			case 2: hipLaunchKernelGGL((k_scan8<MODE, 2>), grid, block, 0, ix->stream, a); break;
+			case 3: hipLaunchKernelGGL((k_scan8<MODE, 3>), grid, block, 0, ix->stream, a); break;
+			case 5: hipLaunchKernelGGL((k_scan8<MODE, 5>), grid, block, 0, ix->stream, a); break;
+			default: hipLaunchKernelGGL((k_scan8<MODE, 8>), grid, block, 0, ix->stream, a); break;
+			}
+		} else {
+			switch (l.nt_bucket) {
+			case 2: hipLaunchKernelGGL((k_scanh<MODE, 2>), grid, block, 0, ix->stream, a); break;
+			case 3: hipLaunchKernelGGL((k_scanh<MODE, 3>), grid, block, 0, ix->stream, a); break;
+			case 5: hipLaunchKernelGGL((k_scanh<MODE, 5>), grid, block, 0, ix->stream, a); break;
+			default: hipLaunchKernelGGL((k_scanh<MODE, 8>), grid, block, 0, ix->stream, a); break;
+			}
 		}
 	}
 }
@@ -1827,7 +2420,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	std::vector<dev_query_t> hq(nq);
 	std::vector<uint32_t> h_ovf, h_cnt;
 	worklist_t wl;
-	uint32_t max_nt = 0;
 	uint64_t total_post = 0;
 	uint8_t *p;
 	dev_query_t *d_q;
@@ -1873,6 +2465,17 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		d.prog_len = q.prog_len;
 		memcpy(d.prog, q.prog, q.prog_len);
 		memcpy(d.truth, q.truth, sizeof(d.truth));
+		/* tokens common to every matching presence mask (<= 8 tokens) */
+		d.req = 0;
+		if (d.nt && d.nt <= 8 && !getenv("NXS_GPU_NOREQ")) {
+			uint32_t r = (1u << d.nt) - 1;
+			for (uint32_t m = 1; m < (1u << d.nt); m++) {
+				if ((d.truth[m >> 5] >> (m & 31)) & 1) {
+					r &= m;
+				}
+			}
+			d.req = r;
+		}
 		for (uint32_t t = 0; t < d.nt; t++) {
 			const uint32_t tid = q.term_id[t];
 			if (tid == 0 || tid > ix->n_terms) {
@@ -1883,7 +2486,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			d.pend[t] = ix->h_post_off[tid + 1];
 			total_post += d.pend[t] - d.pbeg[t];
 		}
-		max_nt = std::max(max_nt, d.nt);
 	}
 	build_worklist(ix, hq, wl);
 	const uint64_t nseg = wl.n_segs;
@@ -1935,7 +2537,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	h_ovf.assign(nq, 0);
 	if (fast) {
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
-		launch_scan<MODE_TOPK>(ix, sa, (uint32_t)nseg, max_nt);
+		launch_scan<MODE_TOPK>(ix, sa, wl);
 		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
 
 		memset(&ra, 0, sizeof(ra));
@@ -2033,13 +2635,11 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		worklist_t xwl;
 		void *xws = NULL;
 		uint8_t *xp;
-		uint32_t xmax_nt = 0;
 		size_t xneed;
 		int rc = -1;
 
 		for (uint32_t j = 0; j < nx; j++) {
 			xhq[j] = hq[xq[j]];
-			xmax_nt = std::max(xmax_nt, xhq[j].nt);
 		}
 		build_worklist(ix, xhq, xwl);
 		const uint64_t xseg = xwl.n_segs;
@@ -2075,7 +2675,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		sa.items = dx_items;
 		sa.seg_count = dx_seg_count;
 		sa.k = 0xffffffffu;
-		launch_scan<MODE_COUNT>(ix, sa, (uint32_t)xseg, xmax_nt);
+		launch_scan<MODE_COUNT>(ix, sa, xwl);
 		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {
 			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
@@ -2127,7 +2727,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			sb.seg_off = dx_seg_off;
 			sb.cand_doc = dx_cdoc;
 			sb.cand_sc = dx_csc;
-			launch_scan<MODE_ALL>(ix, sb, (uint32_t)xseg, xmax_nt);
+			launch_scan<MODE_ALL>(ix, sb, xwl);
 			memset(&ra, 0, sizeof(ra));
 			ra.qmeta = dx_qmeta;
 			ra.seg_cap = 0;

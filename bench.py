@@ -125,28 +125,23 @@ def main():
     idx = nxs.open_files(info["terms"], info["dtmap"], algo="BM25")
     t_load = time.time() - t0
 
-    # ---- this rank's batch: C3 queries, weak scaling (fixed per-GPU batch) --
-    queries = corpus.queries_bool5(terms, args.batch, seed=3 + 1000 * rank, hi=1000)
+    # ---- the batch: C3 queries; weak scaling = 1024 queries per GPU, sharded
+    #      by query (contiguous slices), index replicated on every GPU --------
+    from nxsearch_amd import multi
+    k = args.limit
+    all_queries = corpus.queries_bool5(terms, args.batch * world, seed=3, hi=1000)
+    sb = multi.ShardedBatch(len(all_queries), k, rank, world, dev)
+    queries = all_queries[sb.lo:sb.hi]
     plans, errs = idx.plan_batch(queries, limit=args.limit, algo="BM25", fuzzymatch=False)
     assert not any(errs)
-    k = args.limit
-    d_ids = torch.empty((args.batch, k), dtype=torch.int64, device=dev)
-    d_sc = torch.empty((args.batch, k), dtype=torch.float32, device=dev)
-    d_cnt = torch.empty((args.batch,), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_ids = torch.empty((world * args.batch, k), dtype=torch.int64, device=dev)
-        g_sc = torch.empty((world * args.batch, k), dtype=torch.float32, device=dev)
-        g_cnt = torch.empty((world * args.batch,), dtype=torch.int32, device=dev)
+    d_cnt = sb.counts
 
     def step():
-        r = idx.search_dev(plans, args.batch, k, N.BM25, d_ids.data_ptr(),
-                           d_sc.data_ptr(), d_cnt.data_ptr())
+        r = idx.search_dev(plans, len(queries), k, N.BM25, sb.ids.data_ptr(),
+                           sb.scores.data_ptr(), sb.counts.data_ptr())
         assert r == 0, "a query needed the exact two-pass path"
-        if world > 1:
-            # per-GPU top-k over xGMI (RCCL); ~124 B per query
-            dist.all_gather_into_tensor(g_ids, d_ids)
-            dist.all_gather_into_tensor(g_sc, d_sc)
-            dist.all_gather_into_tensor(g_cnt, d_cnt)
+        # per-GPU top-k records over xGMI (RCCL all-gather); ~124 B per query
+        sb.gather(dist)
 
     for _ in range(args.warmup):
         step()

@@ -297,3 +297,45 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
     for tok, g in zip(fq, ids):
         assert g == oidx.fuzzy(tok.encode())[0], tok
     gidx.close()
+
+
+@pytest.mark.parametrize("env", [{"NXS_GPU_DENSE": "0"}, {"NXS_GPU_DENSE": "1e12"},
+                                 {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
+                                 {"NXS_GPU_NOREQ": "1"}, {"NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
+def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
+    """The tile path (k_scan8), the posting-step path (k_scanh), the generic
+    kernel (k_scan), the single-token kernel and the skip logic are selected by
+    query shape; force each of them over the same mixed workload."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = corpus.write_corpus(str(tmp_path), 60_000, 3000, seed=21)
+    terms = corpus.term_strings(3000, seed=21)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    rng = random.Random(4)
+    T = lambda r: terms[r - 1].decode()
+    qs = [T(rng.randint(1, 500)) for _ in range(8)]
+    qs += corpus.queries_bool5(terms, 24, seed=6, hi=400)
+    qs += ["%s AND (%s OR %s)" % (T(900), T(2), T(3)), "%s AND NOT %s" % (T(1), T(2)),
+           "%s OR %s" % (T(2500), T(2900)), "(%s AND %s) OR %s" % (T(1), T(2), T(1500)),
+           "%s AND %s AND %s" % (T(1), T(1200), T(3))]
+    for limit in (10, 200):
+        got = gidx.search_batch(qs, limit=limit, fuzzymatch=False)
+        for q, g in zip(qs, got):
+            assert_same(g, oidx.search(q, limit=limit, fuzzymatch=False), (env, q, limit))
+    gidx.close()
+
+
+def test_sharded_search_single_rank(nxs, tmp_path):
+    import torch
+    from nxsearch_amd import multi
+    c = corpus.write_corpus(str(tmp_path), 30_000, 2000, seed=8)
+    terms = corpus.term_strings(2000, seed=8)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    qs = corpus.queries_bool5(terms, 33, seed=9, hi=300)
+    ids, sc, cnt = multi.search_sharded(gidx, qs, limit=10, device=torch.device("cuda", 0))
+    for i, q in enumerate(qs):
+        want = oidx.search(q, limit=10, fuzzymatch=False)
+        n = int(cnt[i])
+        got = list(zip(ids[i, :n].tolist(), sc[i, :n].tolist()))
+        assert_same(got, want, q)
+    gidx.close()

@@ -653,6 +653,9 @@ nxs_index_plan_batch(nxs_index_t *idx, nxs_params_t *params,
 	if (get_search_params(idx, params, &sp) == -1) {
 		return -1;
 	}
+	if (nxs_index_refresh(idx) == -1) {	/* search.c:309-312 */
+		return -1;
+	}
 	if ((prep = calloc(n ? n : 1, sizeof(qprep_t))) == NULL) {
 		nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
 		return -1;
@@ -702,6 +705,9 @@ nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
 		}
 	}
 	if (get_search_params(idx, params, &sp) == -1) {
+		return -1;
+	}
+	if (nxs_index_refresh(idx) == -1) {	/* search.c:309-312 */
 		return -1;
 	}
 	if (n == 0) {

@@ -80,11 +80,17 @@ struct nxs_index {
 
 	uint64_t	n_docs;
 	nxsgpu_index_t *dev;
+
+	/* snapshot identity: what idx_terms_sync/idx_dtmap_sync had consumed */
+	char *		terms_path;
+	char *		dtmap_path;
+	uint64_t	terms_seen, dt_seen;	/* header data_len at load */
 };
 
 /* nxs_index.c */
 int	nxs_index_load(nxs_index_t *, const char *terms_path, const char *dtmap_path);
 void	nxs_index_unload(nxs_index_t *);
+int	nxs_index_refresh(nxs_index_t *);
 uint32_t nxs_term_lookup(const nxs_index_t *, const uint8_t *val, size_t len);
 
 /* flattened BK-tree built on the host (exported for the CPU-side tests) */

@@ -573,6 +573,10 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 	uint8_t *term_ok = NULL;
 	int ret = -1;
 
+	if (!idx->terms_path) {
+		idx->terms_path = strdup(terms_path);
+		idx->dtmap_path = strdup(dtmap_path);
+	}
 	if ((idx->tmap = map_file(terms_path, &idx->tmap_len)) == NULL) {
 		nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM,
 		    "could not open terms index: %s", strerror(errno));
@@ -662,6 +666,8 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 		bad = nxsgpu_index_first_bad_doc(idx->dev);
 		if (bad == UINT64_MAX) {
 			idx->n_docs = n;
+			idx->terms_seen = rd32(idx->tmap + 8);
+			idx->dt_seen = rd64(idx->dmap + 8);
 			ret = 0;
 			break;
 		}
@@ -683,8 +689,8 @@ out:
 	return ret;
 }
 
-void
-nxs_index_unload(nxs_index_t *idx)
+static void
+unload_snapshot(nxs_index_t *idx)
 {
 	if (idx->dev) {
 		nxsgpu_index_destroy(idx->dev);
@@ -693,6 +699,56 @@ nxs_index_unload(nxs_index_t *idx)
 	free(idx->thash);
 	if (idx->tmap) munmap(idx->tmap, idx->tmap_len);
 	if (idx->dmap) munmap(idx->dmap, idx->dmap_len);
+	idx->dev = NULL;
+	idx->terms = NULL;
+	idx->thash = NULL;
+	idx->thash_cap = 0;
+	idx->tmap = idx->dmap = NULL;
+	idx->last_id = idx->term_count = 0;
+	idx->n_docs = 0;
+}
+
+void
+nxs_index_unload(nxs_index_t *idx)
+{
+	unload_snapshot(idx);
+	free(idx->terms_path);
+	free(idx->dtmap_path);
+	idx->terms_path = idx->dtmap_path = NULL;
+}
+
+/*
+ * The reference re-syncs appended data before every search (search.c:309-312:
+ * idx_terms_sync + idx_dtmap_sync).  The device index is an immutable
+ * snapshot keyed by the two published data_len fields; when another process
+ * has appended (or removed: that appends a tombstone) since, the snapshot is
+ * rebuilt from the files.  Returns 0 (fresh or rebuilt) or -1.
+ */
+int
+nxs_index_refresh(nxs_index_t *idx)
+{
+	uint64_t t_now, d_now;
+
+	if (!idx->tmap || !idx->dmap) {
+		return -1;
+	}
+	/* data_len is published last, with release semantics (terms.c:303-305,
+	 * dtmap.c:333-337): an acquire load pairs with it */
+	t_now = be32toh(__atomic_load_n((const uint32_t *)(idx->tmap + 8), __ATOMIC_ACQUIRE));
+	d_now = be64toh(__atomic_load_n((const uint64_t *)(idx->dmap + 8), __ATOMIC_ACQUIRE));
+	if (t_now == idx->terms_seen && d_now == idx->dt_seen) {
+		return 0;
+	}
+	{
+		char *tp = strdup(idx->terms_path), *dp = strdup(idx->dtmap_path);
+		int r;
+
+		unload_snapshot(idx);
+		r = nxs_index_load(idx, tp, dp);
+		free(tp);
+		free(dp);
+		return r;
+	}
 }
 
 /* exact Levenshtein of the host side (BK build), exported for the tests */

@@ -339,3 +339,34 @@ def test_sharded_search_single_rank(nxs, tmp_path):
         got = list(zip(ids[i, :n].tolist(), sc[i, :n].tolist()))
         assert_same(got, want, q)
     gidx.close()
+
+
+def test_search_resyncs_appended_and_removed_docs(nxs, tmp_path):
+    """search.c:309-312: every search first picks up what other processes
+    appended.  The files are rewritten IN PLACE (same inode, MAP_SHARED), body
+    first and the header's data_len last, like the reference's publish order."""
+    docs = [(1, "cat dog cow".split()), (2, "dog cow".split())]
+    t, d, _ = nxsfmt.write_index(str(tmp_path), "idx", docs)
+    gidx = nxs.open_files(t, d)
+    assert [x for x, _ in gidx.search("cat")] == [1]
+
+    def publish(all_docs, removed=()):
+        timg, dimg, _ = nxsfmt.build_images(all_docs, removed)
+        for path, img, hdr in ((t, timg, 16), (d, dimg, 32)):
+            with open(path, "r+b") as f:
+                f.seek(hdr)
+                f.write(img[hdr:])
+                f.flush()
+                f.seek(0)
+                f.write(img[:hdr])
+    docs2 = docs + [(3, "cat cat cat".split()), (7, "emu cat".split())]
+    publish(docs2)
+    oidx = O.Index(t, d)
+    for q in ("cat", "emu", "dog OR emu"):
+        assert_same(gidx.search(q), oidx.search(q), q)
+    assert [x for x, _ in gidx.search("cat")][0] == 3
+    publish(docs2, removed=[3])
+    oidx = O.Index(t, d)
+    for q in ("cat", "emu", "cow"):
+        assert_same(gidx.search(q), oidx.search(q), q)
+    gidx.close()

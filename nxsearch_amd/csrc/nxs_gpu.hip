@@ -286,7 +286,6 @@ struct scan_args_t {
 	uint32_t *		cand_doc;
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
-	uint32_t		ablate;		/* timing experiments only (NXS_GPU_ABLATE) */
 };
 
 /* lower bound of `doc` in post[lo, hi) by doc ordinal */
@@ -657,6 +656,14 @@ k_scan(const scan_args_t A)
  *    of them is exhausted -- the device analogue of intersecting the bitmaps
  *    before scoring (search.c:118-174).
  */
+/*
+ * A workgroup here is ONE wavefront: its DS operations execute in issue order,
+ * so cross-lane LDS hand-offs need no s_barrier -- and must not get one:
+ * __syncthreads() also drains vmcnt(0), i.e. every posting prefetch in flight.
+ * This only stops the compiler from moving memory operations across the point.
+ */
+#define	WAVE_SYNC()	__builtin_amdgcn_wave_barrier()
+
 #define	LIST_CAP	512
 #define	TCAND_CAP	64
 
@@ -664,8 +671,8 @@ template <int MODE, int NT>
 __global__ void __launch_bounds__(WAVE)
 k_scan8(const scan_args_t A)
 {
-	__shared__ float s_acc[TILE_W];
-	__shared__ uint8_t s_mask8[TILE_W];
+	__shared__ float s_acc[TILE_W + WAVE];		/* + one dummy slot per lane */
+	__shared__ uint8_t s_mask8[TILE_W + WAVE];
 	__shared__ uint16_t s_list[LIST_CAP];
 	__shared__ uint32_t s_cd[TCAND_CAP];
 	__shared__ float s_cs[TCAND_CAP];
@@ -688,100 +695,104 @@ k_scan8(const scan_args_t A)
 	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
 	uint32_t *s_mask32 = (uint32_t *)s_mask8;
 
-	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
+	for (uint32_t i = lane; i < TILE_W + WAVE; i += WAVE) {
 		s_acc[i] = 0.0f;
-	}
-	for (uint32_t i = lane; i < TILE_W / 4; i += WAVE) {
-		s_mask32[i] = 0;
+		s_mask8[i] = 0;
 	}
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
 	}
-	__syncthreads();
+	WAVE_SYNC();
 
-	/* wave-uniform per-term state (readfirstlane keeps it scalar) */
+	/*
+	 * Wave-uniform per-term state, kept scalar: ab = list index of lane 0 of
+	 * set A's window 0; vm[k] = lanes of window k not consumed yet (a 64-bit
+	 * mask: consuming the in-tile lanes is one s_andn2, the next highest doc
+	 * one s_flbit + v_readlane); lo = first posting of this wavefront's doc
+	 * range; pdoc = doc of the highest unconsumed posting or -1.
+	 */
 	const posting_t *pt[NT];
-	int32_t hi[NT], lo[NT], pdoc[NT];
+	int32_t ab[NT], lo[NT], pdoc[NT];
+	uint64_t vm[NT][K];
 	uint32_t Ad[NT][K], Bd[NT][K];
 	float Ai[NT][K], Bi[NT][K];
 
-	/* (re)load both register sets of term t for cursor hi[t]; sets pdoc */
-	auto load_sets = [&](auto tc) {
-		constexpr int t = decltype(tc)::value;
-		pdoc[t] = -1;
-#pragma unroll
-		for (int k = 0; k < K; k++) {
-			Ad[t][k] = Bd[t][k] = 0;
-			Ai[t][k] = Bi[t][k] = 0.0f;
+	/* lanes of the window starting at list index wb that lie in [lo_, hi_) */
+	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
+		const int32_t a = max(lo_ - wb, 0), e = min(hi_ - wb, WAVE);
+		if (e <= a) {
+			return 0;
 		}
-		if (hi[t] > lo[t]) {
-			const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
-#pragma unroll
-			for (int k = 0; k < K; k++) {
-				const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
-				if (ia >= lo[t] && ia < hi[t]) {
-					const posting_t p = pt[t][ia];
-					Ad[t][k] = p.doc; Ai[t][k] = p.imp;
-				}
-				if (ib >= lo[t]) {
-					const posting_t p = pt[t][ib];
-					Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-				}
-			}
-			const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
-#pragma unroll
-			for (int k = 0; k < K; k++) {
-				if (k == kt) {
-					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-				}
-			}
-		}
+		const uint64_t upto = e >= WAVE ? ~0ull : ((1ull << e) - 1);
+		return upto & ~((1ull << a) - 1);
 	};
-	/* doc of the highest unconsumed posting of term t (or -1) */
 	auto refresh_pdoc = [&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		pdoc[t] = -1;
-		if (hi[t] > lo[t]) {
-			const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
 #pragma unroll
-			for (int k = 0; k < K; k++) {
-				if (k == kt) {
-					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-				}
+		for (int k = K - 1; k >= 0; k--) {
+			if (pdoc[t] < 0 && vm[t][k]) {
+				pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], 63 - __builtin_clzll(vm[t][k]));
 			}
 		}
 	};
-	/* set A drained: take over set B, put K new loads in flight */
-	auto rotate_sets = [&](auto tc, int32_t ab) {
+	/* (re)load both register sets of term t so that postings [lo, hi_) are
+	 * the unconsumed ones */
+	auto load_sets = [&](auto tc, int32_t hi_) {
 		constexpr int t = decltype(tc)::value;
+		pdoc[t] = -1;
+		ab[t] = 0;
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			vm[t][k] = 0;
+		}
+		if (hi_ > lo[t]) {
+			ab[t] = ((hi_ - 1) >> (6 + KSH)) << (6 + KSH);
+#pragma unroll
+			for (int k = 0; k < K; k++) {
+				/* clamped, unpredicated loads: validity lives in vm */
+				const int32_t ia = max(ab[t] + k * WAVE + (int32_t)lane, lo[t]);
+				const int32_t ib = max(ab[t] - SW + k * WAVE + (int32_t)lane, lo[t]);
+				const posting_t pa = pt[t][min(ia, hi_ - 1)];
+				const posting_t pb = pt[t][min(ib, hi_ - 1)];
+				Ad[t][k] = pa.doc; Ai[t][k] = pa.imp;
+				Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
+				vm[t][k] = window_mask(ab[t] + k * WAVE, lo[t], hi_);
+			}
+			refresh_pdoc(tc);
+		}
+	};
+	/* set A is drained: take over set B, put K new loads in flight */
+	auto rotate_sets = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		ab[t] -= SW;
 #pragma unroll
 		for (int k = 0; k < K; k++) {
 			Ad[t][k] = Bd[t][k];
 			Ai[t][k] = Bi[t][k];
+			vm[t][k] = window_mask(ab[t] + k * WAVE, lo[t], 0x7fffffff);
 		}
 #pragma unroll
 		for (int k = 0; k < K; k++) {
-			const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
-			Bd[t][k] = 0; Bi[t][k] = 0.0f;
-			if (ib >= lo[t]) {
-				const posting_t p = pt[t][ib];
-				Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-			}
+			const int32_t ib = max(ab[t] - SW + k * WAVE + (int32_t)lane, lo[t]);
+			const posting_t pb = pt[t][ib];
+			Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
 		}
 	};
 
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
+		int32_t hi0 = 0;
 		pt[t] = A.post;
-		hi[t] = lo[t] = 0;
+		lo[t] = 0;
 		if (t < (int)nt) {
 			const int32_t n = (int32_t)(Q->pend[t] - Q->pbeg[t]);
 			pt[t] = A.post + Q->pbeg[t];
 			/* cursors of this wavefront's doc range [dlo, dhi) */
 			lo[t] = dlo ? wave_lower_bound(pt[t], 0, n, (uint32_t)dlo) : 0;
-			hi[t] = dhi >= A.n_docs ? n : wave_lower_bound(pt[t], lo[t], n, (uint32_t)dhi);
+			hi0 = dhi >= A.n_docs ? n : wave_lower_bound(pt[t], lo[t], n, (uint32_t)dhi);
 		}
-		load_sets(tc);
+		load_sets(tc, hi0);
 	});
 
 	float top = -INFINITY, thr = -INFINITY;
@@ -812,30 +823,19 @@ k_scan8(const scan_args_t A)
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
 				if (t < (int)nt && pdoc[t] >= (int32_t)bound) {
-					const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
-					const int32_t li = max(lo[t], ab);
-					const int32_t kl = (li >> 6) & (K - 1);
-					int32_t lowd = 0;
+					uint64_t left = 0;
 #pragma unroll
 					for (int k = 0; k < K; k++) {
-						if (k == kl) {
-							lowd = __builtin_amdgcn_readlane((int)Ad[t][k], li & 63);
-						}
+						vm[t][k] &= ~__ballot(Ad[t][k] >= bound);
+						left |= vm[t][k];
 					}
-					if (lowd < (int32_t)bound) {
-						/* the boundary is inside set A */
-						uint32_t cnt = 0;
-#pragma unroll
-						for (int k = 0; k < K; k++) {
-							const int32_t idx = ab + k * WAVE + (int32_t)lane;
-							cnt += __popcll(__ballot(idx >= lo[t] && idx < hi[t] && Ad[t][k] >= bound));
-						}
-						hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)cnt);
-						refresh_pdoc(tc);
+					if (left) {
+						refresh_pdoc(tc);	/* the boundary was inside set A */
 					} else {
 						/* the whole set is above it: jump */
-						hi[t] = li > lo[t] ? wave_lower_bound(pt[t], lo[t], li, bound) : lo[t];
-						load_sets(tc);
+						const int32_t li = max(lo[t], ab[t]);
+						const int32_t nh = li > lo[t] ? wave_lower_bound(pt[t], lo[t], li, bound) : lo[t];
+						load_sets(tc, nh);
 					}
 				}
 			});
@@ -861,53 +861,46 @@ k_scan8(const scan_args_t A)
 			constexpr int t = decltype(tc)::value;
 			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
 				for (;;) {
-					const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
-					bool in[K];
+					uint64_t inm[K];
 					float a0[K];
 					uint32_t m0[K], dd[K];
-					uint32_t ctot = 0, act = 0;	/* act: windows with in-tile postings */
+					bool inl[K];
 					bool more = true;	/* windows below may still be in the tile */
 
 					/*
 					 * Read phase, top window first.  A doc occurs once per
 					 * term, so the K windows touch distinct accumulators and
-					 * their LDS reads can all be in flight together.
+					 * their LDS reads can all be in flight together.  Lanes
+					 * without an in-tile posting work on a private dummy slot
+					 * (index TILE_W + lane) with impact 0: no exec-mask
+					 * juggling, the scalar unit is the scarce resource here.
 					 */
 #pragma unroll
 					for (int k = K - 1; k >= 0; k--) {
-						if (more && hi[t] > ab + k * WAVE) {
-							const int32_t idx = ab + k * WAVE + (int32_t)lane;
-							in[k] = idx >= lo[t] && idx < hi[t] && Ad[t][k] >= base;
-							const uint32_t c = __popcll(__ballot(in[k]));
-							const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
-							const int32_t bot_ = max(lo[t], ab + k * WAVE);
-							ctot += c;
-							if ((int32_t)c < top_ - bot_) {
-								more = false;	/* tile boundary inside this window */
-							}
-							if (c) {
-								act |= 1u << k;
-								dd[k] = Ad[t][k] - base;
-								if (in[k] && !(A.ablate & 2)) {
-									a0[k] = s_acc[dd[k]];
-									m0[k] = s_mask8[dd[k]];
-								}
+						inm[k] = 0;
+						if (more && vm[t][k]) {
+							const bool ge = Ad[t][k] >= base;
+							inm[k] = vm[t][k] & __ballot(ge);
+							vm[t][k] &= ~inm[k];
+							more = vm[t][k] == 0;	/* else: the tile ends in this window */
+							if (inm[k]) {
+								inl[k] = (inm[k] >> lane) & 1;
+								dd[k] = inl[k] ? Ad[t][k] - base : TILE_W + lane;
+								a0[k] = s_acc[dd[k]];
+								m0[k] = s_mask8[dd[k]];
 							}
 						}
 					}
 					/* write phase */
 #pragma unroll
 					for (int k = K - 1; k >= 0; k--) {
-						if (act & (1u << k)) {
-							bool first = false;
-							if (in[k] && !(A.ablate & 2)) {
-								const float v = a0[k] + Ai[t][k];
-								s_acc[dd[k]] = v;
-								s_mask8[dd[k]] = (uint8_t)(m0[k] | (1u << t));
-								first = m0[k] == 0;
-								tmax = fmaxf(tmax, v);
-							}
+						if (inm[k]) {
+							const float v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
+							s_acc[dd[k]] = v;
+							s_mask8[dd[k]] = (uint8_t)(m0[k] | (inl[k] ? (1u << t) : 0u));
+							tmax = fmaxf(tmax, v);
 							if (n_list <= LIST_CAP) {
+								const bool first = inl[k] && m0[k] == 0;
 								const uint64_t fb = __ballot(first);
 								const uint32_t nf = __popcll(fb);
 								if (n_list + nf <= LIST_CAP && first) {
@@ -917,9 +910,9 @@ k_scan8(const scan_args_t A)
 							}
 						}
 					}
-					hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
-					if (hi[t] == ab && hi[t] > lo[t]) {
-						rotate_sets(tc, ab);
+					if (more && ab[t] > lo[t]) {
+						/* the whole set was in the tile and postings remain */
+						rotate_sets(tc);
 						continue;
 					}
 					break;
@@ -927,12 +920,9 @@ k_scan8(const scan_args_t A)
 				refresh_pdoc(tc);
 			}
 		});
-		__syncthreads();
+		WAVE_SYNC();
 
 		bool full_scan = n_list > LIST_CAP;
-		if (A.ablate & 1) {
-			continue;
-		}
 		/*
 		 * Scores only grow while a tile is accumulated (all impacts are
 		 * positive), so a doc's final score is one of the values written.
@@ -957,7 +947,7 @@ k_scan8(const scan_args_t A)
 					}
 				}
 			}
-			__syncthreads();
+			WAVE_SYNC();
 			continue;
 		}
 		if (!full_scan) {
@@ -1000,7 +990,7 @@ k_scan8(const scan_args_t A)
 				ncand += ne;
 			}
 			if (!full_scan) {
-				__syncthreads();
+				WAVE_SYNC();
 				if (MODE != MODE_COUNT && ncand) {
 					/* rank by doc (descending) so the segment stays ordered */
 					uint32_t cd = 0, rank = 0;
@@ -1099,7 +1089,7 @@ k_scan8(const scan_args_t A)
 				}
 			}
 		}
-		__syncthreads();
+		WAVE_SYNC();
 	}
 
 	if (lane == 0) {
@@ -1280,7 +1270,7 @@ k_scanh(const scan_args_t A)
 		}
 		s_init[lane] = v;
 	}
-	__syncthreads();
+	WAVE_SYNC();
 
 	/* wave-uniform per-term state */
 	const posting_t *pt[NT];
@@ -1452,7 +1442,7 @@ k_scanh(const scan_args_t A)
 				}
 			}
 		}
-		__syncthreads();
+		WAVE_SYNC();
 
 		/* candidates of this step (skipped when nothing beat the threshold:
 		 * scores only grow within a step, see k_scan8) */
@@ -1488,7 +1478,7 @@ k_scanh(const scan_args_t A)
 				ncand += __popcll(bal);
 			}
 			if (MODE != MODE_COUNT && ncand) {
-				__syncthreads();
+				WAVE_SYNC();
 				if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
 					ovf = true;
 				} else {
@@ -1531,7 +1521,7 @@ k_scanh(const scan_args_t A)
 				s_msk[slot] = 0;
 			}
 		}
-		__syncthreads();
+		WAVE_SYNC();
 	}
 
 	if (lane == 0) {
@@ -1665,43 +1655,63 @@ k_replay(const replay_args_t A)
 	}
 	__syncthreads();
 
-	/* candidates: groups in descending doc range, each already descending */
+	/* candidates: groups in descending doc range, each already descending.
+	 * Segment counts are fetched 64 at a time (one lane each) and empty
+	 * segments -- most of them, once thresholds have warmed up -- are skipped
+	 * without a memory round trip. */
 	const qmeta_t qm = A.qmeta[q];
-	for (int g = (int)qm.n_groups - 1; g >= 0 && cap; g--) {
-		const uint64_t seg = (uint64_t)qm.seg_first + g;
-		const uint64_t sb = A.seg_cap ? seg * A.seg_cap : A.seg_off[seg];
-		const uint32_t n = A.seg_cap ? A.seg_count[seg]
-		    : (uint32_t)(A.seg_off[seg + 1] - A.seg_off[seg]);
-
-		for (uint32_t off = 0; off < n; off += WAVE) {
-			const uint32_t i = off + lane;
-			const bool valid = i < n;
-			float sc = 0.0f;
-			uint32_t dc = 0;
-			if (valid) {
-				sc = A.cand_sc[sb + i];
-				dc = A.cand_doc[sb + i];
+	for (int g0 = (int)qm.n_groups; g0 > 0 && cap; g0 -= WAVE) {
+		const int gi = g0 - 1 - (int)lane;
+		uint32_t cnt_l = 0;
+		uint64_t sb_l = 0;
+		if (gi >= 0) {
+			const uint64_t seg_l = (uint64_t)qm.seg_first + gi;
+			if (A.seg_cap) {
+				cnt_l = A.seg_count[seg_l];
+				sb_l = seg_l * A.seg_cap;
+			} else {
+				sb_l = A.seg_off[seg_l];
+				cnt_l = (uint32_t)(A.seg_off[seg_l + 1] - sb_l);
 			}
-			/* heap.c:68-74: when full, an item <= the root is dropped
-			 * without touching the heap */
-			uint32_t nn = s_n;
-			float mn = s_min;
-			uint64_t pend = __ballot(valid && (nn < cap || sc > mn));
-			while (pend) {
-				const int L = __ffsll((long long)pend) - 1;
-				const float v = __shfl(sc, L);
-				const uint32_t dv = (uint32_t)__shfl((int)dc, L);
-				if (lane == 0) {
-					uint32_t cnt = s_n;
-					heap_add(hs, hd, &cnt, cap, v, dv);
-					s_n = cnt;
-					s_min = hs[0];
+		}
+		uint64_t nonempty = __ballot(cnt_l > 0);
+		while (nonempty) {
+			const int Lg = __ffsll((long long)nonempty) - 1;
+			nonempty &= nonempty - 1;
+			const uint32_t n = (uint32_t)__shfl((int)cnt_l, Lg);
+			const uint64_t sb = ((uint64_t)(uint32_t)__shfl((int)(sb_l >> 32), Lg) << 32) |
+			    (uint32_t)__shfl((int)(uint32_t)sb_l, Lg);
+
+			for (uint32_t off = 0; off < n; off += WAVE) {
+				const uint32_t i = off + lane;
+				const bool valid = i < n;
+				float sc = 0.0f;
+				uint32_t dc = 0;
+				if (valid) {
+					sc = A.cand_sc[sb + i];
+					dc = A.cand_doc[sb + i];
 				}
-				__syncthreads();
-				nn = s_n;
-				mn = s_min;
-				pend &= pend - 1;
-				pend &= __ballot(valid && (nn < cap || sc > mn));
+				/* heap.c:68-74: when full, an item <= the root is dropped
+				 * without touching the heap */
+				uint32_t nn = s_n;
+				float mn = s_min;
+				uint64_t pend = __ballot(valid && (nn < cap || sc > mn));
+				while (pend) {
+					const int L = __ffsll((long long)pend) - 1;
+					const float v = __shfl(sc, L);
+					const uint32_t dv = (uint32_t)__shfl((int)dc, L);
+					if (lane == 0) {
+						uint32_t cnt = s_n;
+						heap_add(hs, hd, &cnt, cap, v, dv);
+						s_n = cnt;
+						s_min = hs[0];
+					}
+					__syncthreads();
+					nn = s_n;
+					mn = s_min;
+					pend &= pend - 1;
+					pend &= __ballot(valid && (nn < cap || sc > mn));
+				}
 			}
 		}
 	}
@@ -2532,7 +2542,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.cand_doc = d_cand_doc;
 	sa.cand_sc = d_cand_sc;
 	sa.overflow = d_ovf;
-	sa.ablate = getenv("NXS_GPU_ABLATE") ? (uint32_t)atoi(getenv("NXS_GPU_ABLATE")) : 0;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {

@@ -648,7 +648,8 @@ k_scan(const scan_args_t A)
  *    descending doc order.  Dense tiles (list overflow) and tiles with more
  *    than 64 candidates take the ordered full scan;
  *  - scores only grow while a tile is accumulated, so if no value written in
- *    the tile beat the candidate threshold the tile is just wiped;
+ *    the tile (to a doc holding every required term) beat the candidate
+ *    threshold the tile is just wiped;
  *  - terms that every matching doc must contain (`req`, from the truth table)
  *    drive the tile choice: the next tile is that of the LOWEST of their
  *    highest remaining docs, everything above it is skipped with a 64-ary
@@ -678,7 +679,7 @@ k_scan8(const scan_args_t A)
 	__shared__ float s_cs[TCAND_CAP];
 	__shared__ uint32_t s_truth[8];
 
-	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : NT <= 5 ? 1 : 0;
+	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : 0;
 	constexpr int K = 1 << KSH;
 	constexpr int SW = WAVE * K;
 
@@ -896,9 +897,14 @@ k_scan8(const scan_args_t A)
 					for (int k = K - 1; k >= 0; k--) {
 						if (inm[k]) {
 							const float v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
+							const uint32_t bits = m0[k] | (inl[k] ? (1u << t) : 0u);
 							s_acc[dd[k]] = v;
-							s_mask8[dd[k]] = (uint8_t)(m0[k] | (inl[k] ? (1u << t) : 0u));
-							tmax = fmaxf(tmax, v);
+							s_mask8[dd[k]] = (uint8_t)bits;
+							/* only docs that already hold every required
+							 * term can become candidates */
+							if ((bits & req) == req) {
+								tmax = fmaxf(tmax, v);
+							}
 							if (n_list <= LIST_CAP) {
 								const bool first = inl[k] && m0[k] == 0;
 								const uint64_t fb = __ballot(first);
@@ -2303,7 +2309,7 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 	const uint64_t min_post = env2 ? strtoull(env2, NULL, 10) : 4096;
 	/* densest term has >= this many postings per tile => tile path */
 	const char *env3 = getenv("NXS_GPU_DENSE");
-	const double dense_thr = env3 ? atof(env3) : 32.0;
+	const double dense_thr = env3 ? atof(env3) : 0.0;	/* step path off by default: the tile path is at least as fast */
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -2322,7 +2328,7 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			cls[i] = 0;
 		} else {
 			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
-			const bool tile = per_tile >= dense_thr || hq[i].nt <= 1 ||
+			const bool tile = dense_thr <= 0.0 || per_tile >= dense_thr || hq[i].nt <= 1 ||
 			    ix->n_docs >= (1ull << 31) || getenv("NXS_GPU_NOSTEP");
 			cls[i] = (tile ? 1u : 2u) * 16 + nt_bucket(hq[i].nt);
 		}

@@ -299,7 +299,7 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
     gidx.close()
 
 
-@pytest.mark.parametrize("env", [{"NXS_GPU_DENSE": "0"}, {"NXS_GPU_DENSE": "1e12"},
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_DENSE": "1e12"}, {"NXS_GPU_DENSE": "8"},
                                  {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
                                  {"NXS_GPU_NOREQ": "1"}, {"NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):

@@ -279,6 +279,7 @@ struct scan_args_t {
 	const qmeta_t *		qmeta;		/* [Q] */
 	const item_t *		items;		/* (query, group) work items */
 	uint32_t		item_base;	/* first item of this launch */
+	const uint32_t *	cursors;	/* [(segments + Q)][MAX_TOKENS]: list position of each range boundary */
 	uint32_t		k;		/* limit (<= 64 in MODE_TOPK) */
 	uint32_t		seg_cap;
 	uint32_t *		seg_count;	/* [segments] */
@@ -287,6 +288,46 @@ struct scan_args_t {
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
 };
+
+/*
+ * k_cursors: where every (query, range boundary) falls in every term's list.
+ * Boundary b of query q is doc b * group_docs; wavefront g of the query then
+ * owns postings [cur[g][t], cur[g+1][t]).  One thread per (boundary, token):
+ * a plain binary search -- ~24 cache lines each, the top levels shared by all
+ * boundaries of a list -- done once per batch instead of by every wavefront.
+ */
+__global__ void
+k_cursors(const posting_t *__restrict__ post, const dev_query_t *__restrict__ queries,
+    const qmeta_t *__restrict__ qmeta, const uint32_t *__restrict__ bnd_q,
+    uint32_t n_bnd, uint64_t n_docs, uint32_t *__restrict__ cursors)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t b = i / NXSGPU_MAX_TOKENS, t = i % NXSGPU_MAX_TOKENS;
+	if (b >= n_bnd) {
+		return;
+	}
+	const uint32_t q = bnd_q[b];
+	const qmeta_t qm = qmeta[q];
+	const dev_query_t *Q = &queries[q];
+	if (t >= Q->nt) {
+		return;
+	}
+	const uint32_t g = b - (qm.seg_first + q);
+	const uint64_t doc = min((uint64_t)g * qm.group_docs, n_docs);
+	const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+	uint64_t lo = pb, hi = pe;
+	if (doc >= n_docs) {
+		lo = pe;
+	} else if (doc == 0) {
+		lo = pb;
+	} else {
+		while (lo < hi) {
+			const uint64_t mid = lo + ((hi - lo) >> 1);
+			if (post[mid].doc < doc) lo = mid + 1; else hi = mid;
+		}
+	}
+	cursors[(uint64_t)b * NXSGPU_MAX_TOKENS + t] = (uint32_t)(lo - pb);
+}
 
 /* lower bound of `doc` in post[lo, hi) by doc ordinal */
 __device__ static inline uint64_t
@@ -409,8 +450,6 @@ k_scan(const scan_args_t A)
 	const uint32_t nt = Q->nt;
 	const posting_t *__restrict__ post = A.post;
 	const uint64_t seg = (uint64_t)qm.seg_first + g;
-	const uint64_t dlo = (uint64_t)g * qm.group_docs;
-	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
 
 	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 		s_acc[i] = 0.0f;
@@ -428,11 +467,12 @@ k_scan(const scan_args_t A)
 	if (lane < nt || (lane >= 32 && lane - 32 < nt)) {
 		const uint32_t t = lane & 31;
 		const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+		const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+		(void)pe;
 		if (lane < 32) {
-			const uint64_t h = post_lower_bound(post, pb, pe, dhi);
-			s_hi[t] = h;
+			s_hi[t] = pb + A.cursors[cb + NXSGPU_MAX_TOKENS];
 		} else {
-			s_lo[t] = post_lower_bound(post, pb, pe, dlo);
+			s_lo[t] = pb + A.cursors[cb];
 		}
 	}
 	__syncthreads();
@@ -692,8 +732,6 @@ k_scan8(const scan_args_t A)
 	const uint32_t nt = Q->nt;
 	const uint32_t req = (MODE == MODE_TOPK || MODE == MODE_COUNT || MODE == MODE_ALL) ? Q->req : 0;
 	const uint64_t seg = (uint64_t)qm.seg_first + g;
-	const uint64_t dlo = (uint64_t)g * qm.group_docs;
-	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
 	uint32_t *s_mask32 = (uint32_t *)s_mask8;
 
 	for (uint32_t i = lane; i < TILE_W + WAVE; i += WAVE) {
@@ -789,9 +827,11 @@ k_scan8(const scan_args_t A)
 		if (t < (int)nt) {
 			const int32_t n = (int32_t)(Q->pend[t] - Q->pbeg[t]);
 			pt[t] = A.post + Q->pbeg[t];
-			/* cursors of this wavefront's doc range [dlo, dhi) */
-			lo[t] = dlo ? wave_lower_bound(pt[t], 0, n, (uint32_t)dlo) : 0;
-			hi0 = dhi >= A.n_docs ? n : wave_lower_bound(pt[t], lo[t], n, (uint32_t)dhi);
+			/* cursors of this wavefront's doc range [dlo, dhi): k_cursors */
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+			(void)n;
+			lo[t] = (int32_t)A.cursors[cb];
+			hi0 = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
 		}
 		load_sets(tc, hi0);
 	});
@@ -1136,8 +1176,10 @@ k_scan1(const scan_args_t A)
 	bool ovf = false;
 
 	if (matches) {
-		lo = dlo ? wave_lower_bound(pt, 0, n, (uint32_t)dlo) : 0;
-		hi = dhi >= A.n_docs ? n : wave_lower_bound(pt, lo, n, (uint32_t)dhi);
+		const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS;
+		(void)n; (void)dlo; (void)dhi;
+		lo = (int32_t)A.cursors[cb];
+		hi = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
 	}
 	if (MODE == MODE_COUNT) {
 		if (lane == 0) {
@@ -1271,8 +1313,9 @@ k_scanh(const scan_args_t A)
 		const uint32_t t = lane & 7;
 		int64_t v = 0;
 		if (t < nt) {
-			const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
-			v = (int64_t)(post_lower_bound(A.post, pb, pe, lane < 8 ? dhi : dlo) - pb);
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+			(void)dlo; (void)dhi;
+			v = (int64_t)A.cursors[cb + (lane < 8 ? NXSGPU_MAX_TOKENS : 0)];
 		}
 		s_init[lane] = v;
 	}
@@ -2289,6 +2332,7 @@ struct worklist_t {
 	std::vector<qmeta_t>	qmeta;
 	std::vector<item_t>	items;
 	std::vector<launch_t>	launches;
+	std::vector<uint32_t>	bnd_q;		/* boundary -> query, n_segs + nq entries */
 	uint32_t		n_segs;
 };
 
@@ -2357,6 +2401,14 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 		wl.qmeta[i].seg_first = wl.n_segs;
 		wl.n_segs += wl.qmeta[i].n_groups;
 	}
+	wl.bnd_q.clear();
+	wl.bnd_q.reserve((size_t)wl.n_segs + nq);
+	for (uint32_t i = 0; i < nq; i++) {
+		/* query i owns boundaries seg_first + i ... + n_groups (inclusive) */
+		for (uint32_t g = 0; g <= wl.qmeta[i].n_groups; g++) {
+			wl.bnd_q.push_back(i);
+		}
+	}
 	wl.items.reserve(wl.n_segs);
 	for (uint32_t oi = 0; oi < nq; oi++) {
 		const uint32_t i = order[oi];
@@ -2376,6 +2428,16 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			wl.items.push_back(it);
 		}
 		wl.launches.back().count = (uint32_t)wl.items.size() - wl.launches.back().first;
+	}
+}
+
+static void
+launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd)
+{
+	const uint64_t threads = (uint64_t)n_bnd * NXSGPU_MAX_TOKENS;
+	if (n_bnd) {
+		hipLaunchKernelGGL(k_cursors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
+		    a.post, a.queries, a.qmeta, d_bnd_q, n_bnd, a.n_docs, (uint32_t *)a.cursors);
 	}
 }
 
@@ -2510,6 +2572,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	{
 		size_t need = 8192 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
+		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + 1024
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
 		if (!ensure_ws(ix, need)) {
 			return -1;
@@ -2521,6 +2584,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	d_items = carve<item_t>(p, nseg);
 	d_seg_count = carve<uint32_t>(p, nseg);
 	d_ovf = carve<uint32_t>(p, nq);
+	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
 	d_ids = dev_out ? d_out_ids : carve<uint64_t>(p, (size_t)nq * kfast);
@@ -2530,6 +2595,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	if (hipMemcpyAsync(d_q, hq.data(), nq * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_items, wl.items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+	    hipMemcpyAsync(d_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
@@ -2548,10 +2614,12 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.cand_doc = d_cand_doc;
 	sa.cand_sc = d_cand_sc;
 	sa.overflow = d_ovf;
+	sa.cursors = d_cursors;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
+		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
 		launch_scan<MODE_TOPK>(ix, sa, wl);
 		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
 
@@ -2664,8 +2732,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		/* device copies of the subset's queries / work list */
 		void *xmeta = NULL;
 		{
-			const size_t mneed = 4096 + nx * sizeof(dev_query_t) + nx * sizeof(qmeta_t)
-			    + xseg * sizeof(item_t) + xseg * 4;
+			const size_t mneed = 8192 + nx * sizeof(dev_query_t) + nx * sizeof(qmeta_t)
+			    + xseg * sizeof(item_t) + xseg * 4
+			    + (xseg + nx) * 4 * (1 + NXSGPU_MAX_TOKENS);
 			if (hipMalloc(&xmeta, mneed) != hipSuccess) {
 				set_error("hipMalloc(%zu) for the exact pass failed", mneed);
 				return -1;
@@ -2676,11 +2745,14 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		qmeta_t *dx_qmeta = carve<qmeta_t>(mp, nx);
 		item_t *dx_items = carve<item_t>(mp, xseg);
 		uint32_t *dx_seg_count = carve<uint32_t>(mp, xseg);
+		uint32_t *dx_bnd_q = carve<uint32_t>(mp, xseg + nx);
+		uint32_t *dx_cursors = carve<uint32_t>(mp, (xseg + nx) * NXSGPU_MAX_TOKENS);
 
 		/* pass 1: count */
 		if (hipMemcpyAsync(dx_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(dx_qmeta, xwl.qmeta.data(), nx * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_bnd_q, xwl.bnd_q.data(), (xseg + nx) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
 			set_error("query upload failed");
 			(void)hipFree(xmeta);
 			return -1;
@@ -2689,7 +2761,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		sa.qmeta = dx_qmeta;
 		sa.items = dx_items;
 		sa.seg_count = dx_seg_count;
+		sa.cursors = dx_cursors;
 		sa.k = 0xffffffffu;
+		launch_cursors(ix, sa, dx_bnd_q, (uint32_t)(xseg + nx));
 		launch_scan<MODE_COUNT>(ix, sa, xwl);
 		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {

@@ -172,9 +172,10 @@ def main():
         + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / max(prof["launches"], 1)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "k_scan8", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic(args, world),
                 "alg_bytes_per_launch": int(alg_bytes),
                 "kernel_ms": round(scan_ms, 4),
                 "replay_ms": round(prof["replay_ms"] / max(prof["launches"], 1), 4)}
@@ -207,6 +208,22 @@ def main():
             shutil.rmtree(work, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per k_scan8 launch from the committed rocprofv3 --pmc passes
+    (profiles/r1_final_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
+    valid only for the workload they were collected on; else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")) as f:
+            p = json.load(f)
+        w = p["workload"]
+        if (w["docs"], w["terms"], w["batch"], w["limit"]) == \
+                (args.docs, args.terms, args.batch, args.limit) and world == 1:
+            return int(p["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def side_measurements(args, idx, terms, queries, torch):

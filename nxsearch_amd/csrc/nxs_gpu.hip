@@ -708,12 +708,14 @@ k_scan(const scan_args_t A)
 #define	LIST_CAP	512
 #define	TCAND_CAP	64
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool HASMASK>
 __global__ void __launch_bounds__(WAVE)
 k_scan8(const scan_args_t A)
 {
 	__shared__ float s_acc[TILE_W + WAVE];		/* + one dummy slot per lane */
-	__shared__ uint8_t s_mask8[TILE_W + WAVE];
+	/* HASMASK = false: pure-OR queries (every non-empty presence mask matches):
+	 * a doc matches iff it was touched, i.e. iff its score is > 0; no mask array */
+	__shared__ uint8_t s_mask8[HASMASK ? TILE_W + WAVE : 4];
 	__shared__ uint16_t s_list[LIST_CAP];
 	__shared__ uint32_t s_cd[TCAND_CAP];
 	__shared__ float s_cs[TCAND_CAP];
@@ -736,7 +738,9 @@ k_scan8(const scan_args_t A)
 
 	for (uint32_t i = lane; i < TILE_W + WAVE; i += WAVE) {
 		s_acc[i] = 0.0f;
-		s_mask8[i] = 0;
+		if (HASMASK) {
+			s_mask8[i] = 0;
+		}
 	}
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
@@ -928,7 +932,7 @@ k_scan8(const scan_args_t A)
 								inl[k] = (inm[k] >> lane) & 1;
 								dd[k] = inl[k] ? Ad[t][k] - base : TILE_W + lane;
 								a0[k] = s_acc[dd[k]];
-								m0[k] = s_mask8[dd[k]];
+								m0[k] = HASMASK ? s_mask8[dd[k]] : 0;
 							}
 						}
 					}
@@ -937,16 +941,20 @@ k_scan8(const scan_args_t A)
 					for (int k = K - 1; k >= 0; k--) {
 						if (inm[k]) {
 							const float v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
-							const uint32_t bits = m0[k] | (inl[k] ? (1u << t) : 0u);
 							s_acc[dd[k]] = v;
-							s_mask8[dd[k]] = (uint8_t)bits;
-							/* only docs that already hold every required
-							 * term can become candidates */
-							if ((bits & req) == req) {
+							if (HASMASK) {
+								const uint32_t bits = m0[k] | (inl[k] ? (1u << t) : 0u);
+								s_mask8[dd[k]] = (uint8_t)bits;
+								/* only docs that already hold every required
+								 * term can become candidates */
+								if ((bits & req) == req) {
+									tmax = fmaxf(tmax, v);
+								}
+							} else {
 								tmax = fmaxf(tmax, v);
 							}
 							if (n_list <= LIST_CAP) {
-								const bool first = inl[k] && m0[k] == 0;
+								const bool first = inl[k] && (HASMASK ? m0[k] == 0 : a0[k] == 0.0f);
 								const uint64_t fb = __ballot(first);
 								const uint32_t nf = __popcll(fb);
 								if (n_list + nf <= LIST_CAP && first) {
@@ -980,8 +988,10 @@ k_scan8(const scan_args_t A)
 				for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 					s_acc[i] = 0.0f;
 				}
-				for (uint32_t i = lane; i < TILE_W / 4; i += WAVE) {
-					s_mask32[i] = 0;
+				if (HASMASK) {
+					for (uint32_t i = lane; i < TILE_W / 4; i += WAVE) {
+						s_mask32[i] = 0;
+					}
 				}
 			} else {
 				for (uint32_t off = 0; off < n_list; off += WAVE) {
@@ -989,7 +999,9 @@ k_scan8(const scan_args_t A)
 					if (i < n_list) {
 						const uint32_t d = s_list[i];
 						s_acc[d] = 0.0f;
-						s_mask8[d] = 0;
+						if (HASMASK) {
+							s_mask8[d] = 0;
+						}
 					}
 				}
 			}
@@ -1006,11 +1018,11 @@ k_scan8(const scan_args_t A)
 				float sc = 0.0f;
 				if (valid) {
 					d = s_list[i];
-					m = s_mask8[d];
+					m = HASMASK ? s_mask8[d] : 1;	/* listed => touched */
 					sc = s_acc[d];
 				}
 				if (MODE == MODE_COUNT) {
-					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					const bool match = valid && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
 					n_out += __popcll(__ballot(match));
 					continue;
 				}
@@ -1018,7 +1030,7 @@ k_scan8(const scan_args_t A)
 				if (__ballot(pre) == 0) {
 					continue;
 				}
-				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				const bool cand = pre && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
 				const uint64_t bal = __ballot(cand);
 				if (!bal) {
 					continue;
@@ -1075,7 +1087,9 @@ k_scan8(const scan_args_t A)
 					if (i < n_list) {
 						const uint32_t d = s_list[i];
 						s_acc[d] = 0.0f;
-						s_mask8[d] = 0;
+						if (HASMASK) {
+							s_mask8[d] = 0;
+						}
 					}
 				}
 			}
@@ -1084,18 +1098,30 @@ k_scan8(const scan_args_t A)
 			/* dense tile: ordered scan, DESCENDING doc (results.c:143-147) */
 			for (int sidx = TILE_W / WAVE - 1; sidx >= 0; sidx--) {
 				const uint32_t d = sidx * WAVE + lane;
-				const uint32_t m = s_mask8[d];
-				if (__ballot(m != 0) == 0) {
-					continue;
-				}
 				float sc = 0.0f;
-				if (m) {
+				uint32_t m;
+				if (HASMASK) {
+					m = s_mask8[d];
+					if (__ballot(m != 0) == 0) {
+						continue;
+					}
+					if (m) {
+						sc = s_acc[d];
+						s_acc[d] = 0.0f;
+						s_mask8[d] = 0;
+					}
+				} else {
 					sc = s_acc[d];
-					s_acc[d] = 0.0f;
-					s_mask8[d] = 0;
+					m = sc != 0.0f;
+					if (__ballot(m != 0) == 0) {
+						continue;
+					}
+					if (m) {
+						s_acc[d] = 0.0f;
+					}
 				}
 				if (MODE == MODE_COUNT) {
-					const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					const bool match = m && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
 					n_out += __popcll(__ballot(match));
 					continue;
 				}
@@ -1103,7 +1129,7 @@ k_scan8(const scan_args_t A)
 				if (__ballot(pre) == 0) {
 					continue;
 				}
-				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				const bool cand = pre && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
 				uint64_t bal = __ballot(cand);
 				if (!bal) {
 					continue;
@@ -2326,7 +2352,7 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
  * paid once).  Items are grouped by kernel class (token-count bucket x
  * tile/step path) and emitted heaviest query first inside a class.
  */
-struct launch_t { uint32_t first, count, nt_bucket, kind; };	/* kind: 0 wide, 1 tile, 2 step */
+struct launch_t { uint32_t first, count, nt_bucket, kind, nomask; };	/* kind: 0 wide, 1 tile, 2 step */
 
 struct worklist_t {
 	std::vector<qmeta_t>	qmeta;
@@ -2374,7 +2400,12 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
 			const bool tile = dense_thr <= 0.0 || per_tile >= dense_thr || hq[i].nt <= 1 ||
 			    ix->n_docs >= (1ull << 31) || getenv("NXS_GPU_NOSTEP");
-			cls[i] = (tile ? 1u : 2u) * 16 + nt_bucket(hq[i].nt);
+			/* pure OR: every non-empty presence mask matches => no mask array */
+			bool or_only = hq[i].nt >= 2 && !getenv("NXS_GPU_NOMASKOFF");
+			for (uint32_t m = 1; or_only && m < (1u << hq[i].nt); m++) {
+				or_only = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
+			}
+			cls[i] = (tile ? 1u : 2u) * 32 + (tile && or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
 		}
 	}
 	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
@@ -2417,7 +2448,8 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			l.first = (uint32_t)wl.items.size();
 			l.count = 0;
 			l.nt_bucket = cls[i] & 15;
-			l.kind = cls[i] >> 4;
+			l.nomask = (cls[i] >> 4) & 1;
+			l.kind = cls[i] >> 5;
 			wl.launches.push_back(l);
 		}
 		/* descending ranges first: they are replayed first */
@@ -2461,15 +2493,15 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
 			switch (l.nt_bucket) {
 			case 1:
 				if (getenv("NXS_GPU_NOSCAN1")) {
-					hipLaunchKernelGGL((k_scan8<MODE, 1>), grid, block, 0, ix->stream, a);
+					hipLaunchKernelGGL((k_scan8<MODE, 1, true>), grid, block, 0, ix->stream, a);
 				} else {
 					hipLaunchKernelGGL((k_scan1<MODE>), grid, block, 0, ix->stream, a);
 				}
 				break;
-			case 2: hipLaunchKernelGGL((k_scan8<MODE, 2>), grid, block, 0, ix->stream, a); break;
-			case 3: hipLaunchKernelGGL((k_scan8<MODE, 3>), grid, block, 0, ix->stream, a); break;
-			case 5: hipLaunchKernelGGL((k_scan8<MODE, 5>), grid, block, 0, ix->stream, a); break;
-			default: hipLaunchKernelGGL((k_scan8<MODE, 8>), grid, block, 0, ix->stream, a); break;
+			case 2: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 2, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 2, true>), grid, block, 0, ix->stream, a); } break;
+			case 3: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 3, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 3, true>), grid, block, 0, ix->stream, a); } break;
+			case 5: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 5, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, true>), grid, block, 0, ix->stream, a); } break;
+			default: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 8, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, true>), grid, block, 0, ix->stream, a); } break;
 			}
 		} else {
 			switch (l.nt_bucket) {

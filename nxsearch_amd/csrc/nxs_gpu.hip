@@ -708,10 +708,22 @@ k_scan(const scan_args_t A)
 #define	LIST_CAP	512
 #define	TCAND_CAP	64
 
-template <int MODE, int NT, bool HASMASK>
+template <int MODE, int NT, int MM>
 __global__ void __launch_bounds__(WAVE)
 k_scan8(const scan_args_t A)
 {
+	/*
+	 * MM = 0: general boolean query, presence-mask byte per doc.
+	 * MM = 1: pure OR (every non-empty mask matches): a doc matches iff it was
+	 *         touched, i.e. iff its score is > 0 -- no mask array.
+	 * MM = 2: "a AND b" (exactly two tokens): no mask array either; token 0
+	 *         stores +score, token 1 only updates docs with a positive entry
+	 *         and stores -score (scores are positive; negation and fabs are
+	 *         exact), a doc matches iff its entry is negative.  One sign bit
+	 *         cannot chain three tokens, those use MM = 0.
+	 */
+	constexpr bool HASMASK = MM == 0;
+	constexpr bool ANDM = MM == 2;
 	__shared__ float s_acc[TILE_W + WAVE];		/* + one dummy slot per lane */
 	/* HASMASK = false: pure-OR queries (every non-empty presence mask matches):
 	 * a doc matches iff it was touched, i.e. iff its score is > 0; no mask array */
@@ -940,21 +952,35 @@ k_scan8(const scan_args_t A)
 #pragma unroll
 					for (int k = K - 1; k >= 0; k--) {
 						if (inm[k]) {
-							const float v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
-							s_acc[dd[k]] = v;
-							if (HASMASK) {
-								const uint32_t bits = m0[k] | (inl[k] ? (1u << t) : 0u);
-								s_mask8[dd[k]] = (uint8_t)bits;
-								/* only docs that already hold every required
-								 * term can become candidates */
-								if ((bits & req) == req) {
+							float v;
+							bool first;
+							if (ANDM) {
+								/* alive: carries the previous token's parity */
+								const bool alive = inl[k] && (t == 0 ||
+								    (a0[k] != 0.0f && (a0[k] < 0.0f) == (((t - 1) & 1) != 0)));
+								v = fabsf(a0[k]) + Ai[t][k];
+								s_acc[dd[k]] = alive ? ((t & 1) ? -v : v) : a0[k];
+								if (alive && t == (int)nt - 1) {
 									tmax = fmaxf(tmax, v);
 								}
+								first = inl[k] && t == 0;
 							} else {
-								tmax = fmaxf(tmax, v);
+								v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
+								s_acc[dd[k]] = v;
+								if (HASMASK) {
+									const uint32_t bits = m0[k] | (inl[k] ? (1u << t) : 0u);
+									s_mask8[dd[k]] = (uint8_t)bits;
+									/* only docs that already hold every required
+									 * term can become candidates */
+									if ((bits & req) == req) {
+										tmax = fmaxf(tmax, v);
+									}
+								} else {
+									tmax = fmaxf(tmax, v);
+								}
+								first = inl[k] && (HASMASK ? m0[k] == 0 : a0[k] == 0.0f);
 							}
 							if (n_list <= LIST_CAP) {
-								const bool first = inl[k] && (HASMASK ? m0[k] == 0 : a0[k] == 0.0f);
 								const uint64_t fb = __ballot(first);
 								const uint32_t nf = __popcll(fb);
 								if (n_list + nf <= LIST_CAP && first) {
@@ -1018,8 +1044,16 @@ k_scan8(const scan_args_t A)
 				float sc = 0.0f;
 				if (valid) {
 					d = s_list[i];
-					m = HASMASK ? s_mask8[d] : 1;	/* listed => touched */
 					sc = s_acc[d];
+					if (HASMASK) {
+						m = s_mask8[d];
+					} else if (ANDM) {
+						/* matched iff the last token's parity is on it */
+						m = sc != 0.0f && (sc < 0.0f) == (((nt - 1) & 1) != 0);
+						sc = fabsf(sc);
+					} else {
+						m = 1;		/* listed => touched */
+					}
 				}
 				if (MODE == MODE_COUNT) {
 					const bool match = valid && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
@@ -1118,6 +1152,10 @@ k_scan8(const scan_args_t A)
 					}
 					if (m) {
 						s_acc[d] = 0.0f;
+					}
+					if (ANDM) {
+						m = m && (sc < 0.0f) == (((nt - 1) & 1) != 0);
+						sc = fabsf(sc);
 					}
 				}
 				if (MODE == MODE_COUNT) {
@@ -2405,7 +2443,16 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			for (uint32_t m = 1; or_only && m < (1u << hq[i].nt); m++) {
 				or_only = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
 			}
-			cls[i] = (tile ? 1u : 2u) * 32 + (tile && or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
+			/* pure AND of exactly two tokens: only the full mask matches.
+			 * (The sign-parity scheme of MM = 2 cannot tell "stuck at token
+			 * t-2" from "updated by token t" for three tokens or more.) */
+			bool and_only = hq[i].nt == 2 && !getenv("NXS_GPU_NOMASKOFF");
+			for (uint32_t m = 1; and_only && m < (1u << hq[i].nt); m++) {
+				const bool hit = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
+				and_only = hit == (m == (1u << hq[i].nt) - 1);
+			}
+			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
+			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
 		}
 	}
 	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
@@ -2448,8 +2495,8 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			l.first = (uint32_t)wl.items.size();
 			l.count = 0;
 			l.nt_bucket = cls[i] & 15;
-			l.nomask = (cls[i] >> 4) & 1;
-			l.kind = cls[i] >> 5;
+			l.nomask = (cls[i] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 pure AND */
+			l.kind = cls[i] >> 6;
 			wl.launches.push_back(l);
 		}
 		/* descending ranges first: they are replayed first */
@@ -2493,15 +2540,15 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
 			switch (l.nt_bucket) {
 			case 1:
 				if (getenv("NXS_GPU_NOSCAN1")) {
-					hipLaunchKernelGGL((k_scan8<MODE, 1, true>), grid, block, 0, ix->stream, a);
+					hipLaunchKernelGGL((k_scan8<MODE, 1, 0>), grid, block, 0, ix->stream, a);
 				} else {
 					hipLaunchKernelGGL((k_scan1<MODE>), grid, block, 0, ix->stream, a);
 				}
 				break;
-			case 2: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 2, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 2, true>), grid, block, 0, ix->stream, a); } break;
-			case 3: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 3, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 3, true>), grid, block, 0, ix->stream, a); } break;
-			case 5: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 5, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, true>), grid, block, 0, ix->stream, a); } break;
-			default: if (l.nomask) { hipLaunchKernelGGL((k_scan8<MODE, 8, false>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, true>), grid, block, 0, ix->stream, a); } break;
+			case 2: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 2, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 2, 0>), grid, block, 0, ix->stream, a); } break;
+			case 3: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 3, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 3, 0>), grid, block, 0, ix->stream, a); } break;
+			case 5: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 5, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, 0>), grid, block, 0, ix->stream, a); } break;
+			default: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 8, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, 0>), grid, block, 0, ix->stream, a); } break;
 			}
 		} else {
 			switch (l.nt_bucket) {

@@ -315,7 +315,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
     T = lambda r: terms[r - 1].decode()
     qs = [T(rng.randint(1, 500)) for _ in range(8)]
     qs += corpus.queries_bool5(terms, 24, seed=6, hi=400)
-    qs += ["%s AND (%s OR %s)" % (T(900), T(2), T(3)), "%s AND NOT %s" % (T(1), T(2)),
+    qs += ["%s AND %s" % (T(1), T(2)), "%s AND %s" % (T(3), T(700)), "%s AND %s" % (T(2800), T(1)),
+           "%s AND (%s OR %s)" % (T(900), T(2), T(3)), "%s AND NOT %s" % (T(1), T(2)),
            "%s OR %s" % (T(2500), T(2900)), "(%s AND %s) OR %s" % (T(1), T(2), T(1500)),
            "%s AND %s AND %s" % (T(1), T(1200), T(3))]
     for limit in (10, 200):

@@ -1787,23 +1787,54 @@ k_replay(const replay_args_t A)
 				cnt_l = (uint32_t)(A.seg_off[seg_l + 1] - sb_l);
 			}
 		}
-		uint64_t nonempty = __ballot(cnt_l > 0);
-		while (nonempty) {
-			const int Lg = __ffsll((long long)nonempty) - 1;
-			nonempty &= nonempty - 1;
-			const uint32_t n = (uint32_t)__shfl((int)cnt_l, Lg);
-			const uint64_t sb = ((uint64_t)(uint32_t)__shfl((int)(sb_l >> 32), Lg) << 32) |
-			    (uint32_t)__shfl((int)(uint32_t)sb_l, Lg);
-
-			for (uint32_t off = 0; off < n; off += WAVE) {
-				const uint32_t i = off + lane;
-				const bool valid = i < n;
-				float sc = 0.0f;
-				uint32_t dc = 0;
-				if (valid) {
-					sc = A.cand_sc[sb + i];
-					dc = A.cand_doc[sb + i];
+		/*
+		 * The candidates of these 64 segments, in feed order (segment lane
+		 * ascending = doc range descending, then position), are packed 64
+		 * to a load by a prefix sum over the counts; RU chunks are in flight.
+		 */
+		uint32_t incl = cnt_l;
+		for (int o = 1; o < WAVE; o <<= 1) {
+			const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (unsigned)o) {
+				incl += v;
+			}
+		}
+		const uint32_t total = (uint32_t)__shfl((int)incl, WAVE - 1);
+		constexpr int RU = 4;
+		for (uint32_t c0 = 0; c0 < total; c0 += WAVE * RU) {
+			float scv[RU];
+			uint32_t dcv[RU];
+#pragma unroll
+			for (int u = 0; u < RU; u++) {
+				const uint32_t j = c0 + u * WAVE + lane;
+				scv[u] = 0.0f;
+				dcv[u] = 0;
+				/* segment lane sl = first lane with incl > j (binary search
+				 * over the lanes' inclusive sums) */
+				uint32_t sl = 0;
+#pragma unroll
+				for (int step = 32; step >= 1; step >>= 1) {
+					const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(sl + step - 1));
+					if (probe <= j) {
+						sl += step;
+					}
 				}
+				sl = min(sl, (uint32_t)WAVE - 1);
+				const uint32_t s_incl = (uint32_t)__shfl((int)incl, (int)sl);
+				const uint32_t s_cnt = (uint32_t)__shfl((int)cnt_l, (int)sl);
+				const uint64_t s_sb = ((uint64_t)(uint32_t)__shfl((int)(sb_l >> 32), (int)sl) << 32) |
+				    (uint32_t)__shfl((int)(uint32_t)sb_l, (int)sl);
+				if (j < total) {
+					const uint64_t at = s_sb + (j - (s_incl - s_cnt));
+					scv[u] = A.cand_sc[at];
+					dcv[u] = A.cand_doc[at];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < RU; u++) {
+				const bool valid = c0 + u * WAVE + lane < total;
+				const float sc = scv[u];
+				const uint32_t dc = dcv[u];
 				/* heap.c:68-74: when full, an item <= the root is dropped
 				 * without touching the heap */
 				uint32_t nn = s_n;

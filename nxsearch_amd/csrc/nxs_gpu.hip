@@ -287,6 +287,7 @@ struct scan_args_t {
 	uint32_t *		cand_doc;
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
+	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
 };
 
 /*
@@ -327,6 +328,41 @@ k_cursors(const posting_t *__restrict__ post, const dev_query_t *__restrict__ qu
 		}
 	}
 	cursors[(uint64_t)b * NXSGPU_MAX_TOKENS + t] = (uint32_t)(lo - pb);
+}
+
+/*
+ * Threshold hand-down between the wavefronts of one query.  A wavefront that
+ * has finished its doc range publishes the k-th largest score it met (if it
+ * met k).  The reference's heap is fed in descending doc id, so while range g
+ * is being fed the heap root is at least the k-th largest score of ANY
+ * higher range alone: a published value of a higher range is a valid
+ * candidate threshold for range g from its very first doc.  Values only ever
+ * make the filter tighter and a stale read (0 = nothing published yet, or an
+ * older value in a non-coherent L2) is merely less tight -- correctness never
+ * depends on visibility, so plain agent-scope relaxed accesses are enough.
+ */
+__device__ static inline float
+range_hint(const scan_args_t &A, const qmeta_t &qm, uint32_t g)
+{
+	const unsigned lane = threadIdx.x & 63;
+	float h = 0.0f;
+
+	for (uint32_t g2 = g + 1 + lane; g2 < qm.n_groups; g2 += WAVE) {
+		h = fmaxf(h, __hip_atomic_load(&A.pub[(uint64_t)qm.seg_first + g2],
+		    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	}
+	for (int o = 32; o; o >>= 1) {
+		h = fmaxf(h, __shfl_xor(h, o));
+	}
+	return h;
+}
+
+__device__ static inline void
+range_publish(const scan_args_t &A, uint64_t seg, float kth)
+{
+	if ((threadIdx.x & 63) == 0 && kth > 0.0f) {
+		__hip_atomic_store(&A.pub[seg], kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 /* lower bound of `doc` in post[lo, hi) by doc ordinal */
@@ -485,7 +521,9 @@ k_scan(const scan_args_t A)
 	/* running top-k of the scores this wavefront has seen: lane i holds the
 	 * i-th largest; thr = k-th largest (or -inf).  Everything the global
 	 * heap replay could accept is > thr (see DESIGN.md "candidate filter"). */
-	float top = -INFINITY, thr = -INFINITY;
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
 	uint32_t n_out = 0;
@@ -602,7 +640,7 @@ k_scan(const scan_args_t A)
 								const uint32_t pos = __popcll(__ballot(top >= v));
 								const float up = __shfl_up(top, 1);
 								top = (lane < pos) ? top : (lane == pos ? v : up);
-								thr = __shfl(top, kidx);
+								thr = fmaxf(__shfl(top, kidx), hint);
 							}
 						}
 					}
@@ -652,7 +690,7 @@ k_scan(const scan_args_t A)
 							const uint32_t pos = __popcll(__ballot(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
-							thr = __shfl(top, kidx);
+							thr = fmaxf(__shfl(top, kidx), hint);
 						}
 					}
 				}
@@ -661,6 +699,9 @@ k_scan(const scan_args_t A)
 		__syncthreads();
 	}
 
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
@@ -852,7 +893,9 @@ k_scan8(const scan_args_t A)
 		load_sets(tc, hi0);
 	});
 
-	float top = -INFINITY, thr = -INFINITY;
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
 	uint32_t n_out = 0;
@@ -1110,7 +1153,7 @@ k_scan8(const scan_args_t A)
 								const uint32_t pos = __popcll(__ballot(top >= v));
 								const float up = __shfl_up(top, 1);
 								top = (lane < pos) ? top : (lane == pos ? v : up);
-								thr = __shfl(top, kidx);
+								thr = fmaxf(__shfl(top, kidx), hint);
 							}
 						}
 					}
@@ -1193,7 +1236,7 @@ k_scan8(const scan_args_t A)
 							const uint32_t pos = __popcll(__ballot(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
-							thr = __shfl(top, kidx);
+							thr = fmaxf(__shfl(top, kidx), hint);
 						}
 					}
 				}
@@ -1202,6 +1245,9 @@ k_scan8(const scan_args_t A)
 		WAVE_SYNC();
 	}
 
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
@@ -1252,7 +1298,9 @@ k_scan1(const scan_args_t A)
 		return;
 	}
 
-	float top = -INFINITY, thr = -INFINITY;
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
@@ -1300,12 +1348,15 @@ k_scan1(const scan_args_t A)
 						const uint32_t pos = __popcll(__ballot(top >= v));
 						const float up = __shfl_up(top, 1);
 						top = (lane < pos) ? top : (lane == pos ? v : up);
-						thr = __shfl(top, kidx);
+						thr = fmaxf(__shfl(top, kidx), hint);
 					}
 				}
 			}
 		}
 		hi -= U * WAVE;
+	}
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
@@ -1435,7 +1486,9 @@ k_scanh(const scan_args_t A)
 		}
 	}
 
-	float top = -INFINITY, thr = -INFINITY;
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
 	uint32_t n_out = 0;
@@ -1618,7 +1671,7 @@ k_scanh(const scan_args_t A)
 							const uint32_t pos = __popcll(__ballot(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
-							thr = __shfl(top, kidx);
+							thr = fmaxf(__shfl(top, kidx), hint);
 						}
 					}
 				}
@@ -1637,6 +1690,9 @@ k_scanh(const scan_args_t A)
 		WAVE_SYNC();
 	}
 
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
@@ -2519,25 +2575,51 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 		}
 	}
 	wl.items.reserve(wl.n_segs);
-	for (uint32_t oi = 0; oi < nq; oi++) {
-		const uint32_t i = order[oi];
-		if (oi == 0 || cls[i] != cls[order[oi - 1]]) {
-			launch_t l;
-			l.first = (uint32_t)wl.items.size();
-			l.count = 0;
-			l.nt_bucket = cls[i] & 15;
-			l.nomask = (cls[i] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 pure AND */
-			l.kind = cls[i] >> 6;
-			wl.launches.push_back(l);
+	/*
+	 * Inside a class, items go out level by level: level l of every query
+	 * (its l-th highest doc range) before level l+1 of any.  All items carry
+	 * about per_wave postings, so this costs no balance, and it spreads one
+	 * query's ranges in time: when a range starts, higher ranges of its query
+	 * have usually finished and published their threshold (range_hint).
+	 */
+	for (uint32_t o0 = 0; o0 < nq; ) {
+		uint32_t o1 = o0, max_g = 0;
+		while (o1 < nq && cls[order[o1]] == cls[order[o0]]) {
+			max_g = std::max(max_g, wl.qmeta[order[o1]].n_groups);
+			o1++;
 		}
-		/* descending ranges first: they are replayed first */
-		for (uint32_t g = wl.qmeta[i].n_groups; g-- > 0; ) {
-			item_t it;
-			it.q = i;
-			it.g = g;
-			wl.items.push_back(it);
+		launch_t l;
+		l.first = (uint32_t)wl.items.size();
+		l.nt_bucket = cls[order[o0]] & 15;
+		l.nomask = (cls[order[o0]] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 two-token AND */
+		l.kind = cls[order[o0]] >> 6;
+		const bool by_level = !getenv("NXS_GPU_NOLEVELS");
+		if (by_level) {
+			for (uint32_t lev = 0; lev < max_g; lev++) {
+				for (uint32_t oi = o0; oi < o1; oi++) {
+					const uint32_t i = order[oi];
+					if (lev < wl.qmeta[i].n_groups) {
+						item_t it;
+						it.q = i;
+						it.g = wl.qmeta[i].n_groups - 1 - lev;
+						wl.items.push_back(it);
+					}
+				}
+			}
+		} else {
+			for (uint32_t oi = o0; oi < o1; oi++) {
+				const uint32_t i = order[oi];
+				for (uint32_t g = wl.qmeta[i].n_groups; g-- > 0; ) {
+					item_t it;
+					it.q = i;
+					it.g = g;
+					wl.items.push_back(it);
+				}
+			}
 		}
-		wl.launches.back().count = (uint32_t)wl.items.size() - wl.launches.back().first;
+		l.count = (uint32_t)wl.items.size() - l.first;
+		wl.launches.push_back(l);
+		o0 = o1;
 	}
 }
 
@@ -2682,7 +2764,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	{
 		size_t need = 8192 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
-		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + 1024
+		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
 		if (!ensure_ws(ix, need)) {
 			return -1;
@@ -2696,6 +2778,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	d_ovf = carve<uint32_t>(p, nq);
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
+	float *d_pub = carve<float>(p, nseg);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
 	d_ids = dev_out ? d_out_ids : carve<uint64_t>(p, (size_t)nq * kfast);
@@ -2706,7 +2789,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_items, wl.items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess) {
+	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess ||
+	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
 	}
@@ -2725,6 +2809,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.cand_sc = d_cand_sc;
 	sa.overflow = d_ovf;
 	sa.cursors = d_cursors;
+	sa.pub = d_pub;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): the default bench line, a rocprofv3 kernel-trace/stats run of the
+# same command, and separate --pmc passes (never combined with other trace domains).
+# Usage: tools/profile_round.sh <tag>      outputs under gpurun_out/<tag>_*
+set -u
+tag=${1:-r1}
+out=$PWD/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+python3 bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+B="python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-extras"
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -o run -- $B > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.log"
+rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_fetch" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_fetch.log"
+rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_pmc_write" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_write.log"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d "$out/${tag}_pmc_sq1" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_sq1.log"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$out/${tag}_pmc_sq2" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_sq2.log"
+tail -c 1500 "$out/${tag}_bench.json"

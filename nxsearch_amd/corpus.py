@@ -62,13 +62,13 @@ def queries_single(terms, n, seed=3, lo=10, hi=10000):
     return [terms[rng.randint(lo, hi) - 1].decode() for _ in range(n)]
 
 
-def queries_bool5(terms, n, seed=3, hi=1000, k=5):
-    """C3: 5 distinct terms of rank uniform in [1, hi]; half AND, half OR."""
+def queries_bool5(terms, n, seed=3, hi=1000, k=5, lo=1):
+    """C3: 5 distinct terms of rank uniform in [lo, hi]; half AND, half OR."""
     rng = random.Random(seed)
     hi = min(hi, len(terms))
     out = []
     for i in range(n):
-        ranks = rng.sample(range(1, hi + 1), min(k, hi))
+        ranks = rng.sample(range(lo, hi + 1), min(k, hi - lo + 1))
         op = " AND " if i % 2 == 0 else " OR "
         out.append(op.join(terms[r - 1].decode() for r in ranks))
     return out

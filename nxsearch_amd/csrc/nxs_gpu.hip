@@ -386,6 +386,30 @@ static_for_impl(F &&f)
 		static_for_impl<I + 1, N>(f);
 	}
 }
+/*
+ * Wave-level predicates without the int round trip of HIP's ballot64(): a lane
+ * condition becomes a 64-bit scalar mask (the v_cmp result itself), a scalar
+ * mask becomes a lane condition again (it is used as the select mask), and a
+ * lane's rank inside a mask is the two v_mbcnt instructions.
+ */
+static __device__ __forceinline__ uint64_t
+ballot64(bool p)
+{
+	return __builtin_amdgcn_ballot_w64(p);
+}
+
+static __device__ __forceinline__ bool
+lane_of(uint64_t wave_uniform_mask)
+{
+	return __builtin_amdgcn_inverse_ballot_w64(wave_uniform_mask);
+}
+
+static __device__ __forceinline__ uint32_t
+lanes_below(uint64_t m)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
 template <int N, typename F>
 __device__ __forceinline__ void
 static_for(F &&f)
@@ -413,7 +437,7 @@ wave_lower_bound(const posting_t *__restrict__ pt, int32_t lo, int32_t hi, uint3
 			v = pt[idx].doc;
 		}
 		/* lanes are monotone: the first lane whose probe is >= bound */
-		const uint64_t m = __ballot(!valid || v >= bound);
+		const uint64_t m = ballot64(!valid || v >= bound);
 		const int32_t L = m ? (int32_t)__ffsll((long long)m) - 1 : WAVE;
 		if (L == 0) {
 			return lo;
@@ -430,7 +454,7 @@ wave_lower_bound(const posting_t *__restrict__ pt, int32_t lo, int32_t hi, uint3
 		if (valid) {
 			v = pt[idx].doc;
 		}
-		const uint64_t m = __ballot(valid && v >= bound);
+		const uint64_t m = ballot64(valid && v >= bound);
 		return m ? lo + (int32_t)__ffsll((long long)m) - 1 : hi;
 	}
 }
@@ -558,7 +582,7 @@ k_scan(const scan_args_t A)
 					p = post[i];
 				}
 				const bool in = valid && p.doc >= base;
-				const uint64_t bal = __ballot(in);
+				const uint64_t bal = ballot64(in);
 				const uint32_t c = __popcll(bal);
 				if (in) {
 					const uint32_t d = p.doc - base;
@@ -591,7 +615,7 @@ k_scan(const scan_args_t A)
 			uint32_t *mask32 = (uint32_t *)s_mask;
 			for (int s = TILE_W / 256 - 1; s >= 0; s--) {
 				const uint32_t mw = mask32[s * WAVE + lane];
-				if (__ballot(mw != 0) == 0) {
+				if (ballot64(mw != 0) == 0) {
 					continue;
 				}
 				if (mw) {
@@ -599,7 +623,7 @@ k_scan(const scan_args_t A)
 				}
 				for (int j = 3; j >= 0; j--) {
 					const uint32_t m = (mw >> (8 * j)) & 0xff;
-					if (__ballot(m != 0) == 0) {
+					if (ballot64(m != 0) == 0) {
 						continue;
 					}
 					const uint32_t d = s * 256 + j * 64 + lane;
@@ -610,11 +634,11 @@ k_scan(const scan_args_t A)
 					}
 					const bool match = m && ((s_truth[m >> 5] >> (m & 31)) & 1);
 					if (MODE == MODE_COUNT) {
-						n_out += __popcll(__ballot(match));
+						n_out += __popcll(ballot64(match));
 						continue;
 					}
 					const bool cand = match && (sc > thr);
-					uint64_t bal = __ballot(cand);
+					uint64_t bal = ballot64(cand);
 					if (!bal) {
 						continue;
 					}
@@ -637,7 +661,7 @@ k_scan(const scan_args_t A)
 							bal &= ~(1ull << L);
 							const float v = __shfl(sc, L);
 							if (v > thr) {
-								const uint32_t pos = __popcll(__ballot(top >= v));
+								const uint32_t pos = __popcll(ballot64(top >= v));
 								const float up = __shfl_up(top, 1);
 								top = (lane < pos) ? top : (lane == pos ? v : up);
 								thr = fmaxf(__shfl(top, kidx), hint);
@@ -650,7 +674,7 @@ k_scan(const scan_args_t A)
 			for (int s = TILE_W / WAVE - 1; s >= 0; s--) {
 				const uint32_t d = s * WAVE + lane;
 				const uint32_t m = s_mask[d];
-				if (__ballot(m != 0) == 0) {
+				if (ballot64(m != 0) == 0) {
 					continue;
 				}
 				float sc = 0.0f;
@@ -661,11 +685,11 @@ k_scan(const scan_args_t A)
 				}
 				const bool match = m && eval_prog(s_prog, Q->prog_len, m);
 				if (MODE == MODE_COUNT) {
-					n_out += __popcll(__ballot(match));
+					n_out += __popcll(ballot64(match));
 					continue;
 				}
 				const bool cand = match && (sc > thr);
-				uint64_t bal = __ballot(cand);
+				uint64_t bal = ballot64(cand);
 				if (!bal) {
 					continue;
 				}
@@ -687,7 +711,7 @@ k_scan(const scan_args_t A)
 						bal &= ~(1ull << L);
 						const float v = __shfl(sc, L);
 						if (v > thr) {
-							const uint32_t pos = __popcll(__ballot(top >= v));
+							const uint32_t pos = __popcll(ballot64(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
 							thr = fmaxf(__shfl(top, kidx), hint);
@@ -779,7 +803,6 @@ k_scan8(const scan_args_t A)
 	constexpr int SW = WAVE * K;
 
 	const unsigned lane = threadIdx.x;
-	const uint64_t lane_lt = (1ull << lane) - 1;
 	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
@@ -926,7 +949,7 @@ k_scan8(const scan_args_t A)
 					uint64_t left = 0;
 #pragma unroll
 					for (int k = 0; k < K; k++) {
-						vm[t][k] &= ~__ballot(Ad[t][k] >= bound);
+						vm[t][k] &= ~ballot64(Ad[t][k] >= bound);
 						left |= vm[t][k];
 					}
 					if (left) {
@@ -954,7 +977,10 @@ k_scan8(const scan_args_t A)
 		}
 
 		uint32_t n_list = 0;
-		float tmax = -INFINITY;		/* largest accumulator value written in this tile */
+		/* largest accumulator value written in this tile, as its bit pattern:
+		 * the values are sums of positive impacts (>= +0), for which unsigned
+		 * order is float order and the max is one v_max_u32 */
+		uint32_t tmax = 0;
 
 		/* accumulate, tokens strictly in token-list order (results.c:134-136) */
 		static_for<NT>([&](auto tc) {
@@ -980,11 +1006,11 @@ k_scan8(const scan_args_t A)
 						inm[k] = 0;
 						if (more && vm[t][k]) {
 							const bool ge = Ad[t][k] >= base;
-							inm[k] = vm[t][k] & __ballot(ge);
+							inm[k] = vm[t][k] & ballot64(ge);
 							vm[t][k] &= ~inm[k];
 							more = vm[t][k] == 0;	/* else: the tile ends in this window */
 							if (inm[k]) {
-								inl[k] = (inm[k] >> lane) & 1;
+								inl[k] = lane_of(inm[k]);
 								dd[k] = inl[k] ? Ad[t][k] - base : TILE_W + lane;
 								a0[k] = s_acc[dd[k]];
 								m0[k] = HASMASK ? s_mask8[dd[k]] : 0;
@@ -996,7 +1022,7 @@ k_scan8(const scan_args_t A)
 					for (int k = K - 1; k >= 0; k--) {
 						if (inm[k]) {
 							float v;
-							bool first;
+							uint64_t fb;	/* lanes touching their doc first in this tile */
 							if (ANDM) {
 								/* alive: carries the previous token's parity */
 								const bool alive = inl[k] && (t == 0 ||
@@ -1004,9 +1030,9 @@ k_scan8(const scan_args_t A)
 								v = fabsf(a0[k]) + Ai[t][k];
 								s_acc[dd[k]] = alive ? ((t & 1) ? -v : v) : a0[k];
 								if (alive && t == (int)nt - 1) {
-									tmax = fmaxf(tmax, v);
+									tmax = max(tmax, __float_as_uint(v));
 								}
-								first = inl[k] && t == 0;
+								fb = t == 0 ? inm[k] : 0;
 							} else {
 								v = a0[k] + (inl[k] ? Ai[t][k] : 0.0f);
 								s_acc[dd[k]] = v;
@@ -1016,18 +1042,18 @@ k_scan8(const scan_args_t A)
 									/* only docs that already hold every required
 									 * term can become candidates */
 									if ((bits & req) == req) {
-										tmax = fmaxf(tmax, v);
+										tmax = max(tmax, __float_as_uint(v));
 									}
 								} else {
-									tmax = fmaxf(tmax, v);
+									tmax = max(tmax, __float_as_uint(v));
 								}
-								first = inl[k] && (HASMASK ? m0[k] == 0 : a0[k] == 0.0f);
+								/* (masks of direct compares: no bool round trip) */
+								fb = inm[k] & (HASMASK ? ballot64(m0[k] == 0) : ballot64(a0[k] == 0.0f));
 							}
 							if (n_list <= LIST_CAP) {
-								const uint64_t fb = __ballot(first);
 								const uint32_t nf = __popcll(fb);
-								if (n_list + nf <= LIST_CAP && first) {
-									s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)dd[k];
+								if (n_list + nf <= LIST_CAP && lane_of(fb)) {
+									s_list[n_list + lanes_below(fb)] = (uint16_t)dd[k];
 								}
 								n_list += nf;
 							}
@@ -1052,7 +1078,7 @@ k_scan8(const scan_args_t A)
 		 * If none of them beats the threshold no doc of the tile can be a
 		 * candidate: just wipe the accumulators.
 		 */
-		if (MODE == MODE_TOPK && __ballot(tmax > thr) == 0) {
+		if (MODE == MODE_TOPK && ballot64(__uint_as_float(tmax) > thr) == 0) {
 			if (full_scan) {
 				for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 					s_acc[i] = 0.0f;
@@ -1100,15 +1126,15 @@ k_scan8(const scan_args_t A)
 				}
 				if (MODE == MODE_COUNT) {
 					const bool match = valid && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
-					n_out += __popcll(__ballot(match));
+					n_out += __popcll(ballot64(match));
 					continue;
 				}
 				const bool pre = valid && (sc > thr);
-				if (__ballot(pre) == 0) {
+				if (ballot64(pre) == 0) {
 					continue;
 				}
 				const bool cand = pre && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
-				const uint64_t bal = __ballot(cand);
+				const uint64_t bal = ballot64(cand);
 				if (!bal) {
 					continue;
 				}
@@ -1118,7 +1144,7 @@ k_scan8(const scan_args_t A)
 					break;
 				}
 				if (cand) {
-					const uint32_t slot = ncand + __popcll(bal & lane_lt);
+					const uint32_t slot = ncand + lanes_below(bal);
 					s_cd[slot] = d;
 					s_cs[slot] = sc;
 				}
@@ -1150,7 +1176,7 @@ k_scan8(const scan_args_t A)
 						for (uint32_t j = 0; j < ncand; j++) {
 							const float v = __shfl(cs, (int)j);
 							if (v > thr) {
-								const uint32_t pos = __popcll(__ballot(top >= v));
+								const uint32_t pos = __popcll(ballot64(top >= v));
 								const float up = __shfl_up(top, 1);
 								top = (lane < pos) ? top : (lane == pos ? v : up);
 								thr = fmaxf(__shfl(top, kidx), hint);
@@ -1179,7 +1205,7 @@ k_scan8(const scan_args_t A)
 				uint32_t m;
 				if (HASMASK) {
 					m = s_mask8[d];
-					if (__ballot(m != 0) == 0) {
+					if (ballot64(m != 0) == 0) {
 						continue;
 					}
 					if (m) {
@@ -1190,7 +1216,7 @@ k_scan8(const scan_args_t A)
 				} else {
 					sc = s_acc[d];
 					m = sc != 0.0f;
-					if (__ballot(m != 0) == 0) {
+					if (ballot64(m != 0) == 0) {
 						continue;
 					}
 					if (m) {
@@ -1203,15 +1229,15 @@ k_scan8(const scan_args_t A)
 				}
 				if (MODE == MODE_COUNT) {
 					const bool match = m && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
-					n_out += __popcll(__ballot(match));
+					n_out += __popcll(ballot64(match));
 					continue;
 				}
 				const bool pre = m && (sc > thr);
-				if (__ballot(pre) == 0) {
+				if (ballot64(pre) == 0) {
 					continue;
 				}
 				const bool cand = pre && (HASMASK ? ((s_truth[m >> 5] >> (m & 31)) & 1) : (m != 0));
-				uint64_t bal = __ballot(cand);
+				uint64_t bal = ballot64(cand);
 				if (!bal) {
 					continue;
 				}
@@ -1233,7 +1259,7 @@ k_scan8(const scan_args_t A)
 						bal &= ~(1ull << L);
 						const float v = __shfl(sc, L);
 						if (v > thr) {
-							const uint32_t pos = __popcll(__ballot(top >= v));
+							const uint32_t pos = __popcll(ballot64(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
 							thr = fmaxf(__shfl(top, kidx), hint);
@@ -1323,7 +1349,7 @@ k_scan1(const scan_args_t A)
 		for (int u = 0; u < U; u++) {
 			/* window u: descending doc = descending lane */
 			const bool cand = iv[u] > thr;
-			uint64_t bal = __ballot(cand);
+			uint64_t bal = ballot64(cand);
 			if (!bal) {
 				continue;
 			}
@@ -1345,7 +1371,7 @@ k_scan1(const scan_args_t A)
 					bal &= ~(1ull << L);
 					const float v = __shfl(iv[u], L);
 					if (v > thr) {
-						const uint32_t pos = __popcll(__ballot(top >= v));
+						const uint32_t pos = __popcll(ballot64(top >= v));
 						const float up = __shfl_up(top, 1);
 						top = (lane < pos) ? top : (lane == pos ? v : up);
 						thr = fmaxf(__shfl(top, kidx), hint);
@@ -1406,7 +1432,6 @@ k_scanh(const scan_args_t A)
 	__shared__ int64_t s_init[16];
 
 	const unsigned lane = threadIdx.x;
-	const uint64_t lane_lt = (1ull << lane) - 1;
 	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
@@ -1521,7 +1546,7 @@ k_scanh(const scan_args_t A)
 						const int32_t idx = ab + k * WAVE + (int32_t)lane;
 						const uint32_t doc = Ad[t][k];
 						const bool in = idx >= lo[t] && idx < hi[t] && doc >= base;
-						const uint32_t c = __popcll(__ballot(in));
+						const uint32_t c = __popcll(ballot64(in));
 						const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
 						const int32_t bot_ = max(lo[t], ab + k * WAVE);
 						ctot += c;
@@ -1535,7 +1560,7 @@ k_scanh(const scan_args_t A)
 							volatile uint32_t *vkey = s_key;
 							uint32_t slot = doc & (TAB - 1);
 							bool pending = in, isnew = false;
-							while (__ballot(pending)) {
+							while (ballot64(pending)) {
 								uint32_t kk = 0;
 								if (pending) {
 									kk = vkey[slot];
@@ -1564,9 +1589,9 @@ k_scanh(const scan_args_t A)
 								s_msk[slot] = (uint8_t)(s_msk[slot] | (1u << t));
 								tmax = fmaxf(tmax, v);
 							}
-							const uint64_t fb = __ballot(isnew);
+							const uint64_t fb = ballot64(isnew);
 							if (isnew) {
-								s_list[n_list + __popcll(fb & lane_lt)] = (uint16_t)slot;
+								s_list[n_list + lanes_below(fb)] = (uint16_t)slot;
 							}
 							n_list += __popcll(fb);
 						}
@@ -1612,7 +1637,7 @@ k_scanh(const scan_args_t A)
 
 		/* candidates of this step (skipped when nothing beat the threshold:
 		 * scores only grow within a step, see k_scan8) */
-		if (MODE == MODE_COUNT || __ballot(tmax > thr) != 0) {
+		if (MODE == MODE_COUNT || ballot64(tmax > thr) != 0) {
 			uint32_t ncand = 0;
 			for (uint32_t off = 0; off < n_list; off += WAVE) {
 				const uint32_t i = off + lane;
@@ -1627,17 +1652,17 @@ k_scanh(const scan_args_t A)
 				}
 				if (MODE == MODE_COUNT) {
 					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
-					n_out += __popcll(__ballot(match));
+					n_out += __popcll(ballot64(match));
 					continue;
 				}
 				const bool pre = valid && (sc > thr);
-				if (__ballot(pre) == 0) {
+				if (ballot64(pre) == 0) {
 					continue;
 				}
 				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
-				const uint64_t bal = __ballot(cand);
+				const uint64_t bal = ballot64(cand);
 				if (cand) {
-					const uint32_t j = ncand + __popcll(bal & lane_lt);
+					const uint32_t j = ncand + lanes_below(bal);
 					s_cd[j] = d;
 					s_cs[j] = sc;
 				}
@@ -1668,7 +1693,7 @@ k_scanh(const scan_args_t A)
 					for (uint32_t j = 0; j < ncand; j++) {
 						const float v = s_cs[j];
 						if (v > thr) {
-							const uint32_t pos = __popcll(__ballot(top >= v));
+							const uint32_t pos = __popcll(ballot64(top >= v));
 							const float up = __shfl_up(top, 1);
 							top = (lane < pos) ? top : (lane == pos ? v : up);
 							thr = fmaxf(__shfl(top, kidx), hint);
@@ -1895,7 +1920,7 @@ k_replay(const replay_args_t A)
 				 * without touching the heap */
 				uint32_t nn = s_n;
 				float mn = s_min;
-				uint64_t pend = __ballot(valid && (nn < cap || sc > mn));
+				uint64_t pend = ballot64(valid && (nn < cap || sc > mn));
 				while (pend) {
 					const int L = __ffsll((long long)pend) - 1;
 					const float v = __shfl(sc, L);
@@ -1910,7 +1935,7 @@ k_replay(const replay_args_t A)
 					nn = s_n;
 					mn = s_min;
 					pend &= pend - 1;
-					pend &= __ballot(valid && (nn < cap || sc > mn));
+					pend &= ballot64(valid && (nn < cap || sc > mn));
 				}
 			}
 		}

@@ -326,6 +326,31 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
     gidx.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}])
+def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
+    """400k docs: queries whose terms are all sparse (few postings per tile, most
+    tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = corpus.write_corpus(str(tmp_path), 400_000, 20_000, seed=31)
+    terms = corpus.term_strings(20_000, seed=31)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    qs = corpus.queries_bool5(terms, 24, seed=7, lo=200, hi=4000)
+    qs += corpus.queries_bool5(terms, 12, seed=8, lo=2000, hi=20_000, k=3)
+    qs += corpus.queries_bool5(terms, 12, seed=9, lo=30, hi=3000, k=7)
+    T = lambda r: terms[r - 1].decode()
+    qs += ["(%s OR %s) AND NOT %s" % (T(300), T(500), T(40)), "%s OR %s OR (%s AND %s)" % (T(900), T(901), T(50), T(60)),
+           "(%s AND %s) OR (%s AND %s)" % (T(100), T(120), T(140), T(160))]
+    for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+        got = gidx.search_batch(qs, limit=10, algo=name, fuzzymatch=False)
+        for q, g in zip(qs, got):
+            assert_same(g, oidx.search(q, algo=algo, limit=10, fuzzymatch=False), (env, q))
+    got = gidx.search_batch(qs[:12], limit=64, fuzzymatch=False)
+    for q, g in zip(qs[:12], got):
+        assert_same(g, oidx.search(q, limit=64, fuzzymatch=False), (env, q, 64))
+    gidx.close()
+
+
 def test_sharded_search_single_rank(nxs, tmp_path):
     import torch
     from nxsearch_amd import multi

@@ -808,7 +808,9 @@ k_scan8(const scan_args_t A)
 	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];
 	const uint32_t nt = Q->nt;
-	const uint32_t req = (MODE == MODE_TOPK || MODE == MODE_COUNT || MODE == MODE_ALL) ? Q->req : 0;
+	/* terms every matching doc must contain; a pure-OR query (MM = 1) has none,
+	 * which removes the whole skip logic from that instantiation */
+	const uint32_t req = (MM == 1) ? 0 : Q->req;
 	const uint64_t seg = (uint64_t)qm.seg_first + g;
 	uint32_t *s_mask32 = (uint32_t *)s_mask8;
 

@@ -793,7 +793,7 @@ k_scan8(const scan_args_t A)
 	/* HASMASK = false: pure-OR queries (every non-empty presence mask matches):
 	 * a doc matches iff it was touched, i.e. iff its score is > 0; no mask array */
 	__shared__ uint8_t s_mask8[HASMASK ? TILE_W + WAVE : 4];
-	__shared__ uint16_t s_list[LIST_CAP];
+	__shared__ uint16_t s_list[LIST_CAP + WAVE];	/* + slack: appends are clamped, not branched */
 	__shared__ uint32_t s_cd[TCAND_CAP];
 	__shared__ float s_cs[TCAND_CAP];
 	__shared__ uint32_t s_truth[8];
@@ -987,7 +987,57 @@ k_scan8(const scan_args_t A)
 		/* accumulate, tokens strictly in token-list order (results.c:134-136) */
 		static_for<NT>([&](auto tc) {
 			constexpr int t = decltype(tc)::value;
-			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
+			if constexpr (K == 1 && !ANDM) {
+				/*
+				 * One window per set (3+ tokens): straight-line read-add-write.
+				 * pdoc[t] >= base implies t < nt (unused terms keep pdoc = -1)
+				 * and that the top unconsumed posting is in this tile.
+				 */
+				if (pdoc[t] >= (int32_t)base) {
+					uint64_t left = vm[t][0];
+					for (;;) {
+						const uint64_t inm = left & ballot64(Ad[t][0] >= base);
+						left ^= inm;
+						if (inm) {
+							const bool inl = lane_of(inm);
+							/* lanes without an in-tile posting add 0 to a private
+							 * dummy slot: no exec-mask juggling */
+							const uint32_t dd = inl ? Ad[t][0] - base : TILE_W + lane;
+							const float a0 = s_acc[dd];
+							const uint32_t m0 = HASMASK ? s_mask8[dd] : 0;
+							const float v = a0 + (inl ? Ai[t][0] : 0.0f);
+							uint64_t fb;	/* lanes touching their doc first in this tile */
+							s_acc[dd] = v;
+							if (HASMASK) {
+								const uint32_t bits = m0 | (inl ? (1u << t) : 0u);
+								s_mask8[dd] = (uint8_t)bits;
+								/* only docs that already hold every required
+								 * term can become candidates */
+								if ((bits & req) == req) {
+									tmax = max(tmax, __float_as_uint(v));
+								}
+								fb = inm & ballot64(m0 == 0);
+							} else {
+								tmax = max(tmax, __float_as_uint(v));
+								fb = inm & ballot64(a0 == 0.0f);
+							}
+							if (lane_of(fb)) {
+								s_list[min(n_list, (uint32_t)LIST_CAP) + lanes_below(fb)] = (uint16_t)dd;
+							}
+							n_list += __popcll(fb);
+						}
+						if (left == 0 && ab[t] > lo[t]) {
+							/* the whole window was in the tile and postings remain */
+							rotate_sets(tc);
+							left = vm[t][0];
+							continue;
+						}
+						break;
+					}
+					vm[t][0] = left;
+					refresh_pdoc(tc);
+				}
+			} else if (t < (int)nt && pdoc[t] >= (int32_t)base) {
 				for (;;) {
 					uint64_t inm[K];
 					float a0[K];

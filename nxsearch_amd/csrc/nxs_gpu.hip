@@ -837,6 +837,17 @@ k_scan8(const scan_args_t A)
 	uint64_t vm[NT][K];
 	uint32_t Ad[NT][K], Bd[NT][K];
 	float Ai[NT][K], Bi[NT][K];
+	/*
+	 * AP (one window per set): set B is filled by loads the compiler does not
+	 * track.  A compiler-visible load into B is waited for on the spot --
+	 * taking B over into A at a rotation is a register copy of the value just
+	 * requested -- so the wavefront stalled for a full memory latency every 64
+	 * postings of every term (measured: ~60% of the kernel).  Here the
+	 * prefetch stays in flight until the NEXT rotation of the term, and the
+	 * whole rotation is one asm block so nothing can be scheduled into it:
+	 * wait (vmcnt(0): loads return in order), copy B to A, request the next B.
+	 */
+	constexpr bool AP = K == 1 && !ANDM;
 
 	/* lanes of the window starting at list index wb that lie in [lo_, hi_) */
 	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
@@ -875,8 +886,8 @@ k_scan8(const scan_args_t A)
 				const int32_t ia = max(ab[t] + k * WAVE + (int32_t)lane, lo[t]);
 				const int32_t ib = max(ab[t] - SW + k * WAVE + (int32_t)lane, lo[t]);
 				const posting_t pa = pt[t][min(ia, hi_ - 1)];
-				const posting_t pb = pt[t][min(ib, hi_ - 1)];
 				Ad[t][k] = pa.doc; Ai[t][k] = pa.imp;
+				const posting_t pb = pt[t][min(ib, hi_ - 1)];
 				Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
 				vm[t][k] = window_mask(ab[t] + k * WAVE, lo[t], hi_);
 			}
@@ -886,6 +897,21 @@ k_scan8(const scan_args_t A)
 	/* set A is drained: take over set B, put K new loads in flight */
 	auto rotate_sets = [&](auto tc) {
 		constexpr int t = decltype(tc)::value;
+		if constexpr (AP) {
+			ab[t] -= WAVE;
+			vm[t][0] = window_mask(ab[t], lo[t], 0x7fffffff);
+			const posting_t *np = &pt[t][max(ab[t] - WAVE + (int32_t)lane, lo[t])];
+			asm volatile(
+			    "s_waitcnt vmcnt(0)\n\t"
+			    "v_mov_b32 %0, %2\n\t"
+			    "v_mov_b32 %1, %3\n\t"
+			    "global_load_dword %2, %4, off\n\t"
+			    "global_load_dword %3, %4, off offset:4"
+			    : "=&v"(Ad[t][0]), "=&v"(Ai[t][0]), "+v"(Bd[t][0]), "+v"(Bi[t][0])
+			    : "v"(np)
+			    : "memory");
+			return;
+		}
 		ab[t] -= SW;
 #pragma unroll
 		for (int k = 0; k < K; k++) {

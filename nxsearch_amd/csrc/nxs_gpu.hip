@@ -102,7 +102,8 @@ struct dev_query_t {
 	uint64_t	pend[NXSGPU_MAX_TOKENS];
 	uint32_t	truth[8];
 	uint32_t	req;		/* tokens present in every matching mask */
-	uint32_t	pad0;
+	uint32_t	n_req;		/* k_scanr: slots [0, n_req) are the required tokens ... */
+	uint8_t		slot_tok[8];	/* ... slot -> token, ascending list length within each group */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
@@ -387,7 +388,7 @@ static_for_impl(F &&f)
 	}
 }
 /*
- * Wave-level predicates without the int round trip of HIP's ballot64(): a lane
+ * Wave-level predicates without the int round trip of HIP's __ballot(): a lane
  * condition becomes a 64-bit scalar mask (the v_cmp result itself), a scalar
  * mask becomes a lane condition again (it is used as the select mask), and a
  * lane's rank inside a mask is the two v_mbcnt instructions.
@@ -416,6 +417,52 @@ static_for(F &&f)
 {
 	static_for_impl<0, N>(f);
 }
+
+/*
+ * The prefetched posting window of term slot T ("set B" of the one-window scan
+ * paths) lives in two accumulation registers that only these asm blocks name.
+ *
+ * Why not ordinary variables: a load the compiler tracks is waited for as
+ * soon as its value is copied, and taking B over into A at a rotation is such
+ * a copy -- the wavefront stalled for a memory latency every 64 postings.  A
+ * load it does not track (inline asm into a C variable) is not safe either:
+ * the register allocator is free to move that variable with v_mov while the
+ * data is still in flight.  The kernels use no AGPRs otherwise, so a0..a15
+ * are out of the compiler's reach: nothing can be scheduled into, copied out
+ * of, or reallocated over a pending prefetch.  bset_take() = wait (loads
+ * return in order), read B into A, request the next window into B.
+ */
+template <int T> __device__ __forceinline__ void bset_request(const posting_t *np);
+template <int T> __device__ __forceinline__ void bset_take(uint32_t &ad, float &ai, const posting_t *np);
+#define	NXS_BSET(T, RD, RI)								\
+template <> __device__ __forceinline__ void						\
+bset_request<T>(const posting_t *np)							\
+{											\
+	asm volatile(									\
+	    "global_load_dword " RD ", %0, off\n\t"					\
+	    "global_load_dword " RI ", %0, off offset:4"				\
+	    : : "v"(np) : "memory", RD, RI);						\
+}											\
+template <> __device__ __forceinline__ void						\
+bset_take<T>(uint32_t &ad, float &ai, const posting_t *np)				\
+{											\
+	asm volatile(									\
+	    "s_waitcnt vmcnt(0)\n\t"							\
+	    "v_accvgpr_read_b32 %0, " RD "\n\t"					\
+	    "v_accvgpr_read_b32 %1, " RI "\n\t"					\
+	    "global_load_dword " RD ", %2, off\n\t"					\
+	    "global_load_dword " RI ", %2, off offset:4"				\
+	    : "=&v"(ad), "=&v"(ai) : "v"(np) : "memory", RD, RI);			\
+}
+NXS_BSET(0, "a0", "a1")
+NXS_BSET(1, "a2", "a3")
+NXS_BSET(2, "a4", "a5")
+NXS_BSET(3, "a6", "a7")
+NXS_BSET(4, "a8", "a9")
+NXS_BSET(5, "a10", "a11")
+NXS_BSET(6, "a12", "a13")
+NXS_BSET(7, "a14", "a15")
+#undef NXS_BSET
 
 /*
  * Wave-cooperative lower bound: first index in [lo, hi) (relative to pt) whose
@@ -837,16 +884,8 @@ k_scan8(const scan_args_t A)
 	uint64_t vm[NT][K];
 	uint32_t Ad[NT][K], Bd[NT][K];
 	float Ai[NT][K], Bi[NT][K];
-	/*
-	 * AP (one window per set): set B is filled by loads the compiler does not
-	 * track.  A compiler-visible load into B is waited for on the spot --
-	 * taking B over into A at a rotation is a register copy of the value just
-	 * requested -- so the wavefront stalled for a full memory latency every 64
-	 * postings of every term (measured: ~60% of the kernel).  Here the
-	 * prefetch stays in flight until the NEXT rotation of the term, and the
-	 * whole rotation is one asm block so nothing can be scheduled into it:
-	 * wait (vmcnt(0): loads return in order), copy B to A, request the next B.
-	 */
+	/* AP (one window per set): set B is the hidden prefetch register pair of
+	 * bset_request()/bset_take(); Bd/Bi are unused then */
 	constexpr bool AP = K == 1 && !ANDM;
 
 	/* lanes of the window starting at list index wb that lie in [lo_, hi_) */
@@ -887,8 +926,12 @@ k_scan8(const scan_args_t A)
 				const int32_t ib = max(ab[t] - SW + k * WAVE + (int32_t)lane, lo[t]);
 				const posting_t pa = pt[t][min(ia, hi_ - 1)];
 				Ad[t][k] = pa.doc; Ai[t][k] = pa.imp;
-				const posting_t pb = pt[t][min(ib, hi_ - 1)];
-				Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
+				if constexpr (AP) {
+					bset_request<t>(&pt[t][min(ib, hi_ - 1)]);
+				} else {
+					const posting_t pb = pt[t][min(ib, hi_ - 1)];
+					Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
+				}
 				vm[t][k] = window_mask(ab[t] + k * WAVE, lo[t], hi_);
 			}
 			refresh_pdoc(tc);
@@ -901,15 +944,7 @@ k_scan8(const scan_args_t A)
 			ab[t] -= WAVE;
 			vm[t][0] = window_mask(ab[t], lo[t], 0x7fffffff);
 			const posting_t *np = &pt[t][max(ab[t] - WAVE + (int32_t)lane, lo[t])];
-			asm volatile(
-			    "s_waitcnt vmcnt(0)\n\t"
-			    "v_mov_b32 %0, %2\n\t"
-			    "v_mov_b32 %1, %3\n\t"
-			    "global_load_dword %2, %4, off\n\t"
-			    "global_load_dword %3, %4, off offset:4"
-			    : "=&v"(Ad[t][0]), "=&v"(Ai[t][0]), "+v"(Bd[t][0]), "+v"(Bi[t][0])
-			    : "v"(np)
-			    : "memory");
+			bset_take<t>(Ad[t][0], Ai[t][0], np);
 			return;
 		}
 		ab[t] -= SW;
@@ -1348,7 +1383,6 @@ k_scan8(const scan_args_t A)
 		}
 		WAVE_SYNC();
 	}
-
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
@@ -1461,6 +1495,298 @@ k_scan1(const scan_args_t A)
 	}
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/*
+ * k_scanr: queries with required terms (`req` != 0: a doc can only match if
+ * it holds every one of them), 2..8 tokens -- the conjunctive shapes.  The
+ * reference intersects the terms' doc bitmaps before it scores anything
+ * (search.c:118-174); this is the same idea on posting windows:
+ *
+ *  - slot 0 is the DRIVER: the required term with the fewest postings.  The
+ *    other slots follow in ascending list length, required ones first
+ *    (dev_query_t::slot_tok, host side);
+ *  - a round takes the driver's unconsumed postings that fall into one
+ *    RW-doc aligned span (at most one 64-posting window), marks their docs
+ *    in an LDS byte map (value = driver lane + 1) and then lets the other
+ *    slots look their own postings of that span up in the map.  A hit hands
+ *    the posting's impact and presence bit to the driver lane's slot
+ *    (s_imp / s_bits); there is no accumulator tile at all;
+ *  - after each required slot the driver lanes that did not get its bit are
+ *    unmarked.  When no lane is left the round is over: denser slots are not
+ *    looked at, and what they hold above the driver's next posting is dropped
+ *    unread at the start of the next round (mask, stream, or jump by a window
+ *    probe / 64-ary search) -- their postings are mostly never loaded;
+ *  - surviving lanes sum their slots' impacts in token order (the f32 order of
+ *    results.c:134-136), test the truth table and go through the same
+ *    threshold filter / candidate emission as the other scan kernels; lanes
+ *    are in ascending doc order, so emission is by descending lane.
+ */
+#define	RW	4096		/* docs per round span (LDS byte map) */
+
+template <int MODE, int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scanr(const scan_args_t A)
+{
+	__shared__ uint8_t s_mark[RW + WAVE];		/* + one always-zero dummy slot per lane */
+	__shared__ uint8_t s_bits[WAVE];		/* presence mask of the driver lane's doc */
+	__shared__ float s_imp[NT][WAVE];		/* [token][driver lane] */
+	__shared__ uint32_t s_truth[8];
+
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint32_t n_req = Q->n_req;		/* slots [0, n_req) are required */
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+
+	for (uint32_t i = lane; i < RW + WAVE; i += WAVE) {
+		s_mark[i] = 0;
+	}
+	s_bits[lane] = 0;
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	WAVE_SYNC();
+
+	/* wave-uniform per-slot state as in k_scan8 (one window per set) */
+	const posting_t *pt[NT];
+	int32_t ab[NT], lo[NT], pdoc[NT];
+	uint32_t tok[NT];
+	uint64_t vm[NT];
+	uint32_t Ad[NT];		/* set B: bset_request()/bset_take() */
+	float Ai[NT];
+
+	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
+		const int32_t a = max(lo_ - wb, 0), e = min(hi_ - wb, WAVE);
+		if (e <= a) {
+			return 0;
+		}
+		const uint64_t upto = e >= WAVE ? ~0ull : ((1ull << e) - 1);
+		return upto & ~((1ull << a) - 1);
+	};
+	auto refresh_pdoc = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = vm[t] ? __builtin_amdgcn_readlane((int)Ad[t], 63 - __builtin_clzll(vm[t])) : -1;
+	};
+	auto load_sets = [&](auto tc, int32_t hi_) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = -1;
+		ab[t] = 0;
+		vm[t] = 0;
+		if (hi_ > lo[t]) {
+			ab[t] = ((hi_ - 1) >> 6) << 6;
+			const int32_t ia = max(ab[t] + (int32_t)lane, lo[t]);
+			const int32_t ib = max(ab[t] - WAVE + (int32_t)lane, lo[t]);
+			const posting_t pa = pt[t][min(ia, hi_ - 1)];
+			Ad[t] = pa.doc; Ai[t] = pa.imp;
+			bset_request<t>(&pt[t][min(ib, hi_ - 1)]);
+			vm[t] = window_mask(ab[t], lo[t], hi_);
+			refresh_pdoc(tc);
+		}
+	};
+	/* set A is drained: wait for B, take it over, request the window below */
+	auto rotate_sets = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		ab[t] -= WAVE;
+		vm[t] = window_mask(ab[t], lo[t], 0x7fffffff);
+		const posting_t *np = &pt[t][max(ab[t] - WAVE + (int32_t)lane, lo[t])];
+		bset_take<t>(Ad[t], Ai[t], np);
+	};
+
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		int32_t hi0 = 0;
+		pt[t] = A.post;
+		lo[t] = 0;
+		tok[t] = 0;
+		if (t < (int)nt) {
+			tok[t] = Q->slot_tok[t];
+			pt[t] = A.post + Q->pbeg[tok[t]];
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + tok[t];
+			lo[t] = (int32_t)A.cursors[cb];
+			hi0 = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+		}
+		load_sets(tc, hi0);
+	});
+
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	bool done = false;		/* a required slot ran out: nothing below can match */
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	while (!done && pdoc[0] >= 0) {
+		const int32_t dtop = pdoc[0];
+		const uint32_t base = (uint32_t)dtop & ~(uint32_t)(RW - 1);
+		/* the driver's postings of this round */
+		const uint64_t inm0 = vm[0] & ballot64(Ad[0] >= base);
+		const bool in0 = lane_of(inm0);
+		const uint32_t dd0 = in0 ? Ad[0] - base : RW + lane;
+		const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)Ad[0], __builtin_ctzll(inm0));
+		uint64_t alive = inm0;
+
+		vm[0] ^= inm0;
+		s_mark[dd0] = in0 ? (uint8_t)(lane + 1) : (uint8_t)0;
+		s_bits[lane] = (uint8_t)(1u << tok[0]);
+		s_imp[tok[0]][lane] = Ai[0];
+		WAVE_SYNC();
+
+		static_for<NT - 1>([&](auto jc) {
+			constexpr int j = decltype(jc)::value + 1;
+			using JC = std::integral_constant<int, j>;
+			if (j < (int)nt && alive && !done) {
+				/* nothing above the driver's top doc can match: drop it unread */
+				if (pdoc[j] > dtop) {
+					for (int tries = 0; ; tries++) {
+						vm[j] &= ~ballot64(Ad[j] > (uint32_t)dtop);
+						if (vm[j] || ab[j] <= lo[j]) {
+							break;		/* the boundary is in this window / list exhausted */
+						}
+						if (tries < 2) {
+							rotate_sets(JC());	/* stream a little ... */
+							continue;
+						}
+						/* ... then jump: lane l probes the first posting of the
+						 * l-th window below; the boundary is in the first one
+						 * that starts at or below the driver's doc */
+						const int32_t li = ab[j];	/* postings [lo, li) are unseen */
+						const int32_t pi = max(li - (int32_t)(lane + 1) * WAVE, lo[j]);
+						const uint32_t pv = pt[j][pi].doc;
+						const uint64_t pm = ballot64(pv <= (uint32_t)dtop);
+						int32_t nh;
+						if (pm) {
+							nh = min(li, max(li - (int32_t)__builtin_ctzll(pm) * WAVE, lo[j] + 1));
+						} else {
+							const int32_t far = max(li - WAVE * WAVE, lo[j]);
+							nh = far > lo[j] ? wave_lower_bound(pt[j], lo[j], far, (uint32_t)dtop + 1) : lo[j];
+						}
+						load_sets(JC(), nh);
+						tries = 2;
+						if (nh <= lo[j]) {
+							break;
+						}
+					}
+					refresh_pdoc(JC());
+				}
+				if (pdoc[j] < 0 && j < (int)n_req) {
+					done = true;
+				}
+				if (pdoc[j] >= (int32_t)rlo) {
+					/* look this slot's postings of the span up in the map */
+					const uint32_t tj = tok[j];
+					uint64_t left = vm[j];
+					for (;;) {
+						const uint64_t inm = left & ballot64(Ad[j] >= rlo);
+						left ^= inm;
+						if (inm) {
+							const bool inl = lane_of(inm);
+							const uint32_t dd = inl ? Ad[j] - base : RW + lane;
+							const uint32_t m = s_mark[dd];
+							if (ballot64(m != 0)) {
+								if (m != 0) {
+									s_imp[tj][m - 1] = Ai[j];
+									s_bits[m - 1] = (uint8_t)(s_bits[m - 1] | (1u << tj));
+								}
+							}
+						}
+						if (left == 0 && ab[j] > lo[j]) {
+							rotate_sets(JC());
+							left = vm[j];
+							continue;
+						}
+						break;
+					}
+					vm[j] = left;
+					refresh_pdoc(JC());
+					WAVE_SYNC();
+				}
+				if (j < (int)n_req) {
+					/* driver lanes whose doc lacks this required term are out */
+					const uint32_t b = s_bits[lane];
+					const uint64_t ok = alive & ballot64(((b >> tok[j]) & 1) != 0);
+					if (lane_of(alive ^ ok)) {
+						s_mark[dd0] = 0;
+					}
+					alive = ok;
+					WAVE_SYNC();
+				}
+			}
+		});
+
+		if (alive) {
+			const bool al = lane_of(alive);
+			const uint32_t mask = al ? s_bits[lane] : 0;
+			const bool match = al && ((s_truth[mask >> 5] >> (mask & 31)) & 1);
+			if (MODE == MODE_COUNT) {
+				n_out += __popcll(ballot64(match));
+			} else {
+				float sc = 0.0f;
+				/* token order (results.c:134-136) */
+#pragma unroll
+				for (int k = 0; k < NT; k++) {
+					if ((mask >> k) & 1) {
+						sc += s_imp[k][lane];
+					}
+				}
+				const bool cand = match && (MODE == MODE_ALL || sc > thr);
+				uint64_t bal = ballot64(cand);
+				if (bal) {
+					const uint32_t ne = __popcll(bal);
+					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+						ovf = true;
+					} else {
+						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+						if (cand) {
+							const uint64_t o = out_base + n_out + __popcll(above);
+							A.cand_doc[o] = Ad[0];
+							A.cand_sc[o] = sc;
+						}
+					}
+					n_out += ne;
+					if (track) {
+						while (bal) {
+							const int L = 63 - __clzll(bal);
+							bal &= ~(1ull << L);
+							const float v = __shfl(sc, L);
+							if (v > thr) {
+								const uint32_t pos = __popcll(ballot64(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = fmaxf(__shfl(top, kidx), hint);
+							}
+						}
+					}
+				}
+			}
+			if (al) {
+				s_mark[dd0] = 0;
+			}
+		}
+		WAVE_SYNC();
+
+		if (vm[0] == 0 && ab[0] > lo[0]) {
+			rotate_sets(std::integral_constant<int, 0>());
+		}
+		refresh_pdoc(std::integral_constant<int, 0>());
+	}
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));
 	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
@@ -2608,6 +2934,7 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 	/* densest term has >= this many postings per tile => tile path */
 	const char *env3 = getenv("NXS_GPU_DENSE");
 	const double dense_thr = env3 ? atof(env3) : 0.0;	/* step path off by default: the tile path is at least as fast */
+	const bool use_scanr = !getenv("NXS_GPU_NOSCANR") && ix->n_docs < (1ull << 31);
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -2643,6 +2970,20 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			}
 			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
+			/* required terms: intersect first (k_scanr).  Its work is set by
+			 * the shortest required list; longer lists are mostly skipped */
+			const uint32_t rmin = getenv("NXS_GPU_SCANR2") ? 2u : 3u;
+			if (tile && hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
+				const uint64_t dfd = hq[i].pend[hq[i].slot_tok[0]] - hq[i].pbeg[hq[i].slot_tok[0]];
+				uint64_t wr = 0;
+				for (uint32_t t = 0; t < hq[i].nt; t++) {
+					wr += std::min<uint64_t>(hq[i].pend[t] - hq[i].pbeg[t], 4 * dfd);
+				}
+				total -= work[i];
+				work[i] = wr;
+				total += wr;
+				cls[i] = 3u * 64 + nt_bucket(hq[i].nt);
+			}
 		}
 	}
 	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
@@ -2766,6 +3107,13 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
 			case 5: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 5, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, 0>), grid, block, 0, ix->stream, a); } break;
 			default: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 8, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, 0>), grid, block, 0, ix->stream, a); } break;
 			}
+		} else if (l.kind == 3) {
+			switch (l.nt_bucket) {
+			case 2: hipLaunchKernelGGL((k_scanr<MODE, 2>), grid, block, 0, ix->stream, a); break;
+			case 3: hipLaunchKernelGGL((k_scanr<MODE, 3>), grid, block, 0, ix->stream, a); break;
+			case 5: hipLaunchKernelGGL((k_scanr<MODE, 5>), grid, block, 0, ix->stream, a); break;
+			default: hipLaunchKernelGGL((k_scanr<MODE, 8>), grid, block, 0, ix->stream, a); break;
+			}
 		} else {
 			switch (l.nt_bucket) {
 			case 2: hipLaunchKernelGGL((k_scanh<MODE, 2>), grid, block, 0, ix->stream, a); break;
@@ -2858,6 +3206,24 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			d.pbeg[t] = ix->h_post_off[tid];
 			d.pend[t] = ix->h_post_off[tid + 1];
 			total_post += d.pend[t] - d.pbeg[t];
+		}
+		/* k_scanr slot order: required tokens first, shortest list first */
+		d.n_req = 0;
+		if (d.req && d.nt <= 8) {
+			uint32_t ord[8];
+			for (uint32_t t = 0; t < d.nt; t++) {
+				ord[t] = t;
+			}
+			std::sort(ord, ord + d.nt, [&](uint32_t x, uint32_t y) {
+				const bool rx = (d.req >> x) & 1, ry = (d.req >> y) & 1;
+				if (rx != ry) return rx;
+				const uint64_t dx = d.pend[x] - d.pbeg[x], dy = d.pend[y] - d.pbeg[y];
+				return dx != dy ? dx < dy : x < y;
+			});
+			for (uint32_t t = 0; t < d.nt; t++) {
+				d.slot_tok[t] = (uint8_t)ord[t];
+				d.n_req += (d.req >> t) & 1;
+			}
 		}
 	}
 	build_worklist(ix, hq, wl);

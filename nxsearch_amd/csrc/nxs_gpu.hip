@@ -110,6 +110,8 @@ struct dev_query_t {
 struct nxsgpu_index {
 	int		device;
 	hipStream_t	stream;
+	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
+	hipEvent_t	ev_cls, ev_join;
 
 	uint64_t	n_docs, n_post;
 	uint32_t	n_terms;
@@ -2219,6 +2221,7 @@ struct replay_args_t {
 	uint32_t *		out_count;
 	const uint64_t *	out_off;	/* [Q+1] or NULL => q * k */
 	const uint32_t *	skip;		/* [Q] nonzero => leave untouched */
+	const uint32_t *	qlist;		/* NULL, or the queries this launch replays (blockIdx -> query) */
 };
 
 template <bool LDS_HEAP>
@@ -2231,7 +2234,7 @@ k_replay(const replay_args_t A)
 	__shared__ float s_min;
 
 	const unsigned lane = threadIdx.x;
-	const uint32_t q = blockIdx.x;
+	const uint32_t q = A.qlist ? A.qlist[blockIdx.x] : blockIdx.x;
 	float *hs;
 	uint32_t *hd, cap;
 
@@ -2658,6 +2661,15 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 			(void)hipEventDestroy(ix->ev[i]);
 		}
 	}
+	if (ix->ev_cls) {
+		(void)hipEventDestroy(ix->ev_cls);
+	}
+	if (ix->ev_join) {
+		(void)hipEventDestroy(ix->ev_join);
+	}
+	if (ix->stream2) {
+		(void)hipStreamDestroy(ix->stream2);
+	}
 	if (ix->stream) {
 		(void)hipStreamDestroy(ix->stream);
 	}
@@ -2700,6 +2712,9 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	}
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_cls, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
 	for (int i = 0; i < 4; i++) {
 		HIP_TRY(hipEventCreate(&ix->ev[i]));
 	}
@@ -2906,13 +2921,14 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
  * paid once).  Items are grouped by kernel class (token-count bucket x
  * tile/step path) and emitted heaviest query first inside a class.
  */
-struct launch_t { uint32_t first, count, nt_bucket, kind, nomask; };	/* kind: 0 wide, 1 tile, 2 step */
+struct launch_t { uint32_t first, count, nt_bucket, kind, nomask, q_first, q_count; };	/* kind: 0 wide, 1 tile, 2 step */
 
 struct worklist_t {
 	std::vector<qmeta_t>	qmeta;
 	std::vector<item_t>	items;
 	std::vector<launch_t>	launches;
 	std::vector<uint32_t>	bnd_q;		/* boundary -> query, n_segs + nq entries */
+	std::vector<uint32_t>	qorder;		/* queries in launch order; launch_t::q_first/q_count index it */
 	uint32_t		n_segs;
 };
 
@@ -2935,6 +2951,9 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 	const char *env3 = getenv("NXS_GPU_DENSE");
 	const double dense_thr = env3 ? atof(env3) : 0.0;	/* step path off by default: the tile path is at least as fast */
 	const bool use_scanr = !getenv("NXS_GPU_NOSCANR") && ix->n_docs < (1ull << 31);
+	const bool no_step = getenv("NXS_GPU_NOSTEP") != NULL, mask_off = !getenv("NXS_GPU_NOMASKOFF");
+	const uint32_t rmin = getenv("NXS_GPU_NOSCANR2") ? 3u : 2u;	/* else "a AND b" takes k_scan8's sign-bit path */
+	const bool by_level = !getenv("NXS_GPU_NOLEVELS");
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -2954,16 +2973,16 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 		} else {
 			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
 			const bool tile = dense_thr <= 0.0 || per_tile >= dense_thr || hq[i].nt <= 1 ||
-			    ix->n_docs >= (1ull << 31) || getenv("NXS_GPU_NOSTEP");
+			    ix->n_docs >= (1ull << 31) || no_step;
 			/* pure OR: every non-empty presence mask matches => no mask array */
-			bool or_only = hq[i].nt >= 2 && !getenv("NXS_GPU_NOMASKOFF");
+			bool or_only = hq[i].nt >= 2 && mask_off;
 			for (uint32_t m = 1; or_only && m < (1u << hq[i].nt); m++) {
 				or_only = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
 			}
 			/* pure AND of exactly two tokens: only the full mask matches.
 			 * (The sign-parity scheme of MM = 2 cannot tell "stuck at token
 			 * t-2" from "updated by token t" for three tokens or more.) */
-			bool and_only = hq[i].nt == 2 && !getenv("NXS_GPU_NOMASKOFF");
+			bool and_only = hq[i].nt == 2 && mask_off;
 			for (uint32_t m = 1; and_only && m < (1u << hq[i].nt); m++) {
 				const bool hit = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
 				and_only = hit == (m == (1u << hq[i].nt) - 1);
@@ -2972,7 +2991,6 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
 			/* required terms: intersect first (k_scanr).  Its work is set by
 			 * the shortest required list; longer lists are mostly skipped */
-			const uint32_t rmin = getenv("NXS_GPU_SCANR2") ? 2u : 3u;
 			if (tile && hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
 				const uint64_t dfd = hq[i].pend[hq[i].slot_tok[0]] - hq[i].pbeg[hq[i].slot_tok[0]];
 				uint64_t wr = 0;
@@ -3019,6 +3037,7 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 		}
 	}
 	wl.items.reserve(wl.n_segs);
+	wl.qorder = order;
 	/*
 	 * Inside a class, items go out level by level: level l of every query
 	 * (its l-th highest doc range) before level l+1 of any.  All items carry
@@ -3037,10 +3056,20 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 		l.nt_bucket = cls[order[o0]] & 15;
 		l.nomask = (cls[order[o0]] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 two-token AND */
 		l.kind = cls[order[o0]] >> 6;
-		const bool by_level = !getenv("NXS_GPU_NOLEVELS");
 		if (by_level) {
+			/* the class is sorted by work, so n_groups does not increase along
+			 * it (checked): the queries that still have a level `lev` form a
+			 * prefix, and the loop is linear in the number of items */
+			bool mono = true;
+			for (uint32_t oi = o0 + 1; oi < o1 && mono; oi++) {
+				mono = wl.qmeta[order[oi]].n_groups <= wl.qmeta[order[oi - 1]].n_groups;
+			}
+			uint32_t live_end = o1;
 			for (uint32_t lev = 0; lev < max_g; lev++) {
-				for (uint32_t oi = o0; oi < o1; oi++) {
+				while (mono && live_end > o0 && wl.qmeta[order[live_end - 1]].n_groups <= lev) {
+					live_end--;
+				}
+				for (uint32_t oi = o0; oi < live_end; oi++) {
 					const uint32_t i = order[oi];
 					if (lev < wl.qmeta[i].n_groups) {
 						item_t it;
@@ -3062,6 +3091,8 @@ build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, wor
 			}
 		}
 		l.count = (uint32_t)wl.items.size() - l.first;
+		l.q_first = o0;
+		l.q_count = o1 - o0;
 		wl.launches.push_back(l);
 		o0 = o1;
 	}
@@ -3077,10 +3108,19 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
 	}
 }
 
+/*
+ * One scan launch per query class.  With `ra` (top-k filter pass) the heap
+ * replay of a class is queued on the second stream as soon as the class's
+ * scan is: the replay is a few latency-bound wavefronts (one per query) and
+ * runs beside the next class's scan instead of after all of them.
+ */
 template <int MODE>
 static void
-launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
+launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
+    const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL)
 {
+	bool forked = false;
+
 	for (const launch_t &l : wl.launches) {
 		scan_args_t a = a0;
 		const dim3 grid(l.count), block(WAVE);
@@ -3122,6 +3162,21 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl)
 			default: hipLaunchKernelGGL((k_scanh<MODE, 8>), grid, block, 0, ix->stream, a); break;
 			}
 		}
+		if (ra && l.q_count) {
+			replay_args_t r = *ra;
+			r.qlist = d_qorder + l.q_first;
+			(void)hipEventRecord(ix->ev_cls, ix->stream);
+			(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
+			hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream2, r);
+			forked = true;
+		}
+	}
+	if (scans_done) {
+		(void)hipEventRecord(scans_done, ix->stream);
+	}
+	if (forked) {
+		(void)hipEventRecord(ix->ev_join, ix->stream2);
+		(void)hipStreamWaitEvent(ix->stream, ix->ev_join, 0);
 	}
 }
 
@@ -3173,6 +3228,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		return 0;
 	}
 
+	static double hp_[6]; static int hp_n;
+	auto now_ = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+	const double hp0 = now_();
 	for (uint32_t i = 0; i < nq; i++) {
 		const nxsgpu_query_t &q = queries[i];
 		dev_query_t &d = hq[i];
@@ -3226,12 +3284,14 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			}
 		}
 	}
+	const double hp1 = now_();
 	build_worklist(ix, hq, wl);
 	const uint64_t nseg = wl.n_segs;
+	const double hp2 = now_();
 
 	/* workspace: queries | meta | items | seg_count | overflow | candidates | outputs */
 	{
-		size_t need = 8192 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
+		size_t need = 8192 + nq * 4 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
 		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
@@ -3248,6 +3308,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	float *d_pub = carve<float>(p, nseg);
+	uint32_t *d_qorder = carve<uint32_t>(p, nq);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
 	d_ids = dev_out ? d_out_ids : carve<uint64_t>(p, (size_t)nq * kfast);
@@ -3258,12 +3319,14 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_items, wl.items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+	    hipMemcpyAsync(d_qorder, wl.qorder.data(), nq * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess ||
 	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
 	}
 
+	const double hp3 = now_();
 	memset(&sa, 0, sizeof(sa));
 	sa.post = ix->d_post[algo];
 	sa.queries = d_q;
@@ -3284,9 +3347,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	if (fast) {
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
 		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
-		launch_scan<MODE_TOPK>(ix, sa, wl);
-		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
-
 		memset(&ra, 0, sizeof(ra));
 		ra.qmeta = d_qmeta;
 		ra.seg_cap = seg_cap;
@@ -3299,7 +3359,15 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		ra.out_sc = d_sc;
 		ra.out_count = d_cnt;
 		ra.skip = d_ovf;
-		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		if (getenv("NXS_GPU_ONEREPLAY")) {
+			launch_scan<MODE_TOPK>(ix, sa, wl);
+			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
+			hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		} else {
+			/* (profile: "replay" is then only what the last class's replay
+			 * adds after the last scan) */
+			launch_scan<MODE_TOPK>(ix, sa, wl, &ra, d_qorder, ix->profiling ? ix->ev[1] : NULL);
+		}
 		if (ix->profiling) (void)hipEventRecord(ix->ev[2], ix->stream);
 		if (hipGetLastError() != hipSuccess) {
 			set_error("kernel launch failed");
@@ -3310,9 +3378,15 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			return -1;
 		}
 		if (dev_out) {
+			const double hp4 = now_();
 			if (hipStreamSynchronize(ix->stream) != hipSuccess) {
 				set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
 				return -1;
+			}
+			if (getenv("NXS_GPU_HOSTPROF")) {
+				const double hp5 = now_();
+				hp_[0] += hp1 - hp0; hp_[1] += hp2 - hp1; hp_[2] += hp3 - hp2; hp_[3] += hp4 - hp3; hp_[4] += hp5 - hp4; hp_n++;
+				if (hp_n % 10 == 0) fprintf(stderr, "hostprof n=%d plan %.3f worklist %.3f upload %.3f launch %.3f sync %.3f ms\n", hp_n, hp_[0]/hp_n, hp_[1]/hp_n, hp_[2]/hp_n, hp_[3]/hp_n, hp_[4]/hp_n);
 			}
 			if (ix->profiling) {
 				float a = 0, b = 0;

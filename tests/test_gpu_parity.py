@@ -302,8 +302,8 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_DENSE": "1e12"}, {"NXS_GPU_DENSE": "8"},
                                  {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
                                  {"NXS_GPU_NOREQ": "1"}, {"NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
-                                 {"NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_SCANR2": "1"},
-                                 {"NXS_GPU_SCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
+                                 {"NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_NOSCANR2": "1"},
+                                 {"NXS_GPU_NOSCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
@@ -328,7 +328,7 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
     gidx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_SCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"}])
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
     tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""

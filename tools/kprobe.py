@@ -13,7 +13,7 @@ ap.add_argument("--docs", type=int, default=10_000_000)
 ap.add_argument("--terms", type=int, default=1_000_000)
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--sets", default="A,B,C,D,E,F")
+ap.add_argument("--sets", default="A,B,C,D,E,F,G,H,I,J")
 a = ap.parse_args()
 work = "/dev/shm/nxs_probe_%d_%d" % (a.docs, a.terms)
 if not os.path.exists(os.path.join(work, "done")):
@@ -37,6 +37,10 @@ sets = {
   "D": ("5-term AND rank 1..1000", [" AND ".join(T(r) for r in rng.sample(range(1, 1001), 5)) for _ in range(a.batch)]),
   "E": ("5-term OR rank 500..1000 (sparse)", [" OR ".join(T(r) for r in rng.sample(range(500, 1001), 5)) for _ in range(a.batch)]),
   "F": ("2-term OR rank 1..50 (dense)", [" OR ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
+  "G": ("2-term AND rank 1..1000", [" AND ".join(T(r) for r in rng.sample(range(1, 1001), 2)) for _ in range(a.batch)]),
+  "H": ("3-term AND rank 1..1000", [" AND ".join(T(r) for r in rng.sample(range(1, 1001), 3)) for _ in range(a.batch)]),
+  "I": ("a AND (b OR c) rank 1..1000", ["%s AND (%s OR %s)" % tuple(T(r) for r in rng.sample(range(1, 1001), 3)) for _ in range(a.batch)]),
+  "J": ("2-term AND rank 1..50 (dense)", [" AND ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
 }
 for name in a.sets.split(","):
     desc, qs = sets[name]

@@ -172,7 +172,9 @@ def main():
         + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / max(prof["launches"], 1)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_scan8", "achieved": round(achieved, 1),
+    # one scan launch per query class and step: k_scan8<0,5,1> (pure OR) and
+    # k_scanr<0,5> (required terms) on C3; kernel_ms is their sum per step
+    roofline = {"bound": "hbm", "kernel": "k_scan8+k_scanr", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(args, world),

@@ -7,9 +7,11 @@ terms synthetic Zipf corpus, 5-term AND/OR BM25 queries, batch 1024, top-10 --
 the configuration the metric is quoted on; it fits one GPU.
 
 A "step" = one batch of 1024 resolved queries through the device path
-(nxsgpu_search_dev: plan upload, k_scan, k_replay, results left in HBM) plus,
-for N > 1, one RCCL all-gather of the per-GPU top-k.  The index is resident
-in HBM before the timed region.  Launch:
+(nxsgpu_search_dev_begin/_end: host planning, plan upload, k_cursors, the scan
+kernels, k_replay, results left in HBM) plus, for N > 1, one RCCL all-gather of
+the per-GPU top-k.  Steps are software-pipelined two deep: the host plans and
+uploads step i+1 while the device runs step i; all K steps have completed when
+the timed region ends.  The index is resident in HBM before it starts.  Launch:
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -130,28 +132,43 @@ def main():
     from nxsearch_amd import multi
     k = args.limit
     all_queries = corpus.queries_bool5(terms, args.batch * world, seed=3, hi=1000)
-    sb = multi.ShardedBatch(len(all_queries), k, rank, world, dev)
+    # two batches in flight (nxsgpu_search_dev_begin/_end): the host plans and
+    # uploads step i+1 while step i runs; each has its own output buffers
+    sbs = [multi.ShardedBatch(len(all_queries), k, rank, world, dev) for _ in range(2)]
+    sb = sbs[0]
     queries = all_queries[sb.lo:sb.hi]
     plans, errs = idx.plan_batch(queries, limit=args.limit, algo="BM25", fuzzymatch=False)
     assert not any(errs)
-    d_cnt = sb.counts
 
-    def step():
-        r = idx.search_dev(plans, len(queries), k, N.BM25, sb.ids.data_ptr(),
-                           sb.scores.data_ptr(), sb.counts.data_ptr())
+    def begin(i):
+        o = sbs[i % 2]
+        idx.search_dev_begin(plans, len(queries), k, N.BM25, o.ids.data_ptr(),
+                             o.scores.data_ptr(), o.counts.data_ptr())
+
+    def end(i):
+        r = idx.search_dev_end()
         assert r == 0, "a query needed the exact two-pass path"
         # per-GPU top-k records over xGMI (RCCL all-gather); ~124 B per query
-        sb.gather(dist)
+        sbs[i % 2].gather(dist)
 
-    for _ in range(args.warmup):
-        step()
+    def run(n):
+        """n steps, software-pipelined: every step is one whole batch through
+        plan upload, cursors, scans, replay (+ all-gather); all have completed
+        when this returns."""
+        for i in range(n):
+            begin(i)
+            if i:
+                end(i - 1)
+        if n:
+            end(n - 1)
+
+    run(args.warmup)
     idx.set_profiling(True)
     idx.profile(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -167,7 +184,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- roofline of the dominant kernel (k_scan) on this rank --------------
-    matched = int(d_cnt.sum().item())
+    matched = int(sbs[(args.steps - 1) % 2].counts.sum().item())
     alg_bytes = prof["postings"] * POSTING_BYTES / max(prof["launches"], 1) \
         + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / max(prof["launches"], 1)

@@ -141,6 +141,19 @@ int		nxsgpu_search_dev(nxsgpu_index_t *, int algo, uint32_t limit,
 		    const nxsgpu_query_t *queries, uint32_t n_queries,
 		    uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts);
 
+/*
+ * The same, split for pipelining: _begin() plans the batch on the host, sends
+ * the plans up and queues the kernels, then returns; _end() waits for the
+ * OLDEST batch in flight and returns its status (0 / 1 / -1 as above).  Up to
+ * two batches may be in flight, so the host prepares batch i+1 while batch i
+ * runs; each needs its own output buffers until its _end().  nxsgpu_search()
+ * and nxsgpu_search_dev() refuse to run while a batch is in flight.
+ */
+int		nxsgpu_search_dev_begin(nxsgpu_index_t *, int algo, uint32_t limit,
+		    const nxsgpu_query_t *queries, uint32_t n_queries,
+		    uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts);
+int		nxsgpu_search_dev_end(nxsgpu_index_t *);
+
 int		nxsgpu_fuzzy(nxsgpu_index_t *, const uint8_t *tok_bytes,
 		    const uint32_t *tok_off, uint32_t n_tokens,
 		    uint32_t *term_ids, uint64_t *visited);

@@ -84,7 +84,8 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
     "nxsgpu_index_destroy", "nxsgpu_index_df", "nxsgpu_index_postings",
     "nxsgpu_index_docs", "nxsgpu_index_first_bad_doc", "nxsgpu_search",
-    "nxsgpu_results_free", "nxsgpu_search_dev", "nxsgpu_fuzzy",
+    "nxsgpu_results_free", "nxsgpu_search_dev", "nxsgpu_search_dev_begin",
+    "nxsgpu_search_dev_end", "nxsgpu_fuzzy",
     "nxsgpu_set_profiling", "nxsgpu_get_profile", "nxsgpu_synchronize",
 ]
 
@@ -156,6 +157,10 @@ def lib():
     L.nxsgpu_search_dev.restype = C.c_int
     L.nxsgpu_search_dev.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(GpuQuery),
                                     C.c_uint32, vp, vp, vp]
+    L.nxsgpu_search_dev_begin.restype = C.c_int
+    L.nxsgpu_search_dev_begin.argtypes = L.nxsgpu_search_dev.argtypes
+    L.nxsgpu_search_dev_end.restype = C.c_int
+    L.nxsgpu_search_dev_end.argtypes = [vp]
     L.nxsgpu_fuzzy.restype = C.c_int
     L.nxsgpu_fuzzy.argtypes = [vp, cp, C.POINTER(C.c_uint32), C.c_uint32,
                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -341,6 +346,19 @@ class Index:
         some query needs the exact two-pass path."""
         r = lib().nxsgpu_search_dev(self.device, algo, limit, plans, n,
                                     d_ids, d_scores, d_counts)
+        if r < 0:
+            raise NxsError(1, lib().nxsgpu_last_error().decode())
+        return r
+
+    def search_dev_begin(self, plans, n, limit, algo, d_ids, d_scores, d_counts):
+        """nxsgpu_search_dev_begin(): queue a batch (at most two in flight)."""
+        if lib().nxsgpu_search_dev_begin(self.device, algo, limit, plans, n,
+                                         d_ids, d_scores, d_counts) != 0:
+            raise NxsError(1, lib().nxsgpu_last_error().decode())
+
+    def search_dev_end(self):
+        """nxsgpu_search_dev_end(): wait for the oldest batch in flight -> 0 / 1."""
+        r = lib().nxsgpu_search_dev_end(self.device)
         if r < 0:
             raise NxsError(1, lib().nxsgpu_last_error().decode())
         return r

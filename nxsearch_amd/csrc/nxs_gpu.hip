@@ -112,6 +112,21 @@ struct nxsgpu_index {
 	hipStream_t	stream;
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
 	hipEvent_t	ev_cls, ev_join;
+	/* nxsgpu_search_dev_begin/_end: two batches in flight, each with its own
+	 * device workspace and pinned staging; plans go up on their own stream */
+	hipStream_t	stream_up;
+	struct dev_slot_t {
+		void *		ws;
+		size_t		ws_len;
+		uint8_t *	h_stage;	/* pinned: uploads, then the overflow flags coming back */
+		size_t		h_stage_len;
+		hipEvent_t	ev_up, ev_done, ev_t[3];
+		bool		active;
+		uint32_t	nq;
+		uint64_t	postings;
+		uint64_t	seq;
+	}		slot[2];
+	uint64_t	slot_seq;
 
 	uint64_t	n_docs, n_post;
 	uint32_t	n_terms;
@@ -2661,6 +2676,24 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 			(void)hipEventDestroy(ix->ev[i]);
 		}
 	}
+	for (int i = 0; i < 2; i++) {
+		nxsgpu_index::dev_slot_t &sl = ix->slot[i];
+		if (sl.active && sl.ev_done) {
+			(void)hipEventSynchronize(sl.ev_done);
+		}
+		(void)hipFree(sl.ws);
+		if (sl.h_stage) {
+			(void)hipHostFree(sl.h_stage);
+		}
+		if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+		if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+		for (int j = 0; j < 3; j++) {
+			if (sl.ev_t[j]) (void)hipEventDestroy(sl.ev_t[j]);
+		}
+	}
+	if (ix->stream_up) {
+		(void)hipStreamDestroy(ix->stream_up);
+	}
 	if (ix->ev_cls) {
 		(void)hipEventDestroy(ix->ev_cls);
 	}
@@ -2713,6 +2746,14 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) {
+		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
+		for (int j = 0; j < 3; j++) {
+			HIP_TRY(hipEventCreate(&ix->slot[i].ev_t[j]));
+		}
+	}
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_cls, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
 	for (int i = 0; i < 4; i++) {
@@ -2939,9 +2980,8 @@ nt_bucket(uint32_t nt)
 }
 
 static void
-build_worklist(const nxsgpu_index_t *ix, const std::vector<dev_query_t> &hq, worklist_t &wl)
+build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl)
 {
-	const uint32_t nq = (uint32_t)hq.size();
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
 	const char *env = getenv("NXS_GPU_WAVES");
 	const uint64_t target = env ? strtoull(env, NULL, 10) : 65536;
@@ -3184,53 +3224,17 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
  * Core of the search: fills device outputs.  If `d_out_*` are NULL the
  * results are copied to the host into `res`.
  */
+/*
+ * Device form of the batch's plans: posting ranges of the tokens, truth
+ * table, required-token mask and k_scanr's slot order.  -1 on a bad plan.
+ */
 static int
-search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
-    uint32_t nq, nxsgpu_results_t *res, uint64_t *d_out_ids, float *d_out_sc,
-    uint32_t *d_out_cnt)
+fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queries, uint32_t nq,
+    dev_query_t *hq, uint64_t &total_post)
 {
-	const bool dev_out = d_out_ids != NULL;
 	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
-	const bool fast = limit <= NXSGPU_FAST_K;
-	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
-	std::vector<dev_query_t> hq(nq);
-	std::vector<uint32_t> h_ovf, h_cnt;
-	worklist_t wl;
-	uint64_t total_post = 0;
-	uint8_t *p;
-	dev_query_t *d_q;
-	qmeta_t *d_qmeta;
-	item_t *d_items;
-	uint32_t *d_seg_count, *d_cand_doc, *d_ovf, *d_cnt;
-	uint64_t *d_ids;
-	float *d_cand_sc, *d_sc;
-	scan_args_t sa;
-	replay_args_t ra;
-	const uint32_t kfast = fast ? (uint32_t)limit : NXSGPU_FAST_K;
+	const bool no_req = getenv("NXS_GPU_NOREQ") != NULL;
 
-	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
-		set_error("invalid algorithm");
-		return -1;
-	}
-	if (limit == 0) {
-		set_error("invalid limit");
-		return -1;
-	}
-	if (hipSetDevice(ix->device) != hipSuccess) {
-		set_error("hipSetDevice failed");
-		return -1;
-	}
-	if (res) {
-		memset(res, 0, sizeof(*res));
-		res->n_queries = nq;
-	}
-	if (nq == 0) {
-		return 0;
-	}
-
-	static double hp_[6]; static int hp_n;
-	auto now_ = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-	const double hp0 = now_();
 	for (uint32_t i = 0; i < nq; i++) {
 		const nxsgpu_query_t &q = queries[i];
 		dev_query_t &d = hq[i];
@@ -3246,7 +3250,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		memcpy(d.truth, q.truth, sizeof(d.truth));
 		/* tokens common to every matching presence mask (<= 8 tokens) */
 		d.req = 0;
-		if (d.nt && d.nt <= 8 && !getenv("NXS_GPU_NOREQ")) {
+		if (d.nt && d.nt <= 8 && !no_req) {
 			uint32_t r = (1u << d.nt) - 1;
 			for (uint32_t m = 1; m < (1u << d.nt); m++) {
 				if ((d.truth[m >> 5] >> (m & 31)) & 1) {
@@ -3284,10 +3288,55 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			}
 		}
 	}
-	const double hp1 = now_();
-	build_worklist(ix, hq, wl);
+	return 0;
+}
+
+static int
+search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res)
+{
+	const bool fast = limit <= NXSGPU_FAST_K;
+	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
+	std::vector<dev_query_t> hq(nq);
+	std::vector<uint32_t> h_ovf, h_cnt;
+	worklist_t wl;
+	uint64_t total_post = 0;
+	uint8_t *p;
+	dev_query_t *d_q;
+	qmeta_t *d_qmeta;
+	item_t *d_items;
+	uint32_t *d_seg_count, *d_cand_doc, *d_ovf, *d_cnt;
+	uint64_t *d_ids;
+	float *d_cand_sc, *d_sc;
+	scan_args_t sa;
+	replay_args_t ra;
+	const uint32_t kfast = fast ? (uint32_t)limit : NXSGPU_FAST_K;
+
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (limit == 0) {
+		set_error("invalid limit");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (res) {
+		memset(res, 0, sizeof(*res));
+		res->n_queries = nq;
+	}
+	if (nq == 0) {
+		return 0;
+	}
+
+	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post) != 0) {
+		return -1;
+	}
+	build_worklist(ix, hq.data(), nq, wl);
 	const uint64_t nseg = wl.n_segs;
-	const double hp2 = now_();
 
 	/* workspace: queries | meta | items | seg_count | overflow | candidates | outputs */
 	{
@@ -3311,9 +3360,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	uint32_t *d_qorder = carve<uint32_t>(p, nq);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
-	d_ids = dev_out ? d_out_ids : carve<uint64_t>(p, (size_t)nq * kfast);
-	d_sc = dev_out ? d_out_sc : carve<float>(p, (size_t)nq * kfast);
-	d_cnt = dev_out ? d_out_cnt : carve<uint32_t>(p, nq);
+	d_ids = carve<uint64_t>(p, (size_t)nq * kfast);
+	d_sc = carve<float>(p, (size_t)nq * kfast);
+	d_cnt = carve<uint32_t>(p, nq);
 
 	if (hipMemcpyAsync(d_q, hq.data(), nq * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
@@ -3326,7 +3375,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		return -1;
 	}
 
-	const double hp3 = now_();
 	memset(&sa, 0, sizeof(sa));
 	sa.post = ix->d_post[algo];
 	sa.queries = d_q;
@@ -3376,33 +3424,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		if (hipMemcpyAsync(h_ovf.data(), d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
 			set_error("copy failed");
 			return -1;
-		}
-		if (dev_out) {
-			const double hp4 = now_();
-			if (hipStreamSynchronize(ix->stream) != hipSuccess) {
-				set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
-				return -1;
-			}
-			if (getenv("NXS_GPU_HOSTPROF")) {
-				const double hp5 = now_();
-				hp_[0] += hp1 - hp0; hp_[1] += hp2 - hp1; hp_[2] += hp3 - hp2; hp_[3] += hp4 - hp3; hp_[4] += hp5 - hp4; hp_n++;
-				if (hp_n % 10 == 0) fprintf(stderr, "hostprof n=%d plan %.3f worklist %.3f upload %.3f launch %.3f sync %.3f ms\n", hp_n, hp_[0]/hp_n, hp_[1]/hp_n, hp_[2]/hp_n, hp_[3]/hp_n, hp_[4]/hp_n);
-			}
-			if (ix->profiling) {
-				float a = 0, b = 0;
-				(void)hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]);
-				(void)hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]);
-				ix->prof.launches++;
-				ix->prof.scan_ms += a;
-				ix->prof.replay_ms += b;
-				ix->prof.postings += total_post;
-			}
-			for (uint32_t i = 0; i < nq; i++) {
-				if (h_ovf[i]) {
-					return 1;
-				}
-			}
-			return 0;
 		}
 	} else {
 		std::fill(h_ovf.begin(), h_ovf.end(), 1u);
@@ -3462,7 +3483,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		for (uint32_t j = 0; j < nx; j++) {
 			xhq[j] = hq[xq[j]];
 		}
-		build_worklist(ix, xhq, xwl);
+		build_worklist(ix, xhq.data(), nx, xwl);
 		const uint64_t xseg = xwl.n_segs;
 		std::vector<uint32_t> sc_cnt(xseg);
 		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
@@ -3633,18 +3654,266 @@ extern "C" int
 nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, nxsgpu_results_t *res)
 {
-	return search_impl(ix, algo, limit, queries, nq, res, NULL, NULL, NULL);
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_search: finish the batches in flight first (nxsgpu_search_dev_end)");
+		return -1;
+	}
+	return search_impl(ix, algo, limit, queries, nq, res);
+}
+
+/*
+ * Device-resident batches, two in flight.  _begin() plans on the host, stages
+ * everything the kernels need in pinned memory, sends it up on its own stream
+ * and queues cursors, scans and replays behind it; _end() waits for the oldest
+ * batch and reports whether one of its queries overflowed its candidate
+ * segments (1: the caller reruns the batch through nxsgpu_search(), which has
+ * the exact two-pass path).  While batch i runs, the host prepares and uploads
+ * batch i+1.  Outputs must be distinct per batch in flight.
+ */
+static int
+slot_ensure(nxsgpu_index::dev_slot_t &sl, size_t ws_need, size_t stage_need)
+{
+	if (sl.ws_len < ws_need) {
+		(void)hipFree(sl.ws);
+		sl.ws = NULL;
+		sl.ws_len = 0;
+		ws_need = (ws_need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+		if (hipMalloc(&sl.ws, ws_need) != hipSuccess) {
+			set_error("hipMalloc(%zu) for the query workspace failed", ws_need);
+			return -1;
+		}
+		sl.ws_len = ws_need;
+	}
+	if (sl.h_stage_len < stage_need) {
+		if (sl.h_stage) {
+			(void)hipHostFree(sl.h_stage);
+		}
+		sl.h_stage = NULL;
+		sl.h_stage_len = 0;
+		stage_need = (stage_need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+		if (hipHostMalloc((void **)&sl.h_stage, stage_need, hipHostMallocDefault) != hipSuccess) {
+			set_error("hipHostMalloc(%zu) failed", stage_need);
+			return -1;
+		}
+		sl.h_stage_len = stage_need;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+{
+	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
+	nxsgpu_index::dev_slot_t *sl = NULL;
+	worklist_t wl;
+	uint64_t total_post = 0;
+
+	if (limit == 0 || limit > NXSGPU_FAST_K || !d_doc_ids || !d_scores || !d_counts) {
+		set_error("nxsgpu_search_dev: limit must be 1..%d and outputs non-NULL", NXSGPU_FAST_K);
+		return -1;
+	}
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	for (int i = 0; i < 2; i++) {
+		if (!ix->slot[i].active) {
+			sl = &ix->slot[i];
+			break;
+		}
+	}
+	if (!sl) {
+		set_error("nxsgpu_search_dev_begin: two batches are already in flight");
+		return -1;
+	}
+	sl->nq = nq;
+	sl->postings = 0;
+	sl->seq = ++ix->slot_seq;
+	if (nq == 0) {
+		sl->active = true;
+		return 0;
+	}
+
+	/* plans straight into the pinned staging area (room for the work list:
+	 * <= target + nq ranges, see build_worklist) */
+	const uint64_t wave_target = getenv("NXS_GPU_WAVES") ? strtoull(getenv("NXS_GPU_WAVES"), NULL, 10) : 65536;
+	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
+	const size_t stage_need = 8192 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 8)
+	    + seg_bound * (sizeof(item_t) + 4) + nq * 4;
+	if (slot_ensure(*sl, 0, stage_need) != 0) {
+		return -1;
+	}
+	uint8_t *hp = sl->h_stage;
+	dev_query_t *h_q = carve<dev_query_t>(hp, nq);
+	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post) != 0) {
+		return -1;
+	}
+	build_worklist(ix, h_q, nq, wl);
+	const uint64_t nseg = wl.n_segs;
+	if (nseg > seg_bound) {
+		set_error("work list larger than its bound (%llu > %zu)", (unsigned long long)nseg, seg_bound);
+		return -1;
+	}
+	qmeta_t *h_qmeta = carve<qmeta_t>(hp, nq);
+	item_t *h_items = carve<item_t>(hp, nseg);
+	uint32_t *h_bnd_q = carve<uint32_t>(hp, nseg + nq);
+	uint32_t *h_qorder = carve<uint32_t>(hp, nq);
+	const size_t up_len = (size_t)(hp - sl->h_stage);
+	uint32_t *h_ovf = carve<uint32_t>(hp, nq);
+	memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
+	memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));
+	memcpy(h_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4);
+	memcpy(h_qorder, wl.qorder.data(), nq * 4);
+
+	/* device workspace: the uploaded block first (same carve sequence => same
+	 * offsets), then what only the kernels touch */
+	const size_t ws_need = 16384 + up_len + nseg * 4 + nq * 4
+	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * 4 + nseg * (size_t)seg_cap * 8;
+	if (slot_ensure(*sl, ws_need, 0) != 0) {
+		return -1;
+	}
+	uint8_t *p = (uint8_t *)sl->ws;
+	dev_query_t *d_q = carve<dev_query_t>(p, nq);
+	qmeta_t *d_qmeta = carve<qmeta_t>(p, nq);
+	item_t *d_items = carve<item_t>(p, nseg);
+	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
+	uint32_t *d_qorder = carve<uint32_t>(p, nq);
+	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
+	uint32_t *d_ovf = carve<uint32_t>(p, nq);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
+	float *d_pub = carve<float>(p, nseg);
+	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
+	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
+
+	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, ix->stream_up) != hipSuccess ||
+	    hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
+	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess ||
+	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess ||
+	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream) != hipSuccess) {
+		set_error("query upload failed");
+		return -1;
+	}
+
+	scan_args_t sa;
+	replay_args_t ra;
+	memset(&sa, 0, sizeof(sa));
+	sa.post = ix->d_post[algo];
+	sa.queries = d_q;
+	sa.n_docs = ix->n_docs;
+	sa.qmeta = d_qmeta;
+	sa.items = d_items;
+	sa.k = limit;
+	sa.seg_cap = seg_cap;
+	sa.seg_count = d_seg_count;
+	sa.cand_doc = d_cand_doc;
+	sa.cand_sc = d_cand_sc;
+	sa.overflow = d_ovf;
+	sa.cursors = d_cursors;
+	sa.pub = d_pub;
+	memset(&ra, 0, sizeof(ra));
+	ra.qmeta = d_qmeta;
+	ra.seg_cap = seg_cap;
+	ra.seg_count = d_seg_count;
+	ra.cand_doc = d_cand_doc;
+	ra.cand_sc = d_cand_sc;
+	ra.doc_ids = ix->d_doc_ids;
+	ra.k = limit;
+	ra.out_ids = d_doc_ids;
+	ra.out_sc = d_scores;
+	ra.out_count = d_counts;
+	ra.skip = d_ovf;
+
+	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
+	launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
+	if (getenv("NXS_GPU_ONEREPLAY")) {
+		launch_scan<MODE_TOPK>(ix, sa, wl);
+		if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
+		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+	} else {
+		/* (profile: "replay" is then only what the last class's replay adds
+		 * after the last scan) */
+		launch_scan<MODE_TOPK>(ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL);
+	}
+	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], ix->stream);
+	if (hipGetLastError() != hipSuccess) {
+		set_error("kernel launch failed");
+		return -1;
+	}
+	if (hipMemcpyAsync(h_ovf, d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+	    hipEventRecord(sl->ev_done, ix->stream) != hipSuccess) {
+		set_error("copy failed");
+		return -1;
+	}
+	sl->postings = total_post;
+	sl->active = true;
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search_dev_end(nxsgpu_index_t *ix)
+{
+	nxsgpu_index::dev_slot_t *sl = NULL;
+
+	for (int i = 0; i < 2; i++) {
+		if (ix->slot[i].active && (!sl || ix->slot[i].seq < sl->seq)) {
+			sl = &ix->slot[i];
+		}
+	}
+	if (!sl) {
+		set_error("nxsgpu_search_dev_end: no batch in flight");
+		return -1;
+	}
+	sl->active = false;
+	if (sl->nq == 0) {
+		return 0;
+	}
+	if (hipEventSynchronize(sl->ev_done) != hipSuccess) {
+		set_error("batch failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	if (ix->profiling) {
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, sl->ev_t[0], sl->ev_t[1]);
+		(void)hipEventElapsedTime(&b, sl->ev_t[1], sl->ev_t[2]);
+		ix->prof.launches++;
+		ix->prof.scan_ms += a;
+		ix->prof.replay_ms += b;
+		ix->prof.postings += sl->postings;
+	}
+	/* the flags sit behind the uploaded block, same carve sequence as _begin */
+	uint8_t *hp = sl->h_stage;
+	(void)carve<dev_query_t>(hp, sl->nq);
+	const qmeta_t *h_qmeta = carve<qmeta_t>(hp, sl->nq);
+	const uint64_t nseg = (uint64_t)h_qmeta[sl->nq - 1].seg_first + h_qmeta[sl->nq - 1].n_groups;
+	(void)carve<item_t>(hp, nseg);
+	(void)carve<uint32_t>(hp, nseg + sl->nq);
+	(void)carve<uint32_t>(hp, sl->nq);
+	const uint32_t *h_ovf = carve<uint32_t>(hp, sl->nq);
+	for (uint32_t i = 0; i < sl->nq; i++) {
+		if (h_ovf[i]) {
+			return 1;
+		}
+	}
+	return 0;
 }
 
 extern "C" int
 nxsgpu_search_dev(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
 {
-	if (limit == 0 || limit > NXSGPU_FAST_K || !d_doc_ids || !d_scores || !d_counts) {
-		set_error("nxsgpu_search_dev: limit must be 1..%d and outputs non-NULL", NXSGPU_FAST_K);
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_search_dev: finish the batches in flight first (nxsgpu_search_dev_end)");
 		return -1;
 	}
-	return search_impl(ix, algo, limit, queries, nq, NULL, d_doc_ids, d_scores, d_counts);
+	if (nxsgpu_search_dev_begin(ix, algo, limit, queries, nq, d_doc_ids, d_scores, d_counts) != 0) {
+		return -1;
+	}
+	return nxsgpu_search_dev_end(ix);
 }
 
 extern "C" void

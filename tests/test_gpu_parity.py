@@ -353,6 +353,42 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     gidx.close()
 
 
+def test_pipelined_device_batches(nxs, tmp_path):
+    """nxsgpu_search_dev_begin/_end: two batches in flight with their own outputs
+    give what the blocking call gives; a third begin and a stray end are errors."""
+    import torch
+    c = corpus.write_corpus(str(tmp_path), 200_000, 8000, seed=41)
+    terms = corpus.term_strings(8000, seed=41)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    dev = torch.device("cuda", 0)
+    k = 10
+    batches = [corpus.queries_bool5(terms, 48, seed=s_, hi=600) for s_ in (1, 2, 3)]
+    plans = [gidx.plan_batch(b, limit=k, algo="BM25", fuzzymatch=False)[0] for b in batches]
+    outs = [(torch.zeros((48, k), dtype=torch.int64, device=dev),
+             torch.zeros((48, k), dtype=torch.float32, device=dev),
+             torch.zeros((48,), dtype=torch.int32, device=dev)) for _ in batches]
+    ptrs = lambda o: (o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    with pytest.raises(N.NxsError):
+        gidx.search_dev_end()                      # nothing in flight
+    gidx.search_dev_begin(plans[0], 48, k, N.BM25, *ptrs(outs[0]))
+    gidx.search_dev_begin(plans[1], 48, k, N.BM25, *ptrs(outs[1]))
+    with pytest.raises(N.NxsError):
+        gidx.search_dev_begin(plans[2], 48, k, N.BM25, *ptrs(outs[2]))   # two is the limit
+    with pytest.raises(N.NxsError):
+        gidx.search_batch(batches[2], limit=k, fuzzymatch=False)         # blocking API refuses meanwhile
+    assert gidx.search_dev_end() == 0              # batch 0
+    gidx.search_dev_begin(plans[2], 48, k, N.BM25, *ptrs(outs[2]))
+    assert gidx.search_dev_end() == 0              # batch 1
+    assert gidx.search_dev_end() == 0              # batch 2
+    for b, o in zip(batches, outs):
+        ids, sc, cnt = (t.cpu() for t in o)
+        for i, q in enumerate(b):
+            want = oidx.search(q, limit=k, fuzzymatch=False)
+            got = [(int(ids[i, j]), float(sc[i, j])) for j in range(int(cnt[i]))]
+            assert_same(got, want, q)
+    gidx.close()
+
+
 def test_sharded_search_single_rank(nxs, tmp_path):
     import torch
     from nxsearch_amd import multi

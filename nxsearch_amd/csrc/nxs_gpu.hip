@@ -43,7 +43,9 @@
 #include "nxs_lev.h"
 
 #define	WAVE		64
+#ifndef TILE_W
 #define	TILE_W		2048		/* docs per wavefront LDS tile */
+#endif
 #define	SEG_CAP_DEFAULT	1024		/* candidate slots per (query, group) */
 
 /* ------------------------------------------------------------------ */
@@ -104,6 +106,7 @@ struct dev_query_t {
 	uint32_t	req;		/* tokens present in every matching mask */
 	uint32_t	n_req;		/* k_scanr: slots [0, n_req) are the required tokens ... */
 	uint8_t		slot_tok[8];	/* ... slot -> token, ascending list length within each group */
+	float		tmax[8];	/* k_scanm: largest impact of tokens 0..7 */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
@@ -141,6 +144,7 @@ struct nxsgpu_index {
 	uint64_t *	d_post_dt;	/* [P] doc<<32 | tf (kept for refresh) */
 	posting_t *	d_post[2];	/* [P] per ranking algo */
 	std::vector<uint64_t> h_post_off;
+	std::vector<float> h_maximp[2];	/* [T+2] largest impact per term and ranking algo */
 
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;
@@ -257,7 +261,8 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
     uint64_t n, const uint32_t *__restrict__ doc_len,
     const double *__restrict__ logtf, const double *__restrict__ idf_bm25,
     const float *__restrict__ idf_tfidf, double adl, double kk, double bb,
-    posting_t *__restrict__ out_bm25, posting_t *__restrict__ out_tfidf)
+    posting_t *__restrict__ out_bm25, posting_t *__restrict__ out_tfidf,
+    uint32_t *__restrict__ max_bm25, uint32_t *__restrict__ max_tfidf)
 {
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -276,6 +281,19 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 		pt.imp = (float)tf * idf_tfidf[t];
 		out_bm25[i] = pb;
 		out_tfidf[i] = pt;
+		/*
+		 * Largest impact of the term (k_scanm's score bounds).  Impacts are
+		 * >= +0, where unsigned order of the bit pattern is float order.  The
+		 * plain read only saves atomics (a stale, smaller value just means one
+		 * atomic more): dense terms converge after a few wavefronts.
+		 */
+		const uint32_t bb_ = __float_as_uint(pb.imp), bt_ = __float_as_uint(pt.imp);
+		if (pb.imp > 0.0f && bb_ > max_bm25[t]) {
+			atomicMax(&max_bm25[t], bb_);
+		}
+		if (pt.imp > 0.0f && bt_ > max_tfidf[t]) {
+			atomicMax(&max_tfidf[t], bt_);
+		}
 	}
 }
 
@@ -480,6 +498,180 @@ NXS_BSET(5, "a10", "a11")
 NXS_BSET(6, "a12", "a13")
 NXS_BSET(7, "a14", "a15")
 #undef NXS_BSET
+
+/*
+ * Prefetch RING of the tile path: R windows per term in flight instead of one.
+ * A dense term drains a 64-posting window in one visit (a few hundred cycles)
+ * while a window takes a memory latency (1-2 us under load) to arrive, so with
+ * one window in flight every rotation of a dense term exposed that latency.
+ * Term slot T owns the AGPR pairs [T*R, T*R + R); pair p holds the window that
+ * is p-th to be consumed (mod R, `ring position`).  Taking the oldest window:
+ *
+ *     s_waitcnt vmcnt(R - 1)
+ *
+ * is exact enough and needs no bookkeeping: vector memory operations retire in
+ * issue order, the R - 1 other pairs of this term were requested after the
+ * oldest one (every take re-requests the pair it has just read, load_ring()
+ * requests all R in order, addresses are clamped instead of predicated so the
+ * count never varies), hence at most R - 1 operations outstanding means the
+ * oldest has landed.  Loads of other terms issued in between only make the
+ * wait longer than necessary, never shorter.  The position is wave-uniform
+ * (an SGPR): the switch below is a scalar branch tree, once per 64 postings.
+ */
+template <int I> __device__ __forceinline__ void bpair_request(const posting_t *np);
+template <int PAIR, int N> struct bpair_take_impl;
+#define	NXS_BPAIR(I, RD, RI, RP)							\
+template <> __device__ __forceinline__ void						\
+bpair_request<I>(const posting_t *np)							\
+{											\
+	asm volatile(									\
+	    "global_load_dwordx2 " RP ", %0, off"					\
+	    : : "v"(np) : "memory", RD, RI);						\
+}											\
+template <int N> struct bpair_take_impl<I, N> {					\
+	static __device__ __forceinline__ void						\
+	run(uint32_t &ad, float &ai, const posting_t *np)				\
+	{										\
+		asm volatile(								\
+		    "s_waitcnt vmcnt(%3)\n\t"						\
+		    "v_accvgpr_read_b32 %0, " RD "\n\t"					\
+		    "v_accvgpr_read_b32 %1, " RI "\n\t"					\
+		    "global_load_dwordx2 " RP ", %2, off"				\
+		    : "=&v"(ad), "=&v"(ai) : "v"(np), "i"(N) : "memory", RD, RI);	\
+	}										\
+};
+NXS_BPAIR(0, "a0", "a1", "a[0:1]")
+NXS_BPAIR(1, "a2", "a3", "a[2:3]")
+NXS_BPAIR(2, "a4", "a5", "a[4:5]")
+NXS_BPAIR(3, "a6", "a7", "a[6:7]")
+NXS_BPAIR(4, "a8", "a9", "a[8:9]")
+NXS_BPAIR(5, "a10", "a11", "a[10:11]")
+NXS_BPAIR(6, "a12", "a13", "a[12:13]")
+NXS_BPAIR(7, "a14", "a15", "a[14:15]")
+NXS_BPAIR(8, "a16", "a17", "a[16:17]")
+NXS_BPAIR(9, "a18", "a19", "a[18:19]")
+NXS_BPAIR(10, "a20", "a21", "a[20:21]")
+NXS_BPAIR(11, "a22", "a23", "a[22:23]")
+NXS_BPAIR(12, "a24", "a25", "a[24:25]")
+NXS_BPAIR(13, "a26", "a27", "a[26:27]")
+NXS_BPAIR(14, "a28", "a29", "a[28:29]")
+NXS_BPAIR(15, "a30", "a31", "a[30:31]")
+NXS_BPAIR(16, "a32", "a33", "a[32:33]")
+NXS_BPAIR(17, "a34", "a35", "a[34:35]")
+NXS_BPAIR(18, "a36", "a37", "a[36:37]")
+NXS_BPAIR(19, "a38", "a39", "a[38:39]")
+NXS_BPAIR(20, "a40", "a41", "a[40:41]")
+NXS_BPAIR(21, "a42", "a43", "a[42:43]")
+NXS_BPAIR(22, "a44", "a45", "a[44:45]")
+NXS_BPAIR(23, "a46", "a47", "a[46:47]")
+NXS_BPAIR(24, "a48", "a49", "a[48:49]")
+NXS_BPAIR(25, "a50", "a51", "a[50:51]")
+NXS_BPAIR(26, "a52", "a53", "a[52:53]")
+NXS_BPAIR(27, "a54", "a55", "a[54:55]")
+NXS_BPAIR(28, "a56", "a57", "a[56:57]")
+NXS_BPAIR(29, "a58", "a59", "a[58:59]")
+NXS_BPAIR(30, "a60", "a61", "a[60:61]")
+NXS_BPAIR(31, "a62", "a63", "a[62:63]")
+#undef NXS_BPAIR
+template <int I, int N> __device__ __forceinline__ void
+bpair_take(uint32_t &ad, float &ai, const posting_t *np)
+{
+	bpair_take_impl<I, N>::run(ad, ai, np);
+}
+
+/*
+ * Exact wait for one ring load.  Vector memory operations retire in issue
+ * order, so a load is done once at most `younger` operations are outstanding,
+ * `younger` = operations issued after it.  The kernels stamp every ring load
+ * with a per-wavefront issue counter, which gives a lower bound of that number
+ * (operations the compiler issues are not counted: the wait can only be longer
+ * than needed, never shorter).  Waiting for vmcnt(R - 1) instead made a term
+ * whose window rotates right after another term's wait for that term's brand
+ * new request: a full memory latency.  s_waitcnt takes an immediate, hence the
+ * branch tree; `younger` is wave-uniform.
+ */
+#define	VM_WAIT(n)	asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+__device__ __forceinline__ void
+vm_wait_younger(uint32_t younger)
+{
+	if (younger >= 8) {
+		if (younger >= 16) {
+			VM_WAIT(16);
+		} else if (younger >= 12) {
+			VM_WAIT(12);
+		} else if (younger >= 10) {
+			VM_WAIT(10);
+		} else {
+			VM_WAIT(8);
+		}
+	} else if (younger >= 4) {
+		if (younger >= 6) {
+			if (younger == 7) { VM_WAIT(7); } else { VM_WAIT(6); }
+		} else {
+			if (younger == 5) { VM_WAIT(5); } else { VM_WAIT(4); }
+		}
+	} else if (younger >= 2) {
+		if (younger == 3) { VM_WAIT(3); } else { VM_WAIT(2); }
+	} else {
+		if (younger == 1) { VM_WAIT(1); } else { VM_WAIT(0); }
+	}
+}
+
+/* request pair `pos` of term slot T (R pairs per term) */
+template <int T, int R> __device__ __forceinline__ void
+bring_request(uint32_t pos, const posting_t *np)
+{
+	static_assert(R == 1 || R == 2 || R == 4 || R == 8, "ring depth");
+	static_assert(T * R + R <= 32, "AGPR pairs");
+	if constexpr (R == 1) {
+		bpair_request<T>(np);
+	} else {
+		static_for<R>([&](auto rc) {
+			constexpr int r = decltype(rc)::value;
+			if (pos == (uint32_t)r) {
+				bpair_request<T * R + r>(np);
+			}
+		});
+	}
+}
+
+/* wait for pair `pos` (the oldest of term slot T), read it, re-request it */
+template <int T, int R> __device__ __forceinline__ void
+bring_take(uint32_t pos, uint32_t younger, uint32_t &ad, float &ai, const posting_t *np)
+{
+#ifndef NXS_VMWAIT_STAMPS
+	(void)younger;
+	vm_wait_younger(R - 1);		/* the stamp-free wait: the R - 1 siblings are younger */
+#else
+	vm_wait_younger(younger);
+#endif
+	if constexpr (R == 1) {
+		bpair_take<T, 63>(ad, ai, np);
+	} else {
+		static_for<R>([&](auto rc) {
+			constexpr int r = decltype(rc)::value;
+			if (pos == (uint32_t)r) {
+				bpair_take<T * R + r, 63>(ad, ai, np);
+			}
+		});
+	}
+}
+
+/* issue stamps of a term's R ring loads, oldest first (FIFO) */
+template <int R> struct ring_stamps {
+	uint32_t st[R];
+	/* operations issued after the oldest load of this ring */
+	__device__ __forceinline__ uint32_t younger(uint32_t seq) const { return seq - st[0] - 1; }
+	/* the oldest was consumed and requested again with stamp `seq` */
+	__device__ __forceinline__ void rotate(uint32_t seq)
+	{
+#pragma unroll
+		for (int r = 0; r + 1 < R; r++) {
+			st[r] = st[r + 1];
+		}
+		st[R - 1] = seq;
+	}
+};
 
 /*
  * Wave-cooperative lower bound: first index in [lo, hi) (relative to pt) whose
@@ -835,6 +1027,12 @@ k_scan(const scan_args_t A)
 #define	WAVE_SYNC()	__builtin_amdgcn_wave_barrier()
 
 #define	LIST_CAP	512
+#ifndef SCAN8_RING_MAX
+#define	SCAN8_RING_MAX	2		/* prefetch ring depth of the one-window tile path */
+#endif
+#ifndef SCANM_RING
+#define	SCANM_RING	2		/* prefetch ring depth of the mask path */
+#endif
 #define	TCAND_CAP	64
 
 template <int MODE, int NT, int MM>
@@ -904,6 +1102,19 @@ k_scan8(const scan_args_t A)
 	/* AP (one window per set): set B is the hidden prefetch register pair of
 	 * bset_request()/bset_take(); Bd/Bi are unused then */
 	constexpr bool AP = K == 1 && !ANDM;
+	/* AP: windows in flight per term below set A, and the ring position of the
+	 * oldest (bring_take) */
+	constexpr int RING = SCAN8_RING_MAX;
+	uint32_t rp[NT];
+	ring_stamps<RING> rst[NT];	/* issue stamps of the ring loads (vm_wait_younger) */
+	uint32_t vseq = 0;
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+#pragma unroll
+		for (int r = 0; r < RING; r++) {
+			rst[t].st[r] = 0;
+		}
+	}
 
 	/* lanes of the window starting at list index wb that lie in [lo_, hi_) */
 	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
@@ -944,7 +1155,15 @@ k_scan8(const scan_args_t A)
 				const posting_t pa = pt[t][min(ia, hi_ - 1)];
 				Ad[t][k] = pa.doc; Ai[t][k] = pa.imp;
 				if constexpr (AP) {
-					bset_request<t>(&pt[t][min(ib, hi_ - 1)]);
+					/* the RING windows below set A, oldest first */
+					static_for<RING>([&](auto rc) {
+						constexpr int r = decltype(rc)::value;
+						const int32_t ir = max(ab[t] - (r + 1) * WAVE + (int32_t)lane, lo[t]);
+						bpair_request<t * RING + r>(&pt[t][min(ir, hi_ - 1)]);
+						rst[t].st[r] = vseq++;
+					});
+					rp[t] = 0;
+					(void)ib;
 				} else {
 					const posting_t pb = pt[t][min(ib, hi_ - 1)];
 					Bd[t][k] = pb.doc; Bi[t][k] = pb.imp;
@@ -960,8 +1179,10 @@ k_scan8(const scan_args_t A)
 		if constexpr (AP) {
 			ab[t] -= WAVE;
 			vm[t][0] = window_mask(ab[t], lo[t], 0x7fffffff);
-			const posting_t *np = &pt[t][max(ab[t] - WAVE + (int32_t)lane, lo[t])];
-			bset_take<t>(Ad[t][0], Ai[t][0], np);
+			const posting_t *np = &pt[t][max(ab[t] - RING * WAVE + (int32_t)lane, lo[t])];
+			bring_take<t, RING>(rp[t], rst[t].younger(vseq), Ad[t][0], Ai[t][0], np);
+			rst[t].rotate(vseq++);
+			rp[t] = (rp[t] + 1) & (RING - 1);
 			return;
 		}
 		ab[t] -= SW;
@@ -1408,6 +1629,526 @@ k_scan8(const scan_args_t A)
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
 		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/*
+ * k_scanm: pure-OR queries of sparse terms ("mask path").
+ *
+ * Why: k_scan8 pays a fixed price per (tile, term) visit, and a tile is only
+ * 2048 docs wide because every doc needs an f32 accumulator in LDS.  A term
+ * of rank 100..1000 has 5-50 postings per such tile: most lanes of a visit are
+ * idle and a 64-posting window is visited in 2-14 tiles (measured: 0.7-1.2 TB/s
+ * on all-sparse queries against 6.2 TB/s on all-dense ones).  But once a
+ * candidate threshold exists, almost no doc of a sparse OR needs its sum:
+ *   - a doc holding ONE term scores that posting's impact: compared with the
+ *     threshold in registers while the window is visited, nothing is stored;
+ *   - a doc holding the term set S scores at most sum_{t in S} max_t (f32 sum
+ *     in token order of the terms' largest impacts: rounding is monotone, so
+ *     this bounds the reference's left-to-right sum); the 2^NT answers
+ *     "|S| >= 2 and bound(S) > thr" are a truth table the wavefront recomputes
+ *     whenever thr moves.
+ * So LDS holds one presence-mask BYTE per doc (a tile is 4x wider for the same
+ * LDS), a visit is one fire-and-forget ds_or_rtn_b32 per window (integer DS
+ * atomics run at full rate -- tools/lds_probe.hip -- unlike ds_add_f32), and
+ * the returned old byte tells the visit of a doc's LAST term which set the doc
+ * holds.  Docs that pass either test go to a pending list; after the tile they
+ * are sorted (descending doc), deduplicated and scored EXACTLY: one lane per
+ * doc, a binary search of the doc in every term's slice, impacts added in
+ * token order from 0.0f (what the accumulator tile does).  They then take the
+ * common threshold filter; everything emitted carries its exact score, in
+ * descending doc order, and every doc whose score beats the heap root at its
+ * turn is emitted (both tests are necessary conditions for that), so k_replay
+ * sees a superset in the right order exactly as with the other scan kernels.
+ *
+ * Cold start: with thr = -inf every posting passes.  The tile width adapts: it
+ * starts at 64 docs and doubles while a tile yields few candidates (halves
+ * when it yields many), up to MT_W.  A tile that overflows the pending list
+ * flags the query for the exact two-pass path.
+ */
+#ifndef MT_W
+#define	MT_W		8192		/* max docs per mask tile (1 byte each) */
+#endif
+#define	MT_W0		64		/* cold-start tile width */
+#define	PEND_CAP	128
+#define	PEND_FLUSH	32		/* score the pending docs once this many wait */
+#define	QSUM_MAX	224		/* quantised score bound of a doc holding every term at its largest impact */
+
+#ifdef NXS_STATS
+/* diagnostic build only (make variant XFLAGS=-DNXS_STATS): k_scanm event counts
+ * and cycle spans, read back with nxsgpu_debug_stats() */
+__device__ unsigned long long g_stats[16];
+#define	STAT_ADD(i, v)	do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#define	STAT_CLK()	((unsigned long long)__builtin_amdgcn_s_memtime())
+extern "C" void
+nxsgpu_debug_stats(unsigned long long *out, int reset)
+{
+	unsigned long long z[16] = { 0 };
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(z));
+	if (reset) {
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));
+	}
+}
+#else
+#define	STAT_ADD(i, v)	do { } while (0)
+#define	STAT_CLK()	0ull
+#endif
+
+/* No min-waves launch bound on kernels that own AGPRs by name (bpair_*): under
+ * register pressure the compiler would spill VGPRs into accumulation registers,
+ * possibly the ones with a prefetch in flight.  tests check .agpr_count. */
+template <int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scanm(const scan_args_t A)
+{
+	constexpr int RING = SCANM_RING;
+	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MT_W / 4 + WAVE];	/* + one dummy word per lane */
+	__shared__ uint32_t s_pend[PEND_CAP];
+
+	const unsigned lane = threadIdx.x;
+	const unsigned long long clk0 = STAT_CLK();
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+
+	for (uint32_t i = lane; i < MT_W / 4 + WAVE; i += WAVE) {
+		s_mask[i] = 0;
+	}
+	WAVE_SYNC();
+
+	/*
+	 * Per term: set A (window at list index ab, being consumed) and set N (the
+	 * window below it, already in registers), then RING windows in flight.
+	 * vmA/vmN = lanes not consumed yet.  A tile may run from A into N but never
+	 * past N, so every posting of a tile is in A or N when the tile is flushed.
+	 */
+	const posting_t *pt[NT];
+	int32_t ab[NT], lo[NT], hi[NT], pdoc[NT];
+	uint64_t vmA[NT], vmN[NT];
+	uint32_t Ad[NT], Nd[NT], rp[NT];
+	float Ai[NT], Ni[NT], tmx[NT];
+	int32_t ldocN[NT];	/* lowest doc of set N if a window lies below it, else 0 */
+	ring_stamps<RING> rst[NT];
+	uint32_t vseq = 0;
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+#pragma unroll
+		for (int r = 0; r < RING; r++) {
+			rst[t].st[r] = 0;
+		}
+	}
+
+	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
+		const int32_t a = max(lo_ - wb, 0), e = min(hi_ - wb, WAVE);
+		if (e <= a) {
+			return 0;
+		}
+		const uint64_t upto = e >= WAVE ? ~0ull : ((1ull << e) - 1);
+		return upto & ~((1ull << a) - 1);
+	};
+	auto refresh_pdoc = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = vmA[t] ? __builtin_amdgcn_readlane((int)Ad[t], 63 - __builtin_clzll(vmA[t]))
+		    : vmN[t] ? __builtin_amdgcn_readlane((int)Nd[t], 63 - __builtin_clzll(vmN[t])) : -1;
+	};
+	auto refresh_ldoc = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		ldocN[t] = (vmN[t] && ab[t] - WAVE > lo[t]) ? __builtin_amdgcn_readlane((int)Nd[t], 0) : 0;
+	};
+	/* set A is drained and a window lies below it: N becomes A, the oldest
+	 * window in flight becomes N, the one RING windows further down is requested */
+	auto shift = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		ab[t] -= WAVE;
+		Ad[t] = Nd[t];
+		Ai[t] = Ni[t];
+		vmA[t] = vmN[t];
+		if (ab[t] > lo[t]) {
+			vmN[t] = window_mask(ab[t] - WAVE, lo[t], 0x7fffffff);
+			const posting_t *np = &pt[t][max(ab[t] - (RING + 1) * WAVE + (int32_t)lane, lo[t])];
+			bring_take<t, RING>(rp[t], rst[t].younger(vseq), Nd[t], Ni[t], np);
+			rst[t].rotate(vseq++);
+			rp[t] = (rp[t] + 1) & (RING - 1);
+		} else {
+			vmN[t] = 0;
+			Nd[t] = 0xffffffffu;	/* no doc */
+		}
+		refresh_ldoc(tc);
+	};
+
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pt[t] = A.post;
+		lo[t] = hi[t] = ab[t] = 0;
+		pdoc[t] = -1;
+		vmA[t] = vmN[t] = 0;
+		rp[t] = 0;
+		tmx[t] = 0.0f;
+		Ad[t] = 0;
+		Ai[t] = 0.0f;
+		Nd[t] = 0xffffffffu;		/* no doc */
+		Ni[t] = 0.0f;
+		ldocN[t] = 0;
+		if (t < (int)nt) {
+			pt[t] = A.post + Q->pbeg[t];
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+			lo[t] = (int32_t)A.cursors[cb];
+			hi[t] = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+			tmx[t] = Q->tmax[t];
+		}
+		if (hi[t] > lo[t]) {
+			ab[t] = ((hi[t] - 1) >> 6) << 6;
+			/* clamped, unpredicated loads: validity lives in the masks */
+			const int32_t ia = max(ab[t] + (int32_t)lane, lo[t]);
+			const posting_t pa = pt[t][min(ia, hi[t] - 1)];
+			Ad[t] = pa.doc; Ai[t] = pa.imp;
+			vmA[t] = window_mask(ab[t], lo[t], hi[t]);
+			if (ab[t] > lo[t]) {
+				const int32_t in = max(ab[t] - WAVE + (int32_t)lane, lo[t]);
+				const posting_t pn = pt[t][in];
+				Nd[t] = pn.doc; Ni[t] = pn.imp;
+				vmN[t] = window_mask(ab[t] - WAVE, lo[t], 0x7fffffff);
+			}
+			static_for<RING>([&](auto rc) {
+				constexpr int r = decltype(rc)::value;
+				const int32_t ir = max(ab[t] - (r + 2) * WAVE + (int32_t)lane, lo[t]);
+				bpair_request<t * RING + r>(&pt[t][min(ir, hi[t] - 1)]);
+				rst[t].st[r] = vseq++;
+			});
+			refresh_pdoc(tc);
+			refresh_ldoc(tc);
+		}
+	});
+
+	float top = -INFINITY;
+	const float hint = range_hint(A, qm, g);	/* 0 = nothing published yet */
+	float thr = hint;				/* scores are > 0: 0 passes everything */
+	const uint32_t kidx = A.k - 1;			/* 1 <= k <= 64 (host) */
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = seg * A.seg_cap;
+
+	/*
+	 * Quantisation: q(x) = floor(x * qs) + 2 with qs = QSUM_MAX / (sum of the
+	 * terms' largest impacts), so a doc's byte never exceeds QSUM_MAX + 2*NT
+	 * <= 240 (no carry into the neighbour doc) and  sum_i q(x_i) / qs  is an
+	 * upper bound of the doc's score: floor(y) + 2 >= y + 1 covers the rounding
+	 * of the f32 product (and of the reference's f32 additions) with a whole
+	 * unit to spare.  A doc can only beat thr if its byte exceeds
+	 * thr_q = floor(thr * qs) - 1.
+	 */
+	float tsum = 0.0f;
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		tsum += tmx[t];
+	}
+	const float qs = tsum > 0.0f ? (float)QSUM_MAX / tsum : 0.0f;
+	/* (thr is wave-uniform but lives in a VGPR: hand the result to the scalar unit) */
+	auto thr_quant = [&](float th) -> int32_t {
+		return __builtin_amdgcn_readfirstlane(th > 0.0f ? (int32_t)min(th * qs, 1.0e6f) - 1 : -1);
+	};
+	int32_t thr_q = thr_quant(thr);
+
+	uint32_t n_pend = 0;
+	auto push = [&](uint64_t m, uint32_t doc) {
+		const uint32_t n = __popcll(m);
+		if (n_pend + n <= PEND_CAP) {
+			if (lane_of(m)) {
+				s_pend[n_pend + lanes_below(m)] = doc;
+			}
+		}
+		n_pend += n;
+	};
+
+	auto rfl32 = [](uint32_t v) -> uint32_t {
+		return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+	};
+	auto rfl64 = [&](uint64_t v) -> uint64_t {
+		return (uint64_t)rfl32((uint32_t)v) | ((uint64_t)rfl32((uint32_t)(v >> 32)) << 32);
+	};
+	/*
+	 * Flush (after every tile that pushed something): sort the pending docs
+	 * (descending), drop duplicates, score them exactly, emit what beats the
+	 * threshold.  Element e = c*64 + lane of the list lives in pd[c].
+	 *
+	 * Scores come from registers: a tile never spans a rotation (below), so
+	 * every posting of the tile sits in its term's set A, or in the window
+	 * before it (Pd/Pi) if the term rotated when the tile drained its set.  A
+	 * doc's impact in term t is found by comparing the doc with the 64 lanes;
+	 * one doc at a time (wave-uniform), terms in token order, sum from 0.0f
+	 * (results.c:134-136).  No memory access.
+	 */
+	auto flush = [&]() {
+		constexpr int PC = PEND_CAP / WAVE;
+		n_pend = rfl32(n_pend);		/* (see the main loop) */
+		n_out = rfl32(n_out);
+		const uint32_t nch = (n_pend + WAVE - 1) / WAVE;
+		uint32_t pd[PC], rk[PC];
+		STAT_ADD(3, 1);
+		STAT_ADD(4, n_pend);
+#pragma unroll
+		for (int c = 0; c < PC; c++) {
+			const uint32_t e = c * WAVE + lane;
+			pd[c] = e < n_pend ? s_pend[e] : 0;
+			rk[c] = 0;
+		}
+		WAVE_SYNC();
+#pragma unroll
+		for (int cj = 0; cj < PC; cj++) {
+			if ((uint32_t)cj < nch) {
+				const uint32_t nj = min(n_pend - cj * WAVE, (uint32_t)WAVE);
+				for (uint32_t j = 0; j < nj; j++) {
+					const uint32_t dj = __builtin_amdgcn_readlane((int)pd[cj], j);
+#pragma unroll
+					for (int c = 0; c < PC; c++) {
+						if ((uint32_t)c < nch) {
+							/* before me: larger doc, or the same doc pushed earlier */
+							rk[c] += (c == cj) ? ((dj > pd[c]) || (dj == pd[c] && j < lane))
+							    : ((dj > pd[c]) || (dj == pd[c] && cj < c));
+						}
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < PC; c++) {
+			const uint32_t e = c * WAVE + lane;
+			if (e < n_pend) {
+				s_pend[rk[c]] = pd[c];
+			}
+		}
+		WAVE_SYNC();
+
+		for (uint32_t off = 0; off < n_pend; off += WAVE) {
+			const uint32_t e = off + lane;
+			const bool valid = e < n_pend;
+			const uint32_t d = valid ? s_pend[e] : 0;
+			const bool dup = valid && e > 0 && s_pend[e - 1] == d;
+			const bool live = valid && !dup;
+			float sc = 0.0f;
+			uint64_t todo = ballot64(live);
+			while (todo) {
+				const int j = __builtin_ctzll(todo);
+				todo &= todo - 1;
+				const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, j);
+				float acc = 0.0f;
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					if (hi[t] > lo[t]) {
+						const uint64_t ma = ballot64(Ad[t] == dj);
+						if (ma) {
+							acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+							    __builtin_bit_cast(int, Ai[t]), __builtin_ctzll(ma)));
+						} else {
+							const uint64_t mp = ballot64(Nd[t] == dj);
+							if (mp) {
+								acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+								    __builtin_bit_cast(int, Ni[t]), __builtin_ctzll(mp)));
+							}
+						}
+					}
+				});
+				sc = (lane == (unsigned)j) ? acc : sc;
+			}
+			const bool cand = live && sc > thr;
+			uint64_t bal = ballot64(cand);
+			if (!bal) {
+				continue;
+			}
+			const uint32_t ne = __popcll(bal);
+			/*
+			 * (Shape matters to the compiler's uniformity analysis: every phi at
+			 * the join of a lane-dependent branch counts as divergent, so such a
+			 * branch must not share its join with an assignment to wave-uniform
+			 * state -- else `ovf`, and through the loop exit everything the main
+			 * loop carries, ends up in VGPRs.)
+			 */
+			const bool room = n_out + ne <= A.seg_cap;
+			if (!room) {
+				ovf = true;
+			}
+			if (room && cand) {
+				/* lanes are in descending doc order */
+				const uint64_t o = out_base + n_out + lanes_below(bal);
+				A.cand_doc[o] = d;
+				A.cand_sc[o] = sc;
+			}
+			n_out += ne;
+			while (bal) {
+				const int L = __builtin_ctzll(bal);
+				const float v = __shfl(sc, L);
+				/* branch-free insert into the sorted top-k register */
+				const bool ins = v > thr;
+				const uint32_t pos = __popcll(ballot64(top >= v));
+				const float up = __shfl_up(top, 1);
+				const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
+				top = ins ? ntop : top;
+				thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
+				bal &= bal - 1;
+			}
+		}
+		WAVE_SYNC();
+		thr_q = thr_quant(thr);
+		n_pend = 0;
+	};
+
+	/* widest tile tried next: small while nothing is known about the threshold */
+	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W : (uint32_t)MT_W0;
+
+	uint32_t ovf_u = 0;		/* `ovf` as the loop carries it */
+	for (;;) {
+		/*
+		 * All of this is wave-uniform and lives in SGPRs; saying so explicitly
+		 * (readfirstlane of an SGPR value folds away) stops the compiler's
+		 * uniformity analysis from talking itself into a divergent loop, which
+		 * put the whole loop state into VGPRs behind exec masks.
+		 */
+		n_pend = rfl32(n_pend);
+		n_out = rfl32(n_out);
+		tw = rfl32(tw);
+		thr_q = (int32_t)rfl32((uint32_t)thr_q);
+		ovf_u = rfl32(ovf_u | (ovf ? 1u : 0u));
+		ovf = ovf_u != 0;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			ab[t] = (int32_t)rfl32((uint32_t)ab[t]);
+			pdoc[t] = (int32_t)rfl32((uint32_t)pdoc[t]);
+			ldocN[t] = (int32_t)rfl32((uint32_t)ldocN[t]);
+			rp[t] = rfl32(rp[t]);
+			vmA[t] = rfl64(vmA[t]);
+			vmN[t] = rfl64(vmN[t]);
+		}
+		/*
+		 * The tile: docs [base, md], md = highest unconsumed doc of any term.
+		 * It must not reach past any term's set N: base is at least the lowest
+		 * doc of every N that has a window below it.  The densest term thus
+		 * brings one to two full windows to every tile.
+		 */
+		int32_t md = -1, low = 0;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			md = max(md, pdoc[t]);
+			low = max(low, pdoc[t] >= 0 ? ldocN[t] : 0);
+		}
+		/* (one loop exit only: with several the compiler treats the loop as
+		 * divergent and keeps all its wave-uniform state in VGPRs) */
+		if (md < 0 || ovf) {
+			break;
+		}
+		const uint32_t base = (uint32_t)max(low, md - (int32_t)tw + 1);
+		const uint32_t n_before = n_pend;
+		STAT_ADD(1, 1);
+		STAT_ADD(8, (uint32_t)md - base + 1);
+
+		/*
+		 * Add.  The old word a visit's atomic returns is looked at only after
+		 * every term has been visited (or before the same term's second
+		 * atomic, when the tile runs from A into N): up to NT atomics are in
+		 * flight and no visit waits for LDS.
+		 */
+		uint32_t oldv[NT], qv[NT], vdoc[NT];
+		uint64_t vis[NT];
+		auto resolve = [&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			if (vis[t]) {
+				/* qv = (q << 8) | shift: bound of the doc's score so far */
+				const uint32_t sum = ((oldv[t] >> (qv[t] & 31)) & 0xffu) + (qv[t] >> 8);
+				const uint64_t cm = vis[t] & ballot64((int32_t)sum > thr_q);
+				if (cm) {
+					push(cm, vdoc[t]);
+				}
+				vis[t] = 0;
+			}
+		};
+		auto visit = [&](auto tc, uint64_t inm, uint32_t wd, float wi) {
+			constexpr int t = decltype(tc)::value;
+			const bool inl = lane_of(inm);
+			const uint32_t dd = wd - base;
+			const uint32_t sh = (dd & 3) * 8;
+			const uint32_t w = inl ? (dd >> 2) : MT_W / 4 + lane;
+			/* floor + 2 >= the exact ceiling whatever the f32 product rounds to */
+			const uint32_t qq = (uint32_t)(wi * qs) + 2;
+			oldv[t] = __hip_atomic_fetch_add(&s_mask[w], inl ? (qq << sh) : 0u,
+			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			qv[t] = (qq << 8) | sh;
+			vdoc[t] = wd;
+			vis[t] = inm;
+			STAT_ADD(2, 1);
+			STAT_ADD(9, __popcll(inm));
+		};
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			vis[t] = 0;
+			oldv[t] = 0;
+			qv[t] = 0;
+			vdoc[t] = 0;
+			if (pdoc[t] >= (int32_t)base) {
+				const uint64_t inA = vmA[t] & ballot64(Ad[t] >= base);
+				if (inA) {
+					visit(tc, inA, Ad[t], Ai[t]);
+					vmA[t] ^= inA;
+				}
+				if (vmA[t] == 0 && vmN[t]) {
+					const uint64_t inN = vmN[t] & ballot64(Nd[t] >= base);
+					if (inN) {
+						resolve(tc);
+						visit(tc, inN, Nd[t], Ni[t]);
+						vmN[t] ^= inN;
+					}
+				}
+			}
+		});
+		static_for<NT>([&](auto tc) {
+			resolve(tc);
+		});
+		WAVE_SYNC();
+
+		/* wipe the tile's bytes (16 B per lane and store) */
+		{
+			/* (wave-uniform trip count: a lane-dependent one makes the compiler
+			 * treat the enclosing loop's state as divergent) */
+			const uint32_t words = ((uint32_t)md - base + 4) >> 2;
+			for (uint32_t i0 = 0; i0 < words; i0 += WAVE * 4) {
+				*(uint4 *)&s_mask[i0 + lane * 4] = make_uint4(0, 0, 0, 0);
+			}
+		}
+
+		const uint32_t n_tile = n_pend - n_before;
+		if (n_pend > PEND_CAP) {
+			ovf = true;
+		} else if (n_pend) {
+			flush();		/* looks the docs up in A and N: before any shift */
+		}
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			while (vmA[t] == 0 && ab[t] > lo[t]) {
+				shift(tc);
+			}
+			refresh_pdoc(tc);
+		});
+		if (n_tile <= 8) {
+			tw = min(tw * 2, (uint32_t)MT_W);
+		} else if (n_tile > 48) {
+			tw = max(tw / 2, (uint32_t)MT_W0);
+		}
+	}
+
+	STAT_ADD(0, 1);
+	STAT_ADD(5, n_out);
+	STAT_ADD(7, STAT_CLK() - clk0);
+	STAT_ADD(10, ovf ? 1 : 0);
+	if (!ovf) {
+		range_publish(A, seg, __shfl(top, kidx));
+	}
+	if (lane == 0) {
+		A.seg_count[seg] = ovf ? 0 : n_out;
+		if (ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -2724,6 +3465,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	void *d_tmp = NULL;
 	double *d_logtf = NULL, *d_idf_bm25 = NULL;
 	float *d_idf_tfidf = NULL;
+	uint32_t *d_maximp = NULL;
 	size_t tmp_bytes = 0;
 	unsigned long long h_first_bad = ~0ull;
 	unsigned int h_max_tf = 0;
@@ -2869,11 +3611,20 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 			HIP_TRY(hipMemcpyAsync(d_logtf, logtf.data(), logtf.size() * 8, hipMemcpyHostToDevice, ix->stream));
 			HIP_TRY(hipMemcpyAsync(d_idf_bm25, idf_b.data(), idf_b.size() * 8, hipMemcpyHostToDevice, ix->stream));
 			HIP_TRY(hipMemcpyAsync(d_idf_tfidf, idf_t.data(), idf_t.size() * 4, hipMemcpyHostToDevice, ix->stream));
+			HIP_TRY(hipMalloc(&d_maximp, ((size_t)T + 2) * 4 * 2));
+			HIP_TRY(hipMemsetAsync(d_maximp, 0, ((size_t)T + 2) * 4 * 2, ix->stream));
 			hipLaunchKernelGGL(k_impacts, dim3(4096), dim3(256), 0, ix->stream,
 			    d_keys, ix->d_post_dt, P, ix->d_doc_len, d_logtf, d_idf_bm25,
 			    d_idf_tfidf, adl >= 1 ? adl : 1.0, kk, bb,
-			    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF]);
+			    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF],
+			    d_maximp, d_maximp + (size_t)T + 2);
 			HIP_TRY(hipGetLastError());
+			ix->h_maximp[NXSGPU_BM25].assign((size_t)T + 2, 0.0f);
+			ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
+			HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_BM25].data(), d_maximp, ((size_t)T + 2) * 4,
+			    hipMemcpyDeviceToHost, ix->stream));
+			HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
+			    hipMemcpyDeviceToHost, ix->stream));
 			HIP_TRY(hipStreamSynchronize(ix->stream));
 		}
 	}
@@ -2896,6 +3647,7 @@ done_partial:
 	(void)hipFree(d_logtf);
 	(void)hipFree(d_idf_bm25);
 	(void)hipFree(d_idf_tfidf);
+	(void)hipFree(d_maximp);
 	return ix;
 fail:
 	(void)hipFree(d_img);
@@ -2911,6 +3663,7 @@ fail:
 	(void)hipFree(d_logtf);
 	(void)hipFree(d_idf_bm25);
 	(void)hipFree(d_idf_tfidf);
+	(void)hipFree(d_maximp);
 	nxsgpu_index_destroy(ix);
 	return NULL;
 }
@@ -2994,6 +3747,9 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	const bool no_step = getenv("NXS_GPU_NOSTEP") != NULL, mask_off = !getenv("NXS_GPU_NOMASKOFF");
 	const uint32_t rmin = getenv("NXS_GPU_NOSCANR2") ? 3u : 2u;	/* else "a AND b" takes k_scan8's sign-bit path */
 	const bool by_level = !getenv("NXS_GPU_NOLEVELS");
+	const bool use_scanm = !getenv("NXS_GPU_NOSCANM") && ix->n_docs < (1ull << 31);
+	/* k_scanm if the densest list holds at most this fraction of the docs */
+	const double scanm_dens = getenv("NXS_GPU_SCANM_DENS") ? atof(getenv("NXS_GPU_SCANM_DENS")) : 0.05;
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -3029,6 +3785,12 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 			}
 			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
+			/* pure OR of 3..5 tokens whose lists are sparse: mask path (k_scanm).
+			 * Dense lists stream faster through the accumulator tiles. */
+			if (tile && or_only && use_scanm && hq[i].nt >= 3 && hq[i].nt <= 5 &&
+			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
+				cls[i] = 4u * 64 + 16 + nt_bucket(hq[i].nt);
+			}
 			/* required terms: intersect first (k_scanr).  Its work is set by
 			 * the shortest required list; longer lists are mostly skipped */
 			if (tile && hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
@@ -3187,6 +3949,21 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			case 5: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 5, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, 0>), grid, block, 0, ix->stream, a); } break;
 			default: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 8, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, 0>), grid, block, 0, ix->stream, a); } break;
 			}
+		} else if (l.kind == 4) {
+			/* mask path: top-k filter pass only; the exact passes (count, emit
+			 * all) of these queries take the pure-OR accumulator tiles */
+			if (MODE == MODE_TOPK && a.k >= 1 && a.k <= WAVE) {
+				switch (l.nt_bucket) {
+				case 3: hipLaunchKernelGGL((k_scanm<3>), grid, block, 0, ix->stream, a); break;
+				default: hipLaunchKernelGGL((k_scanm<5>), grid, block, 0, ix->stream, a); break;
+				}
+			} else {
+				switch (l.nt_bucket) {
+				case 3: hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); break;
+				case 5: hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); break;
+				default: hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); break;
+				}
+			}
 		} else if (l.kind == 3) {
 			switch (l.nt_bucket) {
 			case 2: hipLaunchKernelGGL((k_scanr<MODE, 2>), grid, block, 0, ix->stream, a); break;
@@ -3268,6 +4045,9 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			d.pbeg[t] = ix->h_post_off[tid];
 			d.pend[t] = ix->h_post_off[tid + 1];
 			total_post += d.pend[t] - d.pbeg[t];
+			if (t < 8 && tid < ix->h_maximp[algo].size()) {
+				d.tmax[t] = ix->h_maximp[algo][tid];
+			}
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */
 		d.n_req = 0;

@@ -40,6 +40,9 @@ sets = {
   "G": ("2-term AND rank 1..1000", [" AND ".join(T(r) for r in rng.sample(range(1, 1001), 2)) for _ in range(a.batch)]),
   "H": ("3-term AND rank 1..1000", [" AND ".join(T(r) for r in rng.sample(range(1, 1001), 3)) for _ in range(a.batch)]),
   "I": ("a AND (b OR c) rank 1..1000", ["%s AND (%s OR %s)" % tuple(T(r) for r in rng.sample(range(1, 1001), 3)) for _ in range(a.batch)]),
+  "K": ("5-term OR rank 100..1000 (no dense)", [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 5)) for _ in range(a.batch)]),
+  "L": ("5-term OR rank 1..30 (all dense)", [" OR ".join(T(r) for r in rng.sample(range(1, 31), 5)) for _ in range(a.batch)]),
+  "M": ("5-term OR rank 30..100 (medium)", [" OR ".join(T(r) for r in rng.sample(range(30, 101), 5)) for _ in range(a.batch)]),
   "J": ("2-term AND rank 1..50 (dense)", [" AND ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
 }
 for name in a.sets.split(","):

@@ -287,11 +287,25 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 		 * plain read only saves atomics (a stale, smaller value just means one
 		 * atomic more): dense terms converge after a few wavefronts.
 		 */
-		const uint32_t bb_ = __float_as_uint(pb.imp), bt_ = __float_as_uint(pt.imp);
-		if (pb.imp > 0.0f && bb_ > max_bm25[t]) {
+		uint32_t bb_ = pb.imp > 0.0f ? __float_as_uint(pb.imp) : 0u;
+		uint32_t bt_ = pt.imp > 0.0f ? __float_as_uint(pt.imp) : 0u;
+		/* consecutive postings mostly belong to one term: reduce over the
+		 * wavefront first when they all do (the loop bound is wave-uniform
+		 * except in the last round, where the wavefront may be partial) */
+		const bool whole = (i - (threadIdx.x & 63)) + 63 < n;
+		if (whole && __builtin_amdgcn_ballot_w64(t != (uint32_t)__builtin_amdgcn_readfirstlane((int)t)) == 0) {
+			for (int o = 32; o; o >>= 1) {
+				bb_ = max(bb_, (uint32_t)__shfl_xor((int)bb_, o));
+				bt_ = max(bt_, (uint32_t)__shfl_xor((int)bt_, o));
+			}
+			if ((threadIdx.x & 63) != 0) {
+				bb_ = bt_ = 0;
+			}
+		}
+		if (bb_ > max_bm25[t]) {
 			atomicMax(&max_bm25[t], bb_);
 		}
-		if (pt.imp > 0.0f && bt_ > max_tfidf[t]) {
+		if (bt_ > max_tfidf[t]) {
 			atomicMax(&max_tfidf[t], bt_);
 		}
 	}
@@ -3749,7 +3763,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	const bool by_level = !getenv("NXS_GPU_NOLEVELS");
 	const bool use_scanm = !getenv("NXS_GPU_NOSCANM") && ix->n_docs < (1ull << 31);
 	/* k_scanm if the densest list holds at most this fraction of the docs */
-	const double scanm_dens = getenv("NXS_GPU_SCANM_DENS") ? atof(getenv("NXS_GPU_SCANM_DENS")) : 0.05;
+	const double scanm_dens = getenv("NXS_GPU_SCANM_DENS") ? atof(getenv("NXS_GPU_SCANM_DENS")) : 0.08;
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -3807,8 +3821,12 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 		}
 	}
 	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
+	/* launch order of the classes: the mask path first -- a class's heap replay
+	 * runs beside the NEXT class's scan, and the last class (required-term
+	 * queries: few candidates, short replay) is the one left exposed */
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 4 ? (c & 63) : c + 64; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-		if (cls[x] != cls[y]) return cls[x] < cls[y];
+		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
 	});
 	wl.qmeta.assign(nq, qmeta_t());

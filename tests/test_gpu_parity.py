@@ -303,7 +303,9 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
                                  {"NXS_GPU_NOREQ": "1"}, {"NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_NOSCANR2": "1"},
-                                 {"NXS_GPU_NOSCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
+                                 {"NXS_GPU_NOSCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
@@ -328,7 +330,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
     gidx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"}])
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
+                                 {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
     tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""
@@ -350,6 +353,55 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     got = gidx.search_batch(qs[:12], limit=64, fuzzymatch=False)
     for q, g in zip(qs[:12], got):
         assert_same(g, oidx.search(q, limit=64, fuzzymatch=False), (env, q, 64))
+    gidx.close()
+
+
+@pytest.mark.parametrize("seed,n_docs,vocab_n,max_len", [
+    (11, 3000, 12, 6),       # tiny vocabulary: massive score ties, every term dense
+    (12, 40000, 400, 10),    # Zipf vocabulary: sparse and dense terms in one query
+    (13, 150000, 5000, 8),   # mostly sparse terms: wide tiles, few candidates
+])
+def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len):
+    """k_scanm (quantised score bounds in a byte per doc + exact scores from the
+    register windows) forced for every pure-OR query of 3..5 tokens, whatever
+    the density of its terms: identical ids, order and score bits."""
+    monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    rng = random.Random(seed)
+    vocab = ["w%d" % i for i in range(vocab_n)]
+    weights = [1.0 / (i + 1) for i in range(vocab_n)]
+    pool = rng.choices(vocab, weights, k=8192)
+    docs = random_corpus(rng, n_docs, pool, max_len=max_len, sparse=(seed == 12))
+    gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
+    queries = []
+    for _ in range(40):
+        n = rng.randint(3, 5)
+        hi = rng.choice([min(vocab_n, 12), vocab_n // 2, vocab_n])
+        queries.append(" OR ".join(rng.sample(vocab[:max(hi, n)], n)))
+    queries += [" ".join(vocab[:4]), "%s OR %s OR %s" % (vocab[-1], vocab[-2], vocab[0])]
+    for limit in (1, 3, 10, 64):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = gidx.search_batch(queries, limit=limit, algo=name, fuzzymatch=False)
+            for q, g in zip(queries, got):
+                assert_same(g, oidx.search(q, algo=algo, limit=limit, fuzzymatch=False), (q, limit, name))
+    gidx.close()
+
+
+def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch):
+    """The highest docs all hold every query term: the cold-start tile pushes
+    more docs than the pending list takes, the query is flagged and re-run on
+    the exact two-pass path."""
+    monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    rng = random.Random(5)
+    vocab = ["w%d" % i for i in range(50)]
+    docs = random_corpus(rng, 4000, vocab, max_len=6)
+    last = docs[-1][0]
+    docs += [(last + 1 + i, ["w1", "w2", "w3", "w4", "w5"] * rng.randint(1, 3)) for i in range(200)]
+    gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
+    qs = ["w1 OR w2 OR w3 OR w4 OR w5", "w1 OR w2 OR w3", "w5 OR w30 OR w2 OR w40"]
+    for limit in (1, 10, 64):
+        got = gidx.search_batch(qs, limit=limit, fuzzymatch=False)
+        for q, g in zip(qs, got):
+            assert_same(g, oidx.search(q, limit=limit, fuzzymatch=False), (q, limit))
     gidx.close()
 
 

@@ -218,3 +218,43 @@ def test_synth_corpus_is_valid_and_deterministic(tmp_path):
     assert idx3.dt_count == 500
     ids = [d for d, _ in idx3.search(corpus.term_strings(100, 1)[0].decode(), limit=1000)]
     assert ids and max(ids) > 10 ** 6
+
+
+def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
+    """The scan kernels keep posting windows in flight in accumulation registers
+    that only their inline asm names (nxs_gpu.hip: bset_*/bpair_*).  That is only
+    sound while the compiler allocates no AGPR of its own in those kernels --
+    under register pressure it would spill VGPRs into them.  The code object's
+    metadata must show exactly the owned registers: 2 per window in flight."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("llvm binutils not present")
+    src = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu.hip")).read()
+    ring8 = int(re.search(r"#define\s+SCAN8_RING_MAX\s+(\d+)", src).group(1))
+    ringm = int(re.search(r"#define\s+SCANM_RING\s+(\d+)", src).group(1))
+    so = shutil.copy(N.LIB_PATH, str(tmp_path / "lib.so"))
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", so], check=True, capture_output=True)
+    co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert len(co) == 1, co
+    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", str(tmp_path / co[0])],
+                           check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for m in re.finditer(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count:).)*?\.name:\s+(\S+)", notes, re.S):
+        agpr, name = int(m.group(1)), m.group(2)
+        k8 = re.match(r"_Z7k_scan8ILi\d+ELi(\d+)ELi(\d+)EE", name)
+        kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)EE", name)
+        km = re.match(r"_Z7k_scanmILi(\d+)EE", name)
+        if k8:
+            nt, mm = int(k8.group(1)), int(k8.group(2))
+            want = 2 * ring8 * nt if (nt >= 3 and mm != 2) else 0
+        elif kr:
+            want = 2 * int(kr.group(1))
+        elif km:
+            want = 2 * ringm * int(km.group(1))
+        else:
+            continue
+        seen += 1
+        assert agpr == want, (name, agpr, want)
+    assert seen >= 20, seen

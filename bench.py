@@ -189,9 +189,11 @@ def main():
         + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / max(prof["launches"], 1)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    # one scan launch per query class and step: k_scan8<0,5,1> (pure OR) and
-    # k_scanr<0,5> (required terms) on C3; kernel_ms is their sum per step
-    roofline = {"bound": "hbm", "kernel": "k_scan8+k_scanr", "achieved": round(achieved, 1),
+    # one scan launch per query class and step; on C3: k_scanm<5> (pure OR of
+    # sparse terms), k_scan8<0,5,1> (pure OR with a dense term) and k_scanr<0,5>
+    # (required terms); kernel_ms is their sum per step (HIP events on the
+    # library's stream)
+    roofline = {"bound": "hbm", "kernel": "k_scanm+k_scan8+k_scanr", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(args, world),
@@ -230,11 +232,11 @@ def main():
 
 
 def pmc_traffic(args, world):
-    """HBM bytes per k_scan8 launch from the committed rocprofv3 --pmc passes
-    (profiles/r1_final_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
+    """HBM bytes per step (all scan launches) from the committed rocprofv3 --pmc
+    passes (profiles/r1_s2_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
     valid only for the workload they were collected on; else None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r1_s2_pmc_summary.json")) as f:
             p = json.load(f)
         w = p["workload"]
         if (w["docs"], w["terms"], w["batch"], w["limit"]) == \

@@ -16,6 +16,9 @@
  *                   boolean filter, candidate pre-selection; replaces
  *                   run_query_logic + get_expr_bitmap (search.c:118-278) and
  *                   nxs_resp_addresult (results.c:128-150).
+ *  k_scanm          pure-OR queries of sparse terms: a quantised score bound per
+ *                   doc in LDS (integer DS atomics), exact f32 sums only for the
+ *                   docs that can beat the threshold, from the register windows.
  *  k_replay         exact replay of the reference's capped min-heap + heapsort
  *                   (src/algo/heap.c:58-221; results.c:165-220) over the
  *                   candidates in descending doc order: bit-exact top-k order
@@ -1656,26 +1659,22 @@ k_scan8(const scan_args_t A)
  * of rank 100..1000 has 5-50 postings per such tile: most lanes of a visit are
  * idle and a 64-posting window is visited in 2-14 tiles (measured: 0.7-1.2 TB/s
  * on all-sparse queries against 6.2 TB/s on all-dense ones).  But once a
- * candidate threshold exists, almost no doc of a sparse OR needs its sum:
- *   - a doc holding ONE term scores that posting's impact: compared with the
- *     threshold in registers while the window is visited, nothing is stored;
- *   - a doc holding the term set S scores at most sum_{t in S} max_t (f32 sum
- *     in token order of the terms' largest impacts: rounding is monotone, so
- *     this bounds the reference's left-to-right sum); the 2^NT answers
- *     "|S| >= 2 and bound(S) > thr" are a truth table the wavefront recomputes
- *     whenever thr moves.
- * So LDS holds one presence-mask BYTE per doc (a tile is 4x wider for the same
- * LDS), a visit is one fire-and-forget ds_or_rtn_b32 per window (integer DS
- * atomics run at full rate -- tools/lds_probe.hip -- unlike ds_add_f32), and
- * the returned old byte tells the visit of a doc's LAST term which set the doc
- * holds.  Docs that pass either test go to a pending list; after the tile they
- * are sorted (descending doc), deduplicated and scored EXACTLY: one lane per
- * doc, a binary search of the doc in every term's slice, impacts added in
- * token order from 0.0f (what the accumulator tile does).  They then take the
- * common threshold filter; everything emitted carries its exact score, in
- * descending doc order, and every doc whose score beats the heap root at its
- * turn is emitted (both tests are necessary conditions for that), so k_replay
- * sees a superset in the right order exactly as with the other scan kernels.
+ * candidate threshold exists, almost no doc of a sparse OR needs its sum.
+ *
+ * LDS holds one BYTE per doc (a tile is 4x wider for the same LDS): a
+ * quantised upper bound of the doc's score so far.  A visit is one
+ * fire-and-forget ds_add_rtn_u32 per window (integer DS atomics run at full
+ * rate -- tools/lds_probe.hip -- unlike ds_add_f32); the old byte it returns
+ * plus the posting's own quantised impact, compared with the quantised
+ * threshold, is a necessary condition for "score > thr" (see `Quantisation`
+ * below), for docs holding one term as for docs holding several.  Docs that
+ * pass go to a pending list; after the tile they are sorted (descending doc),
+ * deduplicated and scored EXACTLY from the register windows (see `flush`):
+ * impacts added in token order from 0.0f, what the accumulator tile does.
+ * They then take the common threshold filter; everything emitted carries its
+ * exact score, in descending doc order, and every doc whose score beats the
+ * heap root at its turn is emitted, so k_replay sees a superset in the right
+ * order exactly as with the other scan kernels.
  *
  * Cold start: with thr = -inf every posting passes.  The tile width adapts: it
  * starts at 64 docs and doubles while a tile yields few candidates (halves

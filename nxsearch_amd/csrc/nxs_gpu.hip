@@ -3180,15 +3180,35 @@ fz_distance(const fz_args_t &A, uint32_t tok, const nxsgpu_bknode_t &nd, uint64_
 		const uint64_t *peq = A.peq + (uint64_t)tok * 256;
 		nxs_myers_t s;
 		nxs_myers_init(&s, m);
+		/*
+		 * Eight term bytes at a time: their Peq words are eight independent
+		 * gathers issued together (one L2 round trip), then the dependent
+		 * bit-vector steps.  Fetched inside the step loop they cost one round
+		 * trip per byte -- the kernel was bound by exactly that latency.  Bytes
+		 * past the term's end index a valid table row and are not stepped.
+		 */
 		uint64_t w;
 		memcpy(&w, nd.inl, 8);
-		const uint32_t n0 = min(n, 8u);
-		for (uint32_t i = 0; i < n0; i++) {
-			nxs_myers_step(&s, peq[(w >> (8 * i)) & 0xff]);
-		}
 		const uint8_t *rest = A.bk_bytes + nd.str_off;
-		for (uint32_t i = 8; i < n; i++) {
-			nxs_myers_step(&s, peq[rest[i]]);
+		for (uint32_t i0 = 0; i0 < n; i0 += 8) {
+			uint64_t e[8];
+			if (i0) {
+				/* (the byte pool carries 16 bytes of slack behind its end) */
+				uint32_t lo32, hi32;
+				__builtin_memcpy(&lo32, rest + i0, 4);
+				__builtin_memcpy(&hi32, rest + i0 + 4, 4);
+				w = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+			}
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				e[i] = peq[(w >> (8 * i)) & 0xff];
+			}
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				if (i0 + i < n) {
+					nxs_myers_step(&s, e[i]);
+				}
+			}
 		}
 		return s.score;
 	}
@@ -3228,7 +3248,8 @@ template <bool LONG>
 __global__ void
 k_bk_level(const fz_args_t A)
 {
-	const unsigned lane = threadIdx.x & 63;
+	__shared__ uint32_t s_wtot[16], s_base;
+	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	const uint32_t count = min(*A.cur_count, A.cap);
 	const uint32_t nthreads = gridDim.x * blockDim.x;
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3273,14 +3294,27 @@ k_bk_level(const fz_args_t A)
 			if (lane >= (unsigned)o) incl += v;
 		}
 		const uint32_t total = __shfl((int)incl, WAVE - 1);
-		if (total == 0) {
-			continue;
+		/*
+		 * One returning atomic per WORKGROUP and round, not per wavefront: a
+		 * single counter word takes ~88 M atomics/s (MI355X_MICROARCH.md,
+		 * `dequeue`), and with one per 64 candidates that ceiling -- not memory,
+		 * not the DP -- was the 5.4 G candidates/s this kernel ran at.  `rounds`
+		 * is uniform over the grid, so every wavefront reaches the barriers.
+		 */
+		s_wtot[wid] = total;		/* (all lanes write the same value) */
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t sum = 0;
+			for (unsigned w = 0; w < nw; w++) {
+				const uint32_t tw = s_wtot[w];
+				s_wtot[w] = sum;
+				sum += tw;
+			}
+			s_base = sum ? atomicAdd(A.next_count, sum) : 0;
 		}
-		uint32_t wbase = 0;
-		if (lane == WAVE - 1) {
-			wbase = atomicAdd(A.next_count, total);
-		}
-		wbase = __shfl((int)wbase, WAVE - 1);
+		__syncthreads();
+		const uint32_t wbase = s_base + s_wtot[wid];
+		__syncthreads();		/* s_wtot is rewritten next round */
 		uint32_t o = wbase + incl - nkids;
 		/* ascending slot order = the order bktree_search pushes children */
 		while (bm) {
@@ -4828,7 +4862,7 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			fa.next = (lvl & 1) ? qa : qb;
 			fa.cur_count = counts + lvl;
 			fa.next_count = counts + lvl + 1;
-			hipLaunchKernelGGL(k_bk_level<false>, dim3(2048), dim3(256), 0, ix->stream, fa);
+			hipLaunchKernelGGL(k_bk_level<false>, dim3(512), dim3(1024), 0, ix->stream, fa);
 			if (any_long) {
 				/* tokens longer than 64 bytes: row DP, bounded scratch */
 				hipLaunchKernelGGL(k_bk_level<true>, dim3(LONG_THREADS / 64), dim3(64), 0, ix->stream, fa);

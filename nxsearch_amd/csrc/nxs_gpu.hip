@@ -4788,12 +4788,19 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			any_long = true;
 		}
 	}
-	/* worst case one token visits every node: size chunks so the frontier
-	 * queues can never overflow */
-	chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tok, budget / n_bk));
+	/*
+	 * Worst case one token visits every node: with `safe_chunk` tokens per pass
+	 * the frontier queues can never overflow.  A d <= 2 search visits ~10 % of a
+	 * large tree, though, so the whole batch is tried in ONE pass first (29
+	 * level launches instead of 29 per chunk, and fuller levels); a pass that
+	 * does overflow the queues is repeated with a quarter of the tokens, down to
+	 * the safe size.
+	 */
+	const uint32_t safe_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tok, budget / n_bk));
+	chunk = getenv("NXS_GPU_FUZZY_SAFE") ? safe_chunk : n_tok;
 
 	const uint32_t LONG_THREADS = 64 * 64;
-	const uint64_t cap = (uint64_t)chunk * n_bk;
+	const uint64_t cap = std::max<uint64_t>((uint64_t)safe_chunk * n_bk, std::min<uint64_t>(budget, (uint64_t)chunk * n_bk));
 	const size_t levels = (size_t)ix->bk_depth + 2;
 	size_t need = 4096 + cap * sizeof(fz_item_t) * 2 + levels * 4 + 256
 	    + (size_t)chunk * (256 * 8 + 4 + 8 + 4) + tok_off[n_tok] + 16 + ((size_t)chunk + 1) * 4
@@ -4811,7 +4818,7 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 		ix->fz_len = need;
 	}
 
-	for (uint32_t c0 = 0; c0 < n_tok; c0 += chunk) {
+	for (uint32_t c0 = 0; c0 < n_tok; ) {
 		const uint32_t nc = std::min(chunk, n_tok - c0);
 		const uint32_t boff = tok_off[c0], blen = tok_off[c0 + nc] - boff;
 		std::vector<uint32_t> roff(nc + 1);
@@ -4884,18 +4891,25 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
 			return -1;
 		}
-		if (h_ovf) {
-			set_error("fuzzy frontier overflow (internal error)");
-			return -1;
-		}
 		if (ix->profiling) {
 			float ms = 0;
 			(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
-			ix->prof.fuzzy_ms += ms;
+			ix->prof.fuzzy_ms += ms;		/* a repeated pass is time spent too */
+		}
+		if (h_ovf) {
+			if (chunk <= safe_chunk) {
+				set_error("fuzzy frontier overflow (internal error)");
+				return -1;
+			}
+			chunk = std::max(safe_chunk, chunk / 4);
+			continue;		/* same tokens again, fewer at a time */
+		}
+		if (ix->profiling) {
 			for (size_t l = 0; l < levels; l++) {
 				ix->prof.fuzzy_visits += h_counts[l];
 			}
 		}
+		c0 += nc;
 	}
 	return 0;
 }

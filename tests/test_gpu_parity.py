@@ -263,6 +263,14 @@ def test_fuzzy_matches_oracle(nxs, tmp_path, seed, n_terms, alphabet):
     for tok, g, v in zip(toks, got, vis):
         want, wv = oidx.fuzzy(tok)
         assert (g, v) == (want, wv), tok
+    # frontier queues far too small for the whole batch: the one-pass attempt
+    # overflows and is repeated with fewer tokens at a time, same answers
+    os.environ["NXS_GPU_FUZZY_ITEMS"] = str(3 * n_terms)
+    try:
+        got2, vis2 = gidx.fuzzy(toks, want_visited=True)
+    finally:
+        del os.environ["NXS_GPU_FUZZY_ITEMS"]
+    assert (got2, vis2) == (got, vis)
     gidx.close()
 
 

@@ -1723,6 +1723,7 @@ k_scanm(const scan_args_t A)
 
 	const unsigned lane = threadIdx.x;
 	const unsigned long long clk0 = STAT_CLK();
+	(void)clk0;
 	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
@@ -3973,7 +3974,13 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL)
 {
 	bool forked = false;
+	const launch_t *last_launch = NULL;
 
+	for (const launch_t &l : wl.launches) {
+		if (l.count) {
+			last_launch = &l;
+		}
+	}
 	for (const launch_t &l : wl.launches) {
 		scan_args_t a = a0;
 		const dim3 grid(l.count), block(WAVE);
@@ -4033,10 +4040,20 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 		if (ra && l.q_count) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
-			(void)hipEventRecord(ix->ev_cls, ix->stream);
-			(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
-			hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream2, r);
-			forked = true;
+			if (&l == last_launch) {
+				/* nothing left to run beside it: same stream, no event
+				 * round trip (a single query has only this one) */
+				if (scans_done) {
+					(void)hipEventRecord(scans_done, ix->stream);
+					scans_done = NULL;
+				}
+				hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream, r);
+			} else {
+				(void)hipEventRecord(ix->ev_cls, ix->stream);
+				(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
+				hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream2, r);
+				forked = true;
+			}
 		}
 	}
 	if (scans_done) {
@@ -4179,29 +4196,45 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			return -1;
 		}
 	}
+	/*
+	 * Everything the kernels read from the host is one contiguous block, staged
+	 * in pinned memory and uploaded by ONE copy (the two zero-filled arrays
+	 * included); the flags and the results are one block and ONE copy back.  A
+	 * single query used to pay eleven small pageable copies + two memsets:
+	 * most of its latency.
+	 */
 	p = (uint8_t *)ix->ws;
+	uint8_t *const up0 = p;
 	d_q = carve<dev_query_t>(p, nq);
 	d_qmeta = carve<qmeta_t>(p, nq);
 	d_items = carve<item_t>(p, nseg);
-	d_seg_count = carve<uint32_t>(p, nseg);
-	d_ovf = carve<uint32_t>(p, nq);
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
-	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
-	float *d_pub = carve<float>(p, nseg);
 	uint32_t *d_qorder = carve<uint32_t>(p, nq);
-	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
-	d_cand_sc = carve<float>(p, nseg * seg_cap);
+	float *d_pub = carve<float>(p, nseg);
+	d_ovf = carve<uint32_t>(p, nq);
+	const size_t up_len = (size_t)(p - up0);
+	uint8_t *const down0 = (uint8_t *)d_ovf;
 	d_ids = carve<uint64_t>(p, (size_t)nq * kfast);
 	d_sc = carve<float>(p, (size_t)nq * kfast);
 	d_cnt = carve<uint32_t>(p, nq);
+	const size_t down_len = (size_t)(p - down0);
+	d_seg_count = carve<uint32_t>(p, nseg);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
+	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
+	d_cand_sc = carve<float>(p, nseg * seg_cap);
 
-	if (hipMemcpyAsync(d_q, hq.data(), nq * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemcpyAsync(d_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemcpyAsync(d_items, wl.items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemcpyAsync(d_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemcpyAsync(d_qorder, wl.qorder.data(), nq * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess ||
-	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream) != hipSuccess) {
+	if (!ensure_pin(ix, up_len + down_len + 512)) {
+		return -1;
+	}
+	uint8_t *const h_up = (uint8_t *)ix->h_pin;
+	uint8_t *const h_down = (uint8_t *)(((uintptr_t)h_up + up_len + 255) & ~(uintptr_t)255);
+	memset(h_up, 0, up_len);
+	memcpy(h_up + ((uint8_t *)d_q - up0), hq.data(), nq * sizeof(dev_query_t));
+	memcpy(h_up + ((uint8_t *)d_qmeta - up0), wl.qmeta.data(), nq * sizeof(qmeta_t));
+	memcpy(h_up + ((uint8_t *)d_items - up0), wl.items.data(), nseg * sizeof(item_t));
+	memcpy(h_up + ((uint8_t *)d_bnd_q - up0), wl.bnd_q.data(), (nseg + nq) * 4);
+	memcpy(h_up + ((uint8_t *)d_qorder - up0), wl.qorder.data(), nq * 4);
+	if (hipMemcpyAsync(up0, h_up, up_len, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
 	}
@@ -4252,12 +4285,16 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			set_error("kernel launch failed");
 			return -1;
 		}
-		if (hipMemcpyAsync(h_ovf.data(), d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
+		if (hipMemcpyAsync(h_down, down0, down_len, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
 			set_error("copy failed");
 			return -1;
 		}
 	} else {
 		std::fill(h_ovf.begin(), h_ovf.end(), 1u);
+	}
+	if (hipStreamSynchronize(ix->stream) != hipSuccess) {
+		set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
 	}
 
 	/* host copy of the fast results */
@@ -4267,16 +4304,10 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	if (fast) {
 		f_ids.resize((size_t)nq * kfast);
 		f_sc.resize((size_t)nq * kfast);
-		if (hipMemcpyAsync(f_ids.data(), d_ids, f_ids.size() * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(f_sc.data(), d_sc, f_sc.size() * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(h_cnt.data(), d_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
-			set_error("copy failed");
-			return -1;
-		}
-	}
-	if (hipStreamSynchronize(ix->stream) != hipSuccess) {
-		set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
-		return -1;
+		memcpy(h_ovf.data(), h_down + ((uint8_t *)d_ovf - down0), nq * 4);
+		memcpy(f_ids.data(), h_down + ((uint8_t *)d_ids - down0), f_ids.size() * 8);
+		memcpy(f_sc.data(), h_down + ((uint8_t *)d_sc - down0), f_sc.size() * 4);
+		memcpy(h_cnt.data(), h_down + ((uint8_t *)d_cnt - down0), nq * 4);
 	}
 	if (fast && ix->profiling) {
 		float a = 0, b = 0;

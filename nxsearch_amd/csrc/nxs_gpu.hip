@@ -479,42 +479,10 @@ static_for(F &&f)
  * a copy -- the wavefront stalled for a memory latency every 64 postings.  A
  * load it does not track (inline asm into a C variable) is not safe either:
  * the register allocator is free to move that variable with v_mov while the
- * data is still in flight.  The kernels use no AGPRs otherwise, so a0..a15
- * are out of the compiler's reach: nothing can be scheduled into, copied out
- * of, or reallocated over a pending prefetch.  bset_take() = wait (loads
- * return in order), read B into A, request the next window into B.
+ * data is still in flight.  The kernels use no AGPRs otherwise, so these
+ * registers are out of the compiler's reach: nothing can be scheduled into, copied out
+ * of, or reallocated over a pending prefetch (bpair_request / bpair_take below).
  */
-template <int T> __device__ __forceinline__ void bset_request(const posting_t *np);
-template <int T> __device__ __forceinline__ void bset_take(uint32_t &ad, float &ai, const posting_t *np);
-#define	NXS_BSET(T, RD, RI)								\
-template <> __device__ __forceinline__ void						\
-bset_request<T>(const posting_t *np)							\
-{											\
-	asm volatile(									\
-	    "global_load_dword " RD ", %0, off\n\t"					\
-	    "global_load_dword " RI ", %0, off offset:4"				\
-	    : : "v"(np) : "memory", RD, RI);						\
-}											\
-template <> __device__ __forceinline__ void						\
-bset_take<T>(uint32_t &ad, float &ai, const posting_t *np)				\
-{											\
-	asm volatile(									\
-	    "s_waitcnt vmcnt(0)\n\t"							\
-	    "v_accvgpr_read_b32 %0, " RD "\n\t"					\
-	    "v_accvgpr_read_b32 %1, " RI "\n\t"					\
-	    "global_load_dword " RD ", %2, off\n\t"					\
-	    "global_load_dword " RI ", %2, off offset:4"				\
-	    : "=&v"(ad), "=&v"(ai) : "v"(np) : "memory", RD, RI);			\
-}
-NXS_BSET(0, "a0", "a1")
-NXS_BSET(1, "a2", "a3")
-NXS_BSET(2, "a4", "a5")
-NXS_BSET(3, "a6", "a7")
-NXS_BSET(4, "a8", "a9")
-NXS_BSET(5, "a10", "a11")
-NXS_BSET(6, "a12", "a13")
-NXS_BSET(7, "a14", "a15")
-#undef NXS_BSET
 
 /*
  * Prefetch RING of the tile path: R windows per term in flight instead of one.
@@ -1047,6 +1015,9 @@ k_scan(const scan_args_t A)
 #ifndef SCAN8_RING_MAX
 #define	SCAN8_RING_MAX	2		/* prefetch ring depth of the one-window tile path */
 #endif
+#ifndef SCANR_RING
+#define	SCANR_RING	1		/* prefetch ring depth of the required-term path (1, 2, 4 measured equal) */
+#endif
 #ifndef SCANM_RING
 #define	SCANM_RING	2		/* prefetch ring depth of the mask path */
 #endif
@@ -1117,7 +1088,7 @@ k_scan8(const scan_args_t A)
 	uint32_t Ad[NT][K], Bd[NT][K];
 	float Ai[NT][K], Bi[NT][K];
 	/* AP (one window per set): set B is the hidden prefetch register pair of
-	 * bset_request()/bset_take(); Bd/Bi are unused then */
+	 * bpair_request()/bpair_take(); Bd/Bi are unused then */
 	constexpr bool AP = K == 1 && !ANDM;
 	/* AP: windows in flight per term below set A, and the ring position of the
 	 * oldest (bring_take) */
@@ -2337,7 +2308,13 @@ k_scanr(const scan_args_t A)
 	int32_t ab[NT], lo[NT], pdoc[NT];
 	uint32_t tok[NT];
 	uint64_t vm[NT];
-	uint32_t Ad[NT];		/* set B: bset_request()/bset_take() */
+	constexpr int RING = SCANR_RING;
+	uint32_t rp[NT];		/* ring position of the oldest window in flight */
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		rp[t] = 0;
+	}
+	uint32_t Ad[NT];		/* set A; the windows in flight live in AGPRs (bpair_*) */
 	float Ai[NT];
 
 	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
@@ -2363,18 +2340,27 @@ k_scanr(const scan_args_t A)
 			const int32_t ib = max(ab[t] - WAVE + (int32_t)lane, lo[t]);
 			const posting_t pa = pt[t][min(ia, hi_ - 1)];
 			Ad[t] = pa.doc; Ai[t] = pa.imp;
-			bset_request<t>(&pt[t][min(ib, hi_ - 1)]);
+			(void)ib;
+			/* the RING windows below set A, oldest first (bring_take) */
+			static_for<RING>([&](auto rc) {
+				constexpr int r = decltype(rc)::value;
+				const int32_t ir = max(ab[t] - (r + 1) * WAVE + (int32_t)lane, lo[t]);
+				bpair_request<t * RING + r>(&pt[t][min(ir, hi_ - 1)]);
+			});
+			rp[t] = 0;
 			vm[t] = window_mask(ab[t], lo[t], hi_);
 			refresh_pdoc(tc);
 		}
 	};
-	/* set A is drained: wait for B, take it over, request the window below */
+	/* set A is drained: wait for the oldest window in flight, take it over,
+	 * request the window RING below it */
 	auto rotate_sets = [&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		ab[t] -= WAVE;
 		vm[t] = window_mask(ab[t], lo[t], 0x7fffffff);
-		const posting_t *np = &pt[t][max(ab[t] - WAVE + (int32_t)lane, lo[t])];
-		bset_take<t>(Ad[t], Ai[t], np);
+		const posting_t *np = &pt[t][max(ab[t] - RING * WAVE + (int32_t)lane, lo[t])];
+		bring_take<t, RING>(rp[t], RING - 1, Ad[t], Ai[t], np);
+		rp[t] = (rp[t] + 1) & (RING - 1);
 	};
 
 	static_for<NT>([&](auto tc) {

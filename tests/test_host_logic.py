@@ -234,6 +234,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
     src = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu.hip")).read()
     ring8 = int(re.search(r"#define\s+SCAN8_RING_MAX\s+(\d+)", src).group(1))
     ringm = int(re.search(r"#define\s+SCANM_RING\s+(\d+)", src).group(1))
+    ringr = int(re.search(r"#define\s+SCANR_RING\s+(\d+)", src).group(1))
     so = shutil.copy(N.LIB_PATH, str(tmp_path / "lib.so"))
     subprocess.run([llvm + "/llvm-objdump", "--offloading", so], check=True, capture_output=True)
     co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
@@ -250,7 +251,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
             nt, mm = int(k8.group(1)), int(k8.group(2))
             want = 2 * ring8 * nt if (nt >= 3 and mm != 2) else 0
         elif kr:
-            want = 2 * int(kr.group(1))
+            want = 2 * ringr * int(kr.group(1))
         elif km:
             want = 2 * ringm * int(km.group(1))
         else:

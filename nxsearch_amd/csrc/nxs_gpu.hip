@@ -3939,11 +3939,13 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 }
 
 static void
-launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd)
+launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd,
+    hipStream_t stream = NULL)
 {
 	const uint64_t threads = (uint64_t)n_bnd * NXSGPU_MAX_TOKENS;
 	if (n_bnd) {
-		hipLaunchKernelGGL(k_cursors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
+		hipLaunchKernelGGL(k_cursors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+		    stream ? stream : ix->stream,
 		    a.post, a.queries, a.qmeta, d_bnd_q, n_bnd, a.n_docs, (uint32_t *)a.cursors);
 	}
 }
@@ -4639,10 +4641,8 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
 
 	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, ix->stream_up) != hipSuccess ||
-	    hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
-	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess ||
-	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream) != hipSuccess ||
-	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream) != hipSuccess) {
+	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream_up) != hipSuccess ||
+	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream_up) != hipSuccess) {
 		set_error("query upload failed");
 		return -1;
 	}
@@ -4676,8 +4676,18 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	ra.out_count = d_counts;
 	ra.skip = d_ovf;
 
+	/*
+	 * The range cursors depend on the uploaded plans only: k_cursors (a small,
+	 * latency-bound grid of binary searches) runs on the upload stream, beside
+	 * the previous batch's scans instead of in front of this batch's.
+	 */
+	launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), ix->stream_up);
+	if (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
+	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess) {
+		set_error("query upload failed");
+		return -1;
+	}
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
-	launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
 	if (getenv("NXS_GPU_ONEREPLAY")) {
 		launch_scan<MODE_TOPK>(ix, sa, wl);
 		if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);

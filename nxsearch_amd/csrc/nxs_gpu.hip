@@ -1656,6 +1656,11 @@ k_scan8(const scan_args_t A)
 #define	MT_W		8192		/* max docs per mask tile (1 byte each) */
 #endif
 #define	MT_W0		64		/* cold-start tile width */
+#ifndef MT_W_HINTED
+#define	MT_W_HINTED	2048		/* first tile width when a higher range has published a threshold
+					 * (1024 / 2048 / 8192 measured equal; a weak hint then costs two
+					 * small tiles, not a pending-list overflow) */
+#endif
 #define	PEND_CAP	128
 #define	PEND_FLUSH	32		/* score the pending docs once this many wait */
 #define	QSUM_MAX	224		/* quantised score bound of a doc holding every term at its largest impact */
@@ -1984,7 +1989,7 @@ k_scanm(const scan_args_t A)
 	};
 
 	/* widest tile tried next: small while nothing is known about the threshold */
-	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W : (uint32_t)MT_W0;
+	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
 
 	uint32_t ovf_u = 0;		/* `ovf` as the loop carries it */
 	for (;;) {

@@ -110,7 +110,6 @@ struct dev_query_t {
 	uint32_t	n_req;		/* k_scanr: slots [0, n_req) are the required tokens ... */
 	uint8_t		slot_tok[8];	/* ... slot -> token, ascending list length within each group */
 	float		tmax[8];	/* k_scanm: largest impact of tokens 0..7 */
-	uint32_t	dmask;		/* k_scanm: dense (non-essential) tokens */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
@@ -1654,13 +1653,7 @@ k_scan8(const scan_args_t A)
  * flags the query for the exact two-pass path.
  */
 #ifndef MT_W
-#define	MT_W		6144		/* max docs per mask tile (1 byte each) */
-#endif
-#define	REC_CAP		64		/* essential mode: docs waiting for their non-essential terms */
-#define	REC_FLUSH	32
-#ifndef ESS_RATIO_NUM
-#define	ESS_RATIO_NUM	3		/* essential mode if qD <= NUM/DEN of the quantised threshold */
-#define	ESS_RATIO_DEN	10
+#define	MT_W		8192		/* max docs per mask tile (1 byte each) */
 #endif
 #define	MT_W0		64		/* cold-start tile width */
 #ifndef MT_W_HINTED
@@ -1703,8 +1696,6 @@ k_scanm(const scan_args_t A)
 	constexpr int RING = SCANM_RING;
 	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MT_W / 4 + WAVE];	/* + one dummy word per lane */
 	__shared__ uint32_t s_pend[PEND_CAP];
-	__shared__ uint32_t s_rdoc[REC_CAP];		/* essential mode records: doc ... */
-	__shared__ float s_rimp[NT][REC_CAP];		/* ... and its impact in every essential term (0 = absent) */
 
 	const unsigned lane = threadIdx.x;
 	const unsigned long long clk0 = STAT_CLK();
@@ -1854,36 +1845,6 @@ k_scanm(const scan_args_t A)
 	};
 	int32_t thr_q = thr_quant(thr);
 
-	/*
-	 * Non-essential terms (MaxScore).  The host marks the dense terms of the
-	 * query (dmask); their impacts are small (low idf).  Once the threshold is
-	 * at least boundD = the f32 token-order sum of their largest impacts, a doc
-	 * that holds none of the other ("essential") terms cannot beat it -- the
-	 * reference's heap drops such a doc without touching its state -- so the
-	 * wavefront stops streaming the dense lists altogether ("essential mode"):
-	 * only the essential terms are added to the byte map, against a threshold
-	 * lowered by the dense terms' quantised maxima; a doc that passes gets its
-	 * essential impacts from the register windows right away and its dense
-	 * impacts later, by binary search, together with up to REC_CAP other docs.
-	 */
-	const uint32_t dmask = Q->dmask & ((1u << NT) - 1);
-	float boundD = 0.0f;
-	int32_t qD = 0;
-#pragma unroll
-	for (int t = 0; t < NT; t++) {
-		if ((dmask >> t) & 1) {
-			boundD += tmx[t];
-			qD += (int32_t)(tmx[t] * qs) + 2;
-		}
-	}
-	qD = __builtin_amdgcn_readfirstlane(qD);
-	uint32_t ess = 0, n_rec = 0;
-	int32_t dhi[NT];		/* essential mode: a dense term's postings still of interest end here */
-#pragma unroll
-	for (int t = 0; t < NT; t++) {
-		dhi[t] = hi[t];
-	}
-
 	uint32_t n_pend = 0;
 	auto push = [&](uint64_t m, uint32_t doc) {
 		const uint32_t n = __popcll(m);
@@ -1900,104 +1861,6 @@ k_scanm(const scan_args_t A)
 	};
 	auto rfl64 = [&](uint64_t v) -> uint64_t {
 		return (uint64_t)rfl32((uint32_t)v) | ((uint64_t)rfl32((uint32_t)(v >> 32)) << 32);
-	};
-	/*
-	 * Common tail: lanes hold docs in descending order with their exact
-	 * scores; what beats the threshold goes to the segment and into the
-	 * wavefront's running top-k.
-	 */
-	auto emit = [&](uint32_t d, float sc, bool live) {
-		const bool cand = live && sc > thr;
-		uint64_t bal = ballot64(cand);
-		if (bal) {
-			const uint32_t ne = __popcll(bal);
-			/*
-			 * (Shape matters to the compiler's uniformity analysis: every phi at
-			 * the join of a lane-dependent branch counts as divergent, so such a
-			 * branch must not share its join with an assignment to wave-uniform
-			 * state -- else `ovf`, and through the loop exit everything the main
-			 * loop carries, ends up in VGPRs.)
-			 */
-			const bool room = n_out + ne <= A.seg_cap;
-			if (!room) {
-				ovf = true;
-			}
-			if (room && cand) {
-				/* lanes are in descending doc order */
-				const uint64_t o = out_base + n_out + lanes_below(bal);
-				A.cand_doc[o] = d;
-				A.cand_sc[o] = sc;
-			}
-			n_out += ne;
-			while (bal) {
-				const int L = __builtin_ctzll(bal);
-				const float v = __shfl(sc, L);
-				/* branch-free insert into the sorted top-k register */
-				const bool ins = v > thr;
-				const uint32_t pos = __popcll(ballot64(top >= v));
-				const float up = __shfl_up(top, 1);
-				const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
-				top = ins ? ntop : top;
-				thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
-				bal &= bal - 1;
-			}
-		}
-	};
-	/*
-	 * Essential mode, second stage: the recorded docs (descending) get their
-	 * dense-term impacts by a branch-free lower bound in global memory, all
-	 * dense terms in flight together; then the token-order sum (absent terms
-	 * add 0.0f, which changes nothing) and the common tail.
-	 */
-	auto stage2 = [&]() {
-		n_rec = rfl32(n_rec);
-		n_out = rfl32(n_out);
-		STAT_ADD(12, 1);
-		uint32_t max_len = 1;
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
-			if ((dmask >> t) & 1) {
-				max_len = max(max_len, (uint32_t)max(dhi[t] - lo[t], 0));
-			}
-		}
-		const uint32_t span = max_len <= 1 ? 1u : 1u << (32 - __builtin_clz(max_len - 1));
-		WAVE_SYNC();
-		const bool live = lane < n_rec;
-		const uint32_t d = live ? s_rdoc[lane] : 0;
-		int32_t bl[NT];
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
-			bl[t] = lo[t];
-		}
-		for (uint32_t step = span; step >= 1; step >>= 1) {
-#pragma unroll
-			for (int t = 0; t < NT; t++) {
-				if (((dmask >> t) & 1) && dhi[t] > lo[t]) {
-					const int32_t probe = bl[t] + (int32_t)step - 1;
-					const uint32_t v = pt[t][min(probe, dhi[t] - 1)].doc;
-					if (probe < dhi[t] && v < d) {
-						bl[t] = probe + 1;
-					}
-				}
-			}
-		}
-		float sc = 0.0f;
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
-			if ((dmask >> t) & 1) {
-				if (dhi[t] > lo[t]) {
-					const posting_t p = pt[t][min(bl[t], dhi[t] - 1)];
-					if (bl[t] < dhi[t] && p.doc == d) {
-						sc += p.imp;
-					}
-				}
-			} else {
-				sc += live ? s_rimp[t][lane] : 0.0f;
-			}
-		}
-		emit(d, sc, live);
-		WAVE_SYNC();
-		n_rec = 0;
 	};
 	/*
 	 * Flush (after every tile that pushed something): sort the pending docs
@@ -2064,58 +1927,65 @@ k_scanm(const scan_args_t A)
 				const int j = __builtin_ctzll(todo);
 				todo &= todo - 1;
 				const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, j);
-				float acc = 0.0f;	/* score, or its bound with the dense terms at their maxima */
-				float imp[NT];
+				float acc = 0.0f;
 				static_for<NT>([&](auto tc) {
 					constexpr int t = decltype(tc)::value;
-					imp[t] = 0.0f;
-					if (ess && ((dmask >> t) & 1)) {
-						acc += tmx[t];
-					} else if (hi[t] > lo[t]) {
+					if (hi[t] > lo[t]) {
 						const uint64_t ma = ballot64(Ad[t] == dj);
 						if (ma) {
-							imp[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+							acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
 							    __builtin_bit_cast(int, Ai[t]), __builtin_ctzll(ma)));
 						} else {
 							const uint64_t mp = ballot64(Nd[t] == dj);
 							if (mp) {
-								imp[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+								acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
 								    __builtin_bit_cast(int, Ni[t]), __builtin_ctzll(mp)));
 							}
 						}
-						acc += imp[t];		/* + 0.0f changes nothing */
 					}
 				});
-				if (ess) {
-					/* keep the doc if it can still beat the threshold */
-					const bool keep = __builtin_amdgcn_readfirstlane((int)(acc > thr)) != 0;
-					if (keep) {
-						if (n_rec == REC_CAP) {
-							stage2();
-						}
-						if (lane == 0) {
-							s_rdoc[n_rec] = dj;
-#pragma unroll
-							for (int t = 0; t < NT; t++) {
-								s_rimp[t][n_rec] = imp[t];
-							}
-						}
-						n_rec++;
-					}
-				} else {
-					sc = (lane == (unsigned)j) ? acc : sc;
-				}
+				sc = (lane == (unsigned)j) ? acc : sc;
 			}
-			if (!ess) {
-				emit(d, sc, live);
+			const bool cand = live && sc > thr;
+			uint64_t bal = ballot64(cand);
+			if (!bal) {
+				continue;
+			}
+			const uint32_t ne = __popcll(bal);
+			/*
+			 * (Shape matters to the compiler's uniformity analysis: every phi at
+			 * the join of a lane-dependent branch counts as divergent, so such a
+			 * branch must not share its join with an assignment to wave-uniform
+			 * state -- else `ovf`, and through the loop exit everything the main
+			 * loop carries, ends up in VGPRs.)
+			 */
+			const bool room = n_out + ne <= A.seg_cap;
+			if (!room) {
+				ovf = true;
+			}
+			if (room && cand) {
+				/* lanes are in descending doc order */
+				const uint64_t o = out_base + n_out + lanes_below(bal);
+				A.cand_doc[o] = d;
+				A.cand_sc[o] = sc;
+			}
+			n_out += ne;
+			while (bal) {
+				const int L = __builtin_ctzll(bal);
+				const float v = __shfl(sc, L);
+				/* branch-free insert into the sorted top-k register */
+				const bool ins = v > thr;
+				const uint32_t pos = __popcll(ballot64(top >= v));
+				const float up = __shfl_up(top, 1);
+				const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
+				top = ins ? ntop : top;
+				thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
+				bal &= bal - 1;
 			}
 		}
 		WAVE_SYNC();
-		n_pend = 0;
-		if (ess && n_rec >= REC_FLUSH) {
-			stage2();
-		}
 		thr_q = thr_quant(thr);
+		n_pend = 0;
 	};
 
 	/* widest tile tried next: small while nothing is known about the threshold */
@@ -2135,31 +2005,8 @@ k_scanm(const scan_args_t A)
 		thr_q = (int32_t)rfl32((uint32_t)thr_q);
 		ovf_u = rfl32(ovf_u | (ovf ? 1u : 0u));
 		ovf = ovf_u != 0;
-		ess = rfl32(ess);
-		n_rec = rfl32(n_rec);
-		/* worth it only while the dense terms' maxima are a small part of the
-		 * threshold: the lowered threshold lets more docs through to stage 2 */
-		if (!ess && dmask && qD * ESS_RATIO_DEN <= thr_q * ESS_RATIO_NUM &&
-		    rfl32(thr >= boundD && thr > 0.0f)) {
-			/* enter essential mode: the dense terms are dropped from the scan;
-			 * what is left of their lists ends with set A.  The tile width starts
-			 * over: the pass rate under the lowered threshold is not known yet */
-			ess = 1;
-			tw = MT_W0 * 4;
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				if ((dmask >> t) & 1) {
-					dhi[t] = min(hi[t], max(ab[t], lo[t]) + WAVE);
-					vmA[t] = vmN[t] = 0;
-					pdoc[t] = -1;
-					ldocN[t] = 0;
-				}
-			});
-		}
-		const int32_t thr_eff = ess ? thr_q - qD : thr_q;
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
-			dhi[t] = (int32_t)rfl32((uint32_t)dhi[t]);
 			ab[t] = (int32_t)rfl32((uint32_t)ab[t]);
 			pdoc[t] = (int32_t)rfl32((uint32_t)pdoc[t]);
 			ldocN[t] = (int32_t)rfl32((uint32_t)ldocN[t]);
@@ -2202,7 +2049,7 @@ k_scanm(const scan_args_t A)
 			if (vis[t]) {
 				/* qv = (q << 8) | shift: bound of the doc's score so far */
 				const uint32_t sum = ((oldv[t] >> (qv[t] & 31)) & 0xffu) + (qv[t] >> 8);
-				const uint64_t cm = vis[t] & ballot64((int32_t)sum > thr_eff);
+				const uint64_t cm = vis[t] & ballot64((int32_t)sum > thr_q);
 				if (cm) {
 					push(cm, vdoc[t]);
 				}
@@ -2270,23 +2117,18 @@ k_scanm(const scan_args_t A)
 		}
 		static_for<NT>([&](auto tc) {
 			constexpr int t = decltype(tc)::value;
-			if (!(ess && ((dmask >> t) & 1))) {
-				while (vmA[t] == 0 && ab[t] > lo[t]) {
-					shift(tc);
-				}
-				refresh_pdoc(tc);
+			while (vmA[t] == 0 && ab[t] > lo[t]) {
+				shift(tc);
 			}
+			refresh_pdoc(tc);
 		});
 		if (n_tile <= 8) {
 			tw = min(tw * 2, (uint32_t)MT_W);
-		} else if (n_tile > 32) {
+		} else if (n_tile > 48) {
 			tw = max(tw / 2, (uint32_t)MT_W0);
 		}
 	}
 
-	if (!ovf && ess && n_rec) {
-		stage2();
-	}
 	STAT_ADD(0, 1);
 	STAT_ADD(5, n_out);
 	STAT_ADD(7, STAT_CLK() - clk0);
@@ -3984,14 +3826,8 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
 			/* pure OR of 3..5 tokens whose lists are sparse: mask path (k_scanm).
 			 * Dense lists stream faster through the accumulator tiles. */
-			uint64_t wmax_ess = 0;		/* longest list among the essential tokens */
-			for (uint32_t t = 0; t < hq[i].nt; t++) {
-				if (!((hq[i].dmask >> t) & 1)) {
-					wmax_ess = std::max<uint64_t>(wmax_ess, hq[i].pend[t] - hq[i].pbeg[t]);
-				}
-			}
 			if (tile && or_only && use_scanm && hq[i].nt >= 3 && hq[i].nt <= 5 &&
-			    (double)wmax_ess <= scanm_dens * (double)ix->n_docs) {
+			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
 				cls[i] = 4u * 64 + 16 + nt_bucket(hq[i].nt);
 			}
 			/* required terms: intersect first (k_scanr).  Its work is set by
@@ -4272,21 +4108,6 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			total_post += d.pend[t] - d.pbeg[t];
 			if (t < 8 && tid < ix->h_maximp[algo].size()) {
 				d.tmax[t] = ix->h_maximp[algo][tid];
-			}
-		}
-		/* k_scanm: tokens dense enough to be treated as non-essential (MaxScore);
-		 * at least one token must stay essential */
-		d.dmask = 0;
-		if (d.nt >= 3 && d.nt <= 5) {
-			static const double ne_dens = getenv("NXS_GPU_NE_DENS") ? atof(getenv("NXS_GPU_NE_DENS")) : 0.03;
-			uint32_t dm = 0;
-			for (uint32_t t = 0; t < d.nt; t++) {
-				if ((double)(d.pend[t] - d.pbeg[t]) > ne_dens * (double)ix->n_docs) {
-					dm |= 1u << t;
-				}
-			}
-			if (dm != (1u << d.nt) - 1) {
-				d.dmask = dm;
 			}
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */

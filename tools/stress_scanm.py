@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""One-off stress of the mask path against the oracle: random pure-OR queries of
+3..5 terms over a synthetic Zipf corpus, several limits, both ranking functions,
+default routing and k_scanm forced for every density."""
+import os, sys, random, struct, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import nxsearch_amd as N
+import oracle_lib as O
+from nxsearch_amd import corpus
+docs, nterms = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000, 50_000
+work = "/dev/shm/nxs_stress"
+os.makedirs(work, exist_ok=True)
+c = corpus.write_corpus(work, docs, nterms, seed=77)
+terms = corpus.term_strings(nterms, seed=77)
+T = lambda r: terms[r - 1].decode()
+rng = random.Random(5)
+qs = []
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 400):
+    n = rng.randint(3, 5)
+    lo, hi = rng.choice([(1, 30), (1, 300), (20, 2000), (200, 20000), (1, 50000)])
+    qs.append(" OR ".join(T(r) for r in rng.sample(range(lo, hi + 1), n)))
+oidx = O.Index(c["terms"], c["dtmap"])
+bits = lambda x: struct.pack("<f", x)
+bad = 0
+t0 = time.time()
+want = {}
+for env in ({}, {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"}):
+    for kk, v in env.items():
+        os.environ[kk] = v
+    with N.Nxs(work) as nxs:
+        gidx = nxs.open_files(c["terms"], c["dtmap"])
+        for limit in (1, 10, 64):
+            for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+                got = gidx.search_batch(qs, limit=limit, algo=name, fuzzymatch=False)
+                for q, g in zip(qs, got):
+                    key = (q, limit, algo)
+                    if key not in want:
+                        want[key] = oidx.search(q, algo=algo, limit=limit, fuzzymatch=False)
+                    w = want[key]
+                    if [d for d, _ in g] != [d for d, _ in w] or [bits(s) for _, s in g] != [bits(s) for _, s in w]:
+                        bad += 1
+                        if bad <= 5:
+                            print("MISMATCH", env, q, limit, name, g[:3], w[:3], flush=True)
+                print("env %s limit %d %s done, %d mismatches so far, %.0f s" % (env, limit, name, bad, time.time() - t0), flush=True)
+        gidx.close()
+    for kk in env:
+        del os.environ[kk]
+print("TOTAL mismatches:", bad)
+sys.exit(1 if bad else 0)

@@ -25,7 +25,8 @@ bits = lambda x: struct.pack("<f", x)
 bad = 0
 t0 = time.time()
 want = {}
-for env in ({}, {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"}):
+for env in ({}, {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
+            {"NXS_GPU_NOSCANM": "1"}):
     for kk, v in env.items():
         os.environ[kk] = v
     with N.Nxs(work) as nxs:

@@ -3788,6 +3788,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	const uint32_t rmin = getenv("NXS_GPU_NOSCANR2") ? 3u : 2u;	/* else "a AND b" takes k_scan8's sign-bit path */
 	const bool by_level = !getenv("NXS_GPU_NOLEVELS");
 	const bool use_scanm = !getenv("NXS_GPU_NOSCANM") && ix->n_docs < (1ull << 31);
+	const uint32_t scanm_minnt = getenv("NXS_GPU_SCANM_MINNT") ? (uint32_t)atoi(getenv("NXS_GPU_SCANM_MINNT")) : 2;
 	const uint32_t scanm_maxnt = getenv("NXS_GPU_SCANM_MAXNT") ? (uint32_t)atoi(getenv("NXS_GPU_SCANM_MAXNT")) : 8;
 	/* k_scanm if the densest list holds at most this fraction of the docs */
 	const double scanm_dens = getenv("NXS_GPU_SCANM_DENS") ? atof(getenv("NXS_GPU_SCANM_DENS")) : 0.08;
@@ -3826,9 +3827,9 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 			}
 			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
-			/* pure OR of 3..8 tokens whose lists are sparse: mask path (k_scanm).
+			/* pure OR of 2..8 tokens whose lists are sparse: mask path (k_scanm).
 			 * Dense lists stream faster through the accumulator tiles. */
-			if (tile && or_only && use_scanm && hq[i].nt >= 3 && hq[i].nt <= scanm_maxnt &&
+			if (tile && or_only && use_scanm && hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt &&
 			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
 				cls[i] = 4u * 64 + 16 + nt_bucket(hq[i].nt);
 			}
@@ -4007,12 +4008,14 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			 * all) of these queries take the pure-OR accumulator tiles */
 			if (MODE == MODE_TOPK && a.k >= 1 && a.k <= WAVE) {
 				switch (l.nt_bucket) {
+				case 2:		/* two tokens: the third slot stays empty */
 				case 3: hipLaunchKernelGGL((k_scanm<3>), grid, block, 0, ix->stream, a); break;
 				case 5: hipLaunchKernelGGL((k_scanm<5>), grid, block, 0, ix->stream, a); break;
 				default: hipLaunchKernelGGL((k_scanm<8>), grid, block, 0, ix->stream, a); break;
 				}
 			} else {
 				switch (l.nt_bucket) {
+				case 2: hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); break;
 				case 3: hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); break;
 				case 5: hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); break;
 				default: hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); break;

@@ -371,7 +371,7 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
 ])
 def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len):
     """k_scanm (quantised score bounds in a byte per doc + exact scores from the
-    register windows) forced for every pure-OR query of 3..8 tokens, whatever
+    register windows) forced for every pure-OR query of 2..8 tokens, whatever
     the density of its terms: identical ids, order and score bits."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
     rng = random.Random(seed)
@@ -382,7 +382,7 @@ def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, voc
     gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
     queries = []
     for _ in range(40):
-        n = rng.randint(3, 8)          # k_scanm<3>, <5> and <8>
+        n = rng.randint(2, 8)          # k_scanm<3> (also for two tokens), <5> and <8>
         hi = rng.choice([min(vocab_n, 12), vocab_n // 2, vocab_n])
         queries.append(" OR ".join(rng.sample(vocab[:max(hi, n)], n)))
     queries += [" ".join(vocab[:4]), "%s OR %s OR %s" % (vocab[-1], vocab[-2], vocab[0])]

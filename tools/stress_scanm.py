@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off stress of the mask path against the oracle: random pure-OR queries of
-3..5 terms over a synthetic Zipf corpus, several limits, both ranking functions,
+2..8 terms over a synthetic Zipf corpus, several limits, both ranking functions,
 default routing and k_scanm forced for every density."""
 import os, sys, random, struct, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ T = lambda r: terms[r - 1].decode()
 rng = random.Random(5)
 qs = []
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 400):
-    n = rng.randint(3, 5)
+    n = rng.randint(2, 8)
     lo, hi = rng.choice([(1, 30), (1, 300), (20, 2000), (200, 20000), (1, 50000)])
     qs.append(" OR ".join(T(r) for r in rng.sample(range(lo, hi + 1), n)))
 oidx = O.Index(c["terms"], c["dtmap"])

@@ -45,6 +45,8 @@ sets = {
   "M": ("5-term OR rank 30..100 (medium)", [" OR ".join(T(r) for r in rng.sample(range(30, 101), 5)) for _ in range(a.batch)]),
   "N": ("7-term OR rank 100..1000", [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 7)) for _ in range(a.batch)]),
   "O": ("2-term OR rank 100..1000", [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 2)) for _ in range(a.batch)]),
+  "P": ("(a AND b) OR (c AND d) rank 100..1000", ["(%s AND %s) OR (%s AND %s)" % tuple(T(r) for r in rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
+  "Q": ("a OR b OR (c AND NOT d) rank 100..1000", ["%s OR %s OR (%s AND NOT %s)" % tuple(T(r) for r in rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
   "J": ("2-term AND rank 1..50 (dense)", [" AND ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
 }
 for name in a.sets.split(","):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off stress of the mask path against the oracle: random pure-OR queries of
+"""One-off stress of the mask path against the oracle (argv: docs, queries, [mixed]): random pure-OR
+(or mixed-operator) queries of
 2..8 terms over a synthetic Zipf corpus, several limits, both ranking functions,
 default routing and k_scanm forced for every density."""
 import os, sys, random, struct, time
@@ -19,7 +20,17 @@ qs = []
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 400):
     n = rng.randint(2, 8)
     lo, hi = rng.choice([(1, 30), (1, 300), (20, 2000), (200, 20000), (1, 50000)])
-    qs.append(" OR ".join(T(r) for r in rng.sample(range(lo, hi + 1), n)))
+    ts = [T(r) for r in rng.sample(range(lo, hi + 1), n)]
+    if len(sys.argv) > 3 and sys.argv[3] == "mixed":
+        # random operators (juxtaposition = OR): pure OR, OR-like and AND-like shapes
+        q = ts[0]
+        for t in ts[1:]:
+            q += rng.choice([" OR ", " ", " OR ", " AND NOT ", " AND "]) + t
+        if rng.random() < 0.3 and n >= 4:
+            q = "(%s OR %s) OR (%s AND NOT %s)" % tuple(ts[:4]) + "".join(" OR " + t for t in ts[4:])
+        qs.append(q)
+    else:
+        qs.append(" OR ".join(ts))
 oidx = O.Index(c["terms"], c["dtmap"])
 bits = lambda x: struct.pack("<f", x)
 bad = 0

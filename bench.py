@@ -189,7 +189,7 @@ def main():
         + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / max(prof["launches"], 1)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    # one scan launch per query class and step; on C3: k_scanm<5> (pure OR of
+    # one scan launch per query class and step; on C3: k_scanm<5,false> (pure OR of
     # sparse terms), k_scan8<0,5,1> (pure OR with a dense term) and k_scanr<0,5>
     # (required terms); kernel_ms is their sum per step (HIP events on the
     # library's stream)

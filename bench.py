@@ -4,33 +4,41 @@
 Metric (BASELINE.json): queries/sec + p50 latency, 10M-doc BM25 top-10;
 fuzzy candidates/sec.  Default workload = configs[2] ("C3"): 10M docs / 1M
 terms synthetic Zipf corpus, 5-term AND/OR BM25 queries, batch 1024, top-10 --
-the configuration the metric is quoted on; it fits one GPU.
+the configuration the metric is quoted on; it fits one GPU.  `--workload`
+selects the others (C2 single-term, C4 fuzzy, C5 mixed BM25 + fuzzy at
+50M docs / batch 8192).
 
-A "step" = one batch of 1024 resolved queries through the device path
-(nxsgpu_search_dev_begin/_end: host planning, plan upload, k_cursors, the scan
-kernels, k_replay, results left in HBM) plus, for N > 1, one RCCL all-gather of
-the per-GPU top-k.  Steps are software-pipelined two deep: the host plans and
-uploads step i+1 while the device runs step i; all K steps have completed when
-the timed region ends.  The index is resident in HBM before it starts.  Launch:
+A "step" = one batch of query STRINGS through the public C API
+(nxs_index_search_batch_begin/_end, include/nxs.h): lex + parse + resolve (fuzzy
+misses on the device) + plan on the host's worker threads, upload, k_cursors,
+the scan kernels, k_replay, (N > 1: ONE RCCL all-gather of the ranks' record
+blocks, inside the library), copy to pinned memory, one nxs_resp_t per query,
+every result read and every response released by a C consumer
+(csrc/nxs_benchloop.c -- no Python inside the timed region).  Steps are
+pipelined two deep, as the API allows: the host plans step i+1 while the GPU
+runs step i; all K steps have completed when the timed region ends.  The index
+is resident in HBM before it starts.  Launch:
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Extra objects in that line:
-  roofline      achieved algorithmic HBM GB/s of k_scan (HIP events on its own
-                stream) against the 8 TB/s HBM3E peak
-  cpu_baseline  the oracle (plain-C restatement of the reference) timed on one
-                host core on a bounded sample of the same workload
-  latency / fuzzy / e2e   p50 single-query latency through nxs_index_search(),
-                fuzzy candidates/sec (device vs the genuine reference BK-tree
-                on one core), and the rate through the full C API.
+  roofline      achieved algorithmic HBM GB/s of the scan kernels (HIP events on
+                the library's own stream) against the 8 TB/s HBM3E peak and
+                against the read bandwidth measured on this device
+  cpu_baseline  the oracle (plain-C restatement of the reference) on ONE host
+                core on a bounded sample of the same batch, and on one worker
+                process per core (`np`, the reference's deployment model)
+  device_resident_qps / blocking_qps / latency / tfidf / default_limit / fuzzy
+                side measurements (N = 1 only)
 """
 import argparse
 import ctypes as C
 import json
 import os
 import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -43,24 +51,46 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 POSTING_BYTES = 8               # u32 doc ordinal + f32 score per posting
 RESULT_BYTES = 12               # (u64 doc id, f32 score) per returned result
 
+WORKLOADS = {
+    # name: (docs, terms, batch per step, what)
+    "C2": (1_000_000, 100_000, 1024, "single-term BM25 top-%d"),
+    "C3": (10_000_000, 1_000_000, 1024, "5-term AND/OR BM25 top-%d"),
+    "C4": (10_000_000, 1_000_000, 1024, "one misspelled term per query (Levenshtein d<=2 over the BK-tree), BM25 top-%d"),
+    "C5": (50_000_000, 2_000_000, 8192, "mixed: 75%% 5-term AND/OR + 25%% with one fuzzy token, BM25 top-%d"),
+}
+
+
+class BenchOut(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("results", C.c_uint64),
+                ("checksum", C.c_uint64), ("failed", C.c_uint64)]
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--terms", type=int, default=1_000_000)
-    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C3")
+    ap.add_argument("--docs", type=int, default=None)
+    ap.add_argument("--terms", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--np", type=int, default=0,
+                    help="worker processes of the CPU-NP baseline (0 = host share, at most 16)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the latency / fuzzy / e2e side measurements")
+                    help="skip the latency / fuzzy / device-resident side measurements")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--keep", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--cpu-np-worker", action="store_true", help=argparse.SUPPRESS)
+    a = ap.parse_args()
+    d, t, b, _ = WORKLOADS[a.workload]
+    a.docs = a.docs or d
+    a.terms = a.terms or t
+    a.batch = a.batch or b
+    return a
 
 
 def pick_workdir(args, need_bytes):
@@ -77,19 +107,37 @@ def pick_workdir(args, need_bytes):
     return os.path.join(tempfile.gettempdir(), "nxs_bench_%d" % os.getuid())
 
 
+def make_queries(args, terms, n, corpus):
+    """The batch of workload `args.workload`, seed-stable."""
+    w = args.workload
+    if w == "C2":
+        return corpus.queries_single(terms, n, seed=3)
+    if w == "C3":
+        return corpus.queries_bool5(terms, n, seed=3, hi=1000)
+    if w == "C4":
+        return corpus.queries_fuzzy(terms, n, seed=4)
+    return corpus.queries_mixed(terms, n, seed=6, hi=1000)
+
+
+def c_strings(qs):
+    return (C.c_char_p * max(len(qs), 1))(*[q.encode() if isinstance(q, str) else q for q in qs])
+
+
 def main():
     args = parse_args()
+    if args.cpu_np_worker:
+        return cpu_np_worker(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N > 1 with torch.distributed.run, "
+                 "one rank per GPU)" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import nxsearch_amd as N
-    from nxsearch_amd import corpus
+    from nxsearch_amd import corpus, multi
 
     if not torch.cuda.is_available() or N.lib().nxsgpu_device_count() <= 0:
         sys.exit("bench.py needs a HIP device; there is no CPU fallback")
@@ -120,47 +168,39 @@ def main():
     t_gen = time.time() - t0
     terms = corpus.term_strings(args.terms, seed=args.seed)
 
-    # ---- index resident in HBM --------------------------------------------
+    # ---- index resident in HBM (one replica per GPU) ------------------------
     os.environ["NXS_GPU_DEVICE"] = str(local_rank)
     t0 = time.time()
     nxs = N.Nxs(work)
     idx = nxs.open_files(info["terms"], info["dtmap"], algo="BM25")
     t_load = time.time() - t0
+    L = N.lib()
+    B = C.CDLL(os.path.join(N.CSRC, "libnxsbench.so"))
+    B.nxs_bench_batches.restype = C.c_int
+    B.nxs_bench_batches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
+                                    C.c_uint, C.c_int, C.POINTER(BenchOut)]
+    B.nxs_bench_singles.restype = C.c_int
+    B.nxs_bench_singles.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
+                                    C.POINTER(C.c_double), C.POINTER(BenchOut)]
 
-    # ---- the batch: C3 queries; weak scaling = 1024 queries per GPU, sharded
-    #      by query (contiguous slices), index replicated on every GPU --------
-    from nxsearch_amd import multi
-    k = args.limit
-    all_queries = corpus.queries_bool5(terms, args.batch * world, seed=3, hi=1000)
-    # two batches in flight (nxsgpu_search_dev_begin/_end): the host plans and
-    # uploads step i+1 while step i runs; each has its own output buffers
-    sbs = [multi.ShardedBatch(len(all_queries), k, rank, world, dev) for _ in range(2)]
-    sb = sbs[0]
-    queries = all_queries[sb.lo:sb.hi]
-    plans, errs = idx.plan_batch(queries, limit=args.limit, algo="BM25", fuzzymatch=False)
-    assert not any(errs)
+    # ---- the batch.  C2-C4: weak scaling, `batch` queries per GPU; C5: the
+    #      8192-query batch is fixed and shards over the ranks (strong).  Every
+    #      rank passes the SAME list; the library runs its contiguous slice and
+    #      all-gathers the records (one RCCL collective per step, N > 1) --------
+    strong = args.workload == "C5"
+    n_total = args.batch if strong else args.batch * world
+    queries = make_queries(args, terms, n_total, corpus)
+    fuzzy_on = args.workload in ("C4", "C5")
+    if world > 1:
+        multi.attach(nxs, idx, rank, world, dist, dev)
+    qarr = c_strings(queries)
+    params = N._make_params(args.limit, "BM25", fuzzy_on)
 
-    def begin(i):
-        o = sbs[i % 2]
-        idx.search_dev_begin(plans, len(queries), k, N.BM25, o.ids.data_ptr(),
-                             o.scores.data_ptr(), o.counts.data_ptr())
-
-    def end(i):
-        r = idx.search_dev_end()
-        assert r == 0, "a query needed the exact two-pass path"
-        # per-GPU top-k records over xGMI (RCCL all-gather); ~124 B per query
-        sbs[i % 2].gather(dist)
-
-    def run(n):
-        """n steps, software-pipelined: every step is one whole batch through
-        plan upload, cursors, scans, replay (+ all-gather); all have completed
-        when this returns."""
-        for i in range(n):
-            begin(i)
-            if i:
-                end(i - 1)
-        if n:
-            end(n - 1)
+    def run(steps):
+        out = BenchOut()
+        if B.nxs_bench_batches(idx._h, params, qarr, len(queries), steps, 2, C.byref(out)) != 0:
+            raise N.NxsError(*nxs.error())
+        return out
 
     run(args.warmup)
     idx.set_profiling(True)
@@ -168,7 +208,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps)
+    res = run(args.steps)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -179,48 +219,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_q = args.batch * world * args.steps
+    total_q = n_total * args.steps
     qps = total_q / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # ---- roofline of the dominant kernel (k_scan) on this rank --------------
-    matched = int(sbs[(args.steps - 1) % 2].counts.sum().item())
-    alg_bytes = prof["postings"] * POSTING_BYTES / max(prof["launches"], 1) \
-        + matched * RESULT_BYTES
-    scan_ms = prof["scan_ms"] / max(prof["launches"], 1)
+    # ---- roofline of the dominant kernels (the scan launches) on this rank ----
+    launches = max(prof["launches"], 1)
+    my_share = 1.0 / world if world > 1 else 1.0            # records of all ranks are read back
+    matched = res.results / max(args.steps, 1) * my_share
+    alg_bytes = prof["postings"] * POSTING_BYTES / launches + matched * RESULT_BYTES
+    scan_ms = prof["scan_ms"] / launches
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    measured = L.nxsgpu_hbm_read_gbs(idx.device, 5) if rank == 0 else 0.0
+    traffic, traffic_src = pmc_traffic(args, world)
     # one scan launch per query class and step; on C3: k_scanm<5,false> (pure OR of
     # sparse terms), k_scan8<0,5,1> (pure OR with a dense term) and k_scanr<0,5>
     # (required terms); kernel_ms is their sum per step (HIP events on the
     # library's stream)
-    roofline = {"bound": "hbm", "kernel": "k_scanm+k_scan8+k_scanr", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_scanm+k_scan8+k_scanr" if args.workload in ("C3", "C5") else "k_scan1",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(args, world),
+                "peak_measured": round(measured, 1),
+                "frac_measured": round(achieved / measured, 4) if measured > 0 else None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(alg_bytes),
                 "kernel_ms": round(scan_ms, 4),
-                "replay_ms": round(prof["replay_ms"] / max(prof["launches"], 1), 4)}
+                "replay_ms": round(prof["replay_ms"] / launches, 4)}
 
+    what = WORKLOADS[args.workload][3] % args.limit
     out = {
-        "metric": "queries/sec (10M-doc BM25 top-10, 5-term AND/OR, batch 1024)",
+        "metric": "queries/sec (10M-doc BM25 top-10, 5-term AND/OR, batch 1024)" if args.workload == "C3"
+                  else "queries/sec (%s)" % what,
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3: %d docs / %d terms Zipf, 5-term AND/OR BM25 top-%d, "
-                               "batch %d per GPU" % (args.docs, args.terms, k, args.batch),
-                   "postings": info["postings"], "parallelism": "query-sharded x%d, "
-                   "index replicated" % world},
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d docs / %d terms Zipf, %s, batch %d %s" % (
+                       args.workload, args.docs, args.terms, what, args.batch,
+                       "in all (sharded by query)" if strong else "per GPU"),
+                   "postings": info["postings"],
+                   "boundary": "nxs_index_search_batch_begin/_end: query strings in, nxs_resp_t out, "
+                               "two batches in flight",
+                   "parallelism": "query-sharded x%d, index replicated, one RCCL all-gather of "
+                                  "record blocks per step" % world if world > 1 else
+                                  "one GPU, no collective"},
         "roofline": roofline,
+        "results_per_step": int(res.results // max(args.steps, 1)),
+        "failed_queries": int(res.failed),
         "setup_s": {"corpus": round(t_gen, 1), "index_load": round(t_load, 1)},
     }
 
     if rank == 0 and world == 1:
         if not args.no_extras:
-            out.update(side_measurements(args, idx, terms, queries, torch))
+            out.update(side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev))
         if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, info, queries, idx)
+            out["cpu_baseline"] = cpu_baseline(args, info, queries, idx, fuzzy_on, work)
     barrier()
+    L.nxs_params_release(params)
     idx.close()
     nxs.close()
     if rank == 0:
@@ -232,71 +288,146 @@ def main():
 
 
 def pmc_traffic(args, world):
-    """HBM bytes per step (all scan launches) from the committed rocprofv3 --pmc
-    passes (profiles/r1_s2_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
-    valid only for the workload they were collected on; else None."""
+    """HBM bytes per step (all scan launches) from the newest committed rocprofv3
+    --pmc summary whose workload matches this run (collected by
+    tools/profile_round.sh on the same command), and the file it came from;
+    (None, None) otherwise -- the counters are not collected inside this run."""
+    best = (None, None)
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_s2_pmc_summary.json")) as f:
-            p = json.load(f)
-        w = p["workload"]
-        if (w["docs"], w["terms"], w["batch"], w["limit"]) == \
-                (args.docs, args.terms, args.batch, args.limit) and world == 1:
-            return int(p["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        names = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_summary.json"))
+    except OSError:
+        return best
+    for name in names:
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                p = json.load(f)
+            w = p["workload"]
+            if (w["docs"], w["terms"], w["batch"], w["limit"]) == \
+                    (args.docs, args.terms, args.batch, args.limit) and world == 1 and \
+                    w.get("name", "C3") == args.workload:
+                best = (int(p["hbm_bytes_per_launch"]), "profiles/" + name)
+        except (OSError, KeyError, ValueError):
+            pass
+    return best
 
 
-def side_measurements(args, idx, terms, queries, torch):
-    """p50 latency (C2-style single-term queries through nxs_index_search),
-    the full C-API batch rate, and the fuzzy path (C4)."""
+def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
+    """Device-resident rate, blocking-API rate, p50 latency, TF-IDF pass, the
+    default-limit path, and the fuzzy path (C4) with its own roofline object."""
     import nxsearch_amd as N
     from nxsearch_amd import corpus
+    L = N.lib()
     res = {}
-    # single-query latency, top-10, one term of rank uniform in [10, 10^4]
-    singles = corpus.queries_single(terms, 200, seed=5)
-    for q in singles[:20]:
-        idx.search(q, limit=args.limit, fuzzymatch=False)
-    lat = []
-    for q in singles:
-        t0 = time.perf_counter()
-        idx.search(q, limit=args.limit, fuzzymatch=False)
-        lat.append(time.perf_counter() - t0)
-    lat.sort()
-    res["latency"] = {"p50_ms": round(1e3 * lat[len(lat) // 2], 4),
-                      "p95_ms": round(1e3 * lat[int(len(lat) * 0.95)], 4),
-                      "what": "nxs_index_search(), single-term BM25 top-%d, n=%d" % (args.limit, len(lat))}
-    # the whole C API on the batch: parse + resolve + plan + device + resp objects
-    idx.search_batch(queries, limit=args.limit, fuzzymatch=False)
+    k = args.limit
+    fuzzy_on = args.workload in ("C4", "C5")
+
+    # (1) pre-resolved plans, results left in HBM (round 1's headline): what the
+    #     device does once the host front half and the response objects are gone
+    plans, errs = idx.plan_batch(queries, limit=k, algo="BM25", fuzzymatch=fuzzy_on)
+    nq = len(queries)
+    bufs = [(torch.zeros((nq, k), dtype=torch.int64, device=dev),
+             torch.zeros((nq, k), dtype=torch.float32, device=dev),
+             torch.zeros((nq,), dtype=torch.int32, device=dev)) for _ in range(2)]
+
+    def dev_run(n):
+        for i in range(n):
+            o = bufs[i % 2]
+            idx.search_dev_begin(plans, nq, k, N.BM25, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+            if i:
+                idx.search_dev_end()
+        if n:
+            idx.search_dev_end()
+    dev_run(3)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        idx.search_batch(queries, limit=args.limit, fuzzymatch=False)
-    dt = (time.perf_counter() - t0) / reps
-    res["e2e"] = {"queries_per_s": round(len(queries) / dt, 1),
-                  "what": "nxs_index_search_batch(): host parse/plan + H2D + kernels + D2H + resp"}
-    # fuzzy: C4 = 1024 tokens, Levenshtein d<=2 over the BK-tree of all terms
-    toks = corpus.queries_fuzzy(terms, args.batch, seed=4)
+    dev_run(args.steps)
+    torch.cuda.synchronize()
+    res["device_resident_qps"] = round(nq * args.steps / (time.perf_counter() - t0), 1)
+
+    # (2) the blocking call (no batch overlap)
+    o = BenchOut()
+    p = N._make_params(k, "BM25", fuzzy_on)
+    B.nxs_bench_batches(idx._h, p, qarr, nq, 2, 1, C.byref(o))
+    B.nxs_bench_batches(idx._h, p, qarr, nq, 10, 1, C.byref(o))
+    res["blocking_qps"] = round(nq * 10 / o.seconds, 1)
+
+    # (3) single-query latency: nxs_index_search(), one term of rank uniform in
+    #     [10, 10^4], top-k, n = 1000 (SURVEY 8d), timed inside the C consumer
+    singles = corpus.queries_single(terms, 1100, seed=5)
+    sarr = c_strings(singles)
+    lat = (C.c_double * len(singles))()
+    pl = N._make_params(k, "BM25", False)
+    B.nxs_bench_singles(idx._h, pl, sarr, 100, lat, C.byref(o))
+    B.nxs_bench_singles(idx._h, pl, sarr, len(singles), lat, C.byref(o))
+    ls = sorted(lat[100:])
+    res["latency"] = {"p50_ms": round(1e-3 * ls[len(ls) // 2], 4),
+                      "p95_ms": round(1e-3 * ls[int(len(ls) * 0.95)], 4),
+                      "p99_ms": round(1e-3 * ls[int(len(ls) * 0.99)], 4),
+                      "what": "nxs_index_search(), single-term BM25 top-%d, n=%d" % (k, len(ls))}
+    L.nxs_params_release(pl)
+
+    # (4) TF-IDF pass over the same batch (SURVEY 8d)
+    pt = N._make_params(k, "TF-IDF", fuzzy_on)
+    B.nxs_bench_batches(idx._h, pt, qarr, nq, 2, 2, C.byref(o))
+    B.nxs_bench_batches(idx._h, pt, qarr, nq, 10, 2, C.byref(o))
+    res["tfidf"] = {"queries_per_s": round(nq * 10 / o.seconds, 1), "failed": int(o.failed)}
+    L.nxs_params_release(pt)
+
+    # (5) default limit (1000): what nxs_index_search(idx, NULL, ...) takes -- the
+    #     exact two-pass path with the heap in global memory; 64 queries, once
+    pd = N._make_params(None, "BM25", fuzzy_on) if fuzzy_on else N._make_params(None, "BM25", False)
+    sub = c_strings(queries[:64])
+    B.nxs_bench_batches(idx._h, pd, sub, 64, 1, 1, C.byref(o))
+    B.nxs_bench_batches(idx._h, pd, sub, 64, 2, 1, C.byref(o))
+    res["default_limit"] = {"queries_per_s": round(64 * 2 / o.seconds, 1), "limit": 1000,
+                            "results_per_query": round(o.results / 128.0, 1),
+                            "what": "first 64 queries of the batch, nxs_index_search_batch(), limit 1000"}
+    L.nxs_params_release(pd)
+    L.nxs_params_release(p)
+
+    # (6) fuzzy: C4 = 1024 tokens, Levenshtein d<=2 over the BK-tree of all terms
+    toks = corpus.queries_fuzzy(terms, 1024, seed=4)
     idx.fuzzy(toks[:64])
+    ids_ref, vis = idx.fuzzy(toks, want_visited=True)        # the reference's visit set (no pruning)
     idx.set_profiling(True)
     idx.profile(reset=True)
-    t0 = time.perf_counter()
-    ids = idx.fuzzy(toks)
-    dt = time.perf_counter() - t0
-    p = idx.profile(reset=True)
+    best_dt = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ids = idx.fuzzy(toks)
+        dt = time.perf_counter() - t0
+        best_dt = dt if best_dt is None else min(best_dt, dt)
+    pr = idx.profile(reset=True)
     idx.set_profiling(False)
-    res["fuzzy"] = {"candidates_per_s": round(p["fuzzy_visits"] / (p["fuzzy_ms"] * 1e-3), 1)
-                    if p["fuzzy_ms"] > 0 else None,
-                    "tokens_per_s": round(len(toks) / dt, 1),
-                    "candidates": p["fuzzy_visits"], "device_ms": round(p["fuzzy_ms"], 3),
-                    "resolved": sum(1 for i in ids if i),
+    evals, pairs, ms = pr["fuzzy_visits"] / 3.0, pr["fuzzy_pairs"] / 3.0, pr["fuzzy_ms"] / 3.0
+    mean_len = sum(len(t) for t in terms[:100000]) / 100000.0
+    tok_len = sum(len(t) for t in toks) / float(len(toks))
+    # bytes per candidate (DESIGN.md): 8 B queue item in + 32 B node + 8 B per pushed child
+    fz_bytes = pairs * 8 + evals * 32 + pairs * 8
+    res["fuzzy"] = {"candidates_per_s": round(evals / (ms * 1e-3), 1) if ms > 0 else None,
+                    "tokens_per_s": round(len(toks) / best_dt, 1),
+                    "candidates": int(evals), "pairs_dequeued": int(pairs),
+                    "reference_visits": int(sum(vis)),
+                    "device_ms": round(ms, 3), "resolved": sum(1 for i in ids if i),
+                    "same_as_unpruned": ids == ids_ref,
+                    "levels": [int(x / 3) for x in pr["fuzzy_level"] if x],
+                    "roofline": {"bound": "hbm", "kernel": "k_bk_level",
+                                 "achieved": round(fz_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(fz_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                                 "alg_bytes": int(fz_bytes),
+                                 "cells_per_s": round(evals * mean_len * tok_len / (ms * 1e-3), 1) if ms > 0 else None,
+                                 "note": "random 32-B node + 8-B item gathers from a 40 MB tree: served by "
+                                         "L2 / Infinity Cache, HBM peak is the nominal denominator only"},
                     "what": "C4: %d tokens, d<=2 over a %d-term BK-tree" % (len(toks), args.terms)}
     return res
 
 
-def cpu_baseline(args, info, queries, idx):
+def cpu_baseline(args, info, queries, idx, fuzzy_on, work):
     """The oracle on ONE host core, on a bounded sample of the same batch
-    (same corpus, first queries of the batch), next to the GPU number."""
+    (same corpus, first queries of the batch), next to the GPU number; then one
+    worker process per core (the reference's deployment model)."""
     import oracle_lib as O
     t0 = time.time()
     oidx = O.Index(info["terms"], info["dtmap"])
@@ -306,10 +437,10 @@ def cpu_baseline(args, info, queries, idx):
     mism = 0
     for q in queries:
         t0 = time.perf_counter()
-        want = oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=False)
+        want = oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=fuzzy_on)
         t_used += time.perf_counter() - t0
         pairs += oidx.last_pairs
-        got = idx.search(q, limit=args.limit, fuzzymatch=False)
+        got = idx.search(q, limit=args.limit, fuzzymatch=fuzzy_on)
         if got != want:
             mism += 1
         n += 1
@@ -319,7 +450,8 @@ def cpu_baseline(args, info, queries, idx):
             "sample": "first %d queries of the batch, %.1f s, %d (doc,term) pairs scored; "
                       "oracle/nxs_oracle.c (reference algorithm restated in C)" % (n, t_used, pairs),
             "parity_mismatches": mism, "load_s": round(t_load, 1),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+    oidx.close()
     # fuzzy baseline on the genuine reference bktree.c/levdist.c (oracle/_ref)
     if O.ref() is not None and not args.no_extras:
         from nxsearch_amd import corpus
@@ -327,7 +459,7 @@ def cpu_baseline(args, info, queries, idx):
         t0 = time.time()
         tree = O.RefBKTree(terms)
         t_build = time.time() - t0
-        toks = corpus.queries_fuzzy(terms, args.batch, seed=4)
+        toks = corpus.queries_fuzzy(terms, 1024, seed=4)
         vis, t_used, m = 0, 0.0, 0
         for t in toks:
             t0 = time.perf_counter()
@@ -337,12 +469,95 @@ def cpu_baseline(args, info, queries, idx):
             m += 1
             if t_used >= min(budget, 10.0):
                 break
-        base["fuzzy"] = {"candidates_per_s": round(vis / t_used, 1), "cores": 1,
-                         "kind": "reference", "tokens": m, "build_s": round(t_build, 1),
+        base["fuzzy"] = {"candidates_per_s": round(vis / t_used, 1), "tokens_per_s": round(m / t_used, 2),
+                         "cores": 1, "kind": "reference", "tokens": m, "build_s": round(t_build, 1),
                          "sample": "reference src/algo/bktree.c + levdist.c compiled in place (oracle/_ref)"}
         tree.close()
-    oidx.close()
+    # one worker PROCESS per core over disjoint query slices (compose/nginx.conf:2
+    # `worker_processes auto`): a child program without a GPU context, so that it
+    # can fork its workers after loading the index once
+    if not args.no_extras:
+        try:
+            share = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            share = os.cpu_count() or 1
+        np_ = args.np or min(share, 16)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-np-worker", "--workload", args.workload,
+               "--docs", str(args.docs), "--terms", str(args.terms), "--batch", str(args.batch),
+               "--limit", str(args.limit), "--seed", str(args.seed), "--np", str(np_),
+               "--cpu-seconds", str(min(args.cpu_seconds, 20.0)), "--workdir", work]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            base["np"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:            # the baseline is a report, never a reason to lose the run
+            base["np"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return base
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_np_worker(args):
+    """Child program (no GPU): load the oracle index once, fork `--np` workers,
+    each answers a disjoint slice of the batch for the time budget."""
+    import oracle_lib as O
+    from nxsearch_amd import corpus
+    with open(os.path.join(args.workdir, "done")) as f:
+        info = json.load(f)
+    terms = corpus.term_strings(args.terms, seed=args.seed)
+    queries = make_queries(args, terms, args.batch, corpus)
+    fuzzy_on = args.workload in ("C4", "C5")
+    t0 = time.time()
+    oidx = O.Index(info["terms"], info["dtmap"])
+    t_load = time.time() - t0
+    P = max(1, args.np)
+    pipes = []
+    t_start = time.time()
+    for w in range(P):
+        r, wfd = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            n, t_used = 0, 0.0
+            t_begin = time.perf_counter()
+            for q in queries[w::P]:
+                oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=fuzzy_on)
+                n += 1
+                t_used = time.perf_counter() - t_begin
+                if t_used >= args.cpu_seconds:
+                    break
+            os.write(wfd, ("%d %.6f\n" % (n, t_used)).encode())
+            os._exit(0)
+        os.close(wfd)
+        pipes.append((pid, r))
+    rate, done = 0.0, 0
+    for pid, r in pipes:
+        data = b""
+        while True:
+            chunk = os.read(r, 256)
+            if not chunk:
+                break
+            data += chunk
+        os.close(r)
+        os.waitpid(pid, 0)
+        n, t_used = data.split()
+        done += int(n)
+        if float(t_used) > 0:
+            rate += int(n) / float(t_used)
+    print(json.dumps({"value": round(rate, 3), "unit": "queries/s", "cores": P, "kind": "port",
+                      "queries_done": done, "wall_s": round(time.time() - t_start, 1),
+                      "load_s": round(t_load, 1), "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+                      "sample": "one oracle worker process per core over disjoint slices of the batch "
+                                "(index loaded once, forked), %.0f s budget each" % args.cpu_seconds}),
+          flush=True)
 
 
 if __name__ == "__main__":

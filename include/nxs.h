@@ -88,6 +88,37 @@ int		nxs_index_search_batch(nxs_index_t *, nxs_params_t *,
 		    nxs_resp_t **resps, nxs_err_t *errs);
 
 /*
+ * The same, split for pipelining (new): _begin() parses, resolves and plans
+ * the batch on the host (worker threads), queues it on the device and returns;
+ * _end() waits for the OLDEST batch in flight and builds its responses.  Up to
+ * two batches may be in flight, so the host prepares batch i+1 while the GPU
+ * runs batch i.  `queries` need not outlive _begin().  The index re-syncs with
+ * the files (search.c:309-312) only when no batch is in flight.
+ */
+int		nxs_index_search_batch_begin(nxs_index_t *, nxs_params_t *,
+		    const char *const *queries, size_t n);
+int		nxs_index_search_batch_end(nxs_index_t *, nxs_resp_t **resps,
+		    nxs_err_t *errs);
+
+/*
+ * Query sharding over the GPUs of one node (new; the reference scales out with
+ * independent worker processes, compose/nginx.conf:2).  One process per GPU,
+ * each with a replica of the index (NXS_GPU_DEVICE selects the device at open).
+ * Rank 0 calls nxs_shard_unique_id(), the application hands the
+ * NXS_SHARD_UID_BYTES bytes to the other ranks, then EVERY rank calls
+ * nxs_index_shard() (collective: it builds an RCCL communicator).  From then on
+ * every rank passes the SAME batch to nxs_index_search_batch[_begin]; each
+ * rank runs its contiguous slice, one RCCL all-gather of fixed-size per-query
+ * records over xGMI reassembles the batch, and every rank receives all n
+ * responses.  Applies to limit <= 64; larger limits run replicated (every rank
+ * computes the whole batch).  nxs_index_search() (one query) never shards.
+ * nxs_index_shard(idx, 0, 1, NULL) detaches.
+ */
+#define	NXS_SHARD_UID_BYTES	128
+int		nxs_shard_unique_id(nxs_t *, uint8_t *uid);
+int		nxs_index_shard(nxs_index_t *, int rank, int world, const uint8_t *uid);
+
+/*
  * Front half of a batch only: parse + resolve (fuzzy misses on the device) +
  * compile into device plans (struct nxsgpu_query = nxsgpu_query_t of
  * nxs_gpu.h), for callers that keep the results on the device

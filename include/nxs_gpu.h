@@ -110,7 +110,9 @@ typedef struct {
 	double		replay_ms;
 	double		fuzzy_ms;
 	uint64_t	postings;	/* summed algorithmic postings         */
-	uint64_t	fuzzy_visits;
+	uint64_t	fuzzy_visits;	/* Levenshtein distance evaluations    */
+	uint64_t	fuzzy_pairs;	/* (token, node) pairs dequeued        */
+	uint64_t	fuzzy_level[40];/* ... per BFS level                   */
 } nxsgpu_profile_t;
 
 int		nxsgpu_device_count(void);
@@ -130,6 +132,29 @@ int		nxsgpu_search(nxsgpu_index_t *, int algo, uint64_t limit,
 		    const nxsgpu_query_t *queries, uint32_t n_queries,
 		    nxsgpu_results_t *res);
 void		nxsgpu_results_free(nxsgpu_results_t *);
+
+/*
+ * Queries that do not fit nxsgpu_query_t (more than NXSGPU_MAX_TOKENS live
+ * tokens, a program of more than NXSGPU_MAX_PROG items, or an evaluation
+ * stack deeper than 64): run_query_logic (search.c:210-278) has no such
+ * bounds.  Variable-size plan, generic kernel, always the exact two-pass path.
+ */
+#define	NXSGPU_WIDE_MAX_TOKENS	1024
+#define	NXSGPU_WOP_AND		0xfff0u
+#define	NXSGPU_WOP_OR		0xfff1u
+#define	NXSGPU_WOP_ANDNOT	0xfff2u
+#define	NXSGPU_WOP_EMPTY	0xffffu	/* push the empty set (search.c:140) */
+
+typedef struct {
+	uint32_t	n_tokens;	/* token-list order */
+	const uint32_t *term_id;
+	uint32_t	prog_len;
+	const uint16_t *prog;		/* postfix: < 0x8000 pushes token i, else NXSGPU_WOP_* */
+} nxsgpu_wide_query_t;
+
+int		nxsgpu_search_wide(nxsgpu_index_t *, int algo, uint64_t limit,
+		    const nxsgpu_wide_query_t *queries, uint32_t n_queries,
+		    nxsgpu_results_t *res);
 
 /*
  * Device-resident variant for multi-GPU gathers: limit <= NXSGPU_FAST_K,
@@ -157,6 +182,91 @@ int		nxsgpu_search_dev_end(nxsgpu_index_t *);
 int		nxsgpu_fuzzy(nxsgpu_index_t *, const uint8_t *tok_bytes,
 		    const uint32_t *tok_off, uint32_t n_tokens,
 		    uint32_t *term_ids, uint64_t *visited);
+
+/*
+ * ---- host batches as fixed-size records; query sharding over several GPUs ----
+ *
+ * The reference scales out by running independent worker processes
+ * (compose/nginx.conf:2); here a batch shards BY QUERY over the GPUs of a node
+ * (SURVEY.md 8e): every rank holds a replica of the device index, takes a
+ * contiguous slice of the batch, and ONE RCCL all-gather of fixed-size
+ * per-query records reassembles the batch on every rank.
+ *
+ * Record of one query (limit k <= NXSGPU_FAST_K), NXSGPU_REC_BYTES(k) bytes:
+ *	u32 count | u32 flags | u64 doc_id[k] | f32 score[k] | pad to 8
+ * A rank's BLOCK = n_slots records followed by n_slots u32 status words (the
+ * nxs_err_t of a query that never reached the device; padded to 8 bytes).
+ * With one rank there is no collective and the block is simply the batch's
+ * host copy.
+ */
+#define	NXSGPU_REC_BYTES(k)	((8 + 12 * (size_t)(k) + 7) & ~(size_t)7)
+#define	NXSGPU_BLOCK_BYTES(n_slots, k) \
+	((size_t)(n_slots) * NXSGPU_REC_BYTES(k) + (((size_t)(n_slots) * 4 + 7) & ~(size_t)7))
+#define	NXSGPU_REC_INEXACT	1u	/* flags: the query needs the exact two-pass path (nxsgpu_search) */
+#define	NXSGPU_UID_BYTES	128	/* = NCCL_UNIQUE_ID_BYTES */
+
+typedef struct nxsgpu_comm nxsgpu_comm_t;
+
+/* contiguous slice [lo, hi) of an n-query batch owned by `rank`, and the
+ * largest slice (= n_slots of every rank's block) */
+void		nxsgpu_shard_slice(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi);
+uint64_t	nxsgpu_shard_capacity(uint64_t n, int world);
+
+/*
+ * One RCCL communicator over the ranks' GPUs.  Rank 0 obtains the unique id,
+ * the application hands its bytes to the other ranks (MPI, a file, a socket,
+ * torch.distributed ...), then EVERY rank calls nxsgpu_comm_create (collective).
+ * librccl is loaded on first use; single-GPU users never touch it.
+ */
+int		nxsgpu_comm_unique_id(uint8_t uid[NXSGPU_UID_BYTES]);
+nxsgpu_comm_t *	nxsgpu_comm_create(int device, int rank, int world,
+		    const uint8_t uid[NXSGPU_UID_BYTES]);
+void		nxsgpu_comm_destroy(nxsgpu_comm_t *);
+int		nxsgpu_comm_rank(const nxsgpu_comm_t *);
+int		nxsgpu_comm_world(const nxsgpu_comm_t *);
+/* blocking all-gather of host buffers (staged through the device): the rare
+ * fix-up round of a sharded batch, barriers */
+int		nxsgpu_comm_allgather(nxsgpu_comm_t *, const void *send, void *recv,
+		    size_t bytes_per_rank);
+/* batches of this index all-gather their record blocks over `comm` (NULL: detach) */
+int		nxsgpu_index_set_comm(nxsgpu_index_t *, nxsgpu_comm_t *);
+
+typedef struct {
+	uint32_t	n_slots;	/* records per block */
+	uint32_t	k;
+	uint32_t	world;		/* blocks */
+	size_t		rec_bytes, block_bytes;
+	const uint8_t *	blocks;		/* host memory, valid until the second-next _begin */
+} nxsgpu_batch_view_t;
+
+/*
+ * Pipelined host batches (up to two in flight, shared with
+ * nxsgpu_search_dev_begin): the result of plans[i] goes to record
+ * slot_of_plan[i] of this rank's block; status[n_slots] travels with it.
+ * _begin() queues upload, cursors, scans, heap replays, the all-gather (if
+ * `gather` is set and a communicator is attached: every rank must then call
+ * with the same n_slots and limit) and the copy to pinned host memory, then
+ * returns; _end() waits for
+ * the OLDEST batch in flight and hands out the blocks.  0 / -1.
+ */
+int		nxsgpu_batch_begin(nxsgpu_index_t *, int algo, uint32_t limit,
+		    const nxsgpu_query_t *plans, uint32_t n_plans,
+		    const uint32_t *slot_of_plan, const uint32_t *status,
+		    uint32_t n_slots, int gather);
+int		nxsgpu_batch_end(nxsgpu_index_t *, nxsgpu_batch_view_t *);
+/* number of batches in flight (either API) */
+int		nxsgpu_batches_in_flight(const nxsgpu_index_t *);
+
+/* re-read the NXS_GPU_* switches (they are parsed once at index create);
+ * tests and A/B tools only */
+void		nxsgpu_index_reconfigure(nxsgpu_index_t *);
+
+/*
+ * Measured HBM roofline on THIS device: streams the index's own posting array
+ * (16 B per lane, every CU busy) `reps` times and reports the best read rate in
+ * GB/s, the denominator bench.py prints beside the nominal 8 TB/s.  0 on error.
+ */
+double		nxsgpu_hbm_read_gbs(nxsgpu_index_t *, int reps);
 
 void		nxsgpu_set_profiling(nxsgpu_index_t *, int on);
 void		nxsgpu_get_profile(nxsgpu_index_t *, nxsgpu_profile_t *, int reset);

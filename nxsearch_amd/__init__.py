@@ -67,7 +67,8 @@ class GpuProfile(C.Structure):
     """nxsgpu_profile_t"""
     _fields_ = [("launches", C.c_uint64), ("scan_ms", C.c_double),
                 ("replay_ms", C.c_double), ("fuzzy_ms", C.c_double),
-                ("postings", C.c_uint64), ("fuzzy_visits", C.c_uint64)]
+                ("postings", C.c_uint64), ("fuzzy_visits", C.c_uint64),
+                ("fuzzy_pairs", C.c_uint64), ("fuzzy_level", C.c_uint64 * 40)]
 
 
 # every symbol include/nxs.h and include/nxs_gpu.h declare
@@ -78,7 +79,8 @@ NXS_H_SYMBOLS = [
     "nxs_index_search", "nxs_resp_iter_reset", "nxs_resp_iter_result",
     "nxs_resp_resultcount", "nxs_resp_tojson", "nxs_resp_release",
     "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
-    "nxs_index_plan_batch",
+    "nxs_index_plan_batch", "nxs_index_search_batch_begin",
+    "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
 ]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -87,6 +89,11 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_results_free", "nxsgpu_search_dev", "nxsgpu_search_dev_begin",
     "nxsgpu_search_dev_end", "nxsgpu_fuzzy",
     "nxsgpu_set_profiling", "nxsgpu_get_profile", "nxsgpu_synchronize",
+    "nxsgpu_search_wide", "nxsgpu_shard_slice", "nxsgpu_shard_capacity",
+    "nxsgpu_comm_unique_id", "nxsgpu_comm_create", "nxsgpu_comm_destroy",
+    "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_allgather",
+    "nxsgpu_index_set_comm", "nxsgpu_batch_begin", "nxsgpu_batch_end",
+    "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_hbm_read_gbs",
 ]
 
 _lib = None
@@ -107,7 +114,7 @@ def lib():
         raise ImportError(
             "%s is missing: build it with `make -C %s` (hipcc, gfx950). "
             "There is no CPU fallback for the query path." % (LIB_PATH, CSRC))
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, cp = C.c_void_p, C.c_char_p
     L.nxs_open.restype = vp
     L.nxs_open.argtypes = [cp]
@@ -131,6 +138,14 @@ def lib():
     L.nxs_index_search_batch.restype = C.c_int
     L.nxs_index_search_batch.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t,
                                          C.POINTER(vp), C.POINTER(C.c_int)]
+    L.nxs_index_search_batch_begin.restype = C.c_int
+    L.nxs_index_search_batch_begin.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t]
+    L.nxs_index_search_batch_end.restype = C.c_int
+    L.nxs_index_search_batch_end.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.nxs_shard_unique_id.restype = C.c_int
+    L.nxs_shard_unique_id.argtypes = [vp, C.c_char_p]
+    L.nxs_index_shard.restype = C.c_int
+    L.nxs_index_shard.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.nxs_index_plan_batch.restype = C.c_int
     L.nxs_index_plan_batch.argtypes = [vp, vp, C.POINTER(cp), C.c_size_t,
                                        C.POINTER(GpuQuery), C.POINTER(C.c_int)]
@@ -164,6 +179,15 @@ def lib():
     L.nxsgpu_fuzzy.restype = C.c_int
     L.nxsgpu_fuzzy.argtypes = [vp, cp, C.POINTER(C.c_uint32), C.c_uint32,
                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.nxsgpu_shard_slice.argtypes = [C.c_uint64, C.c_int, C.c_int,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.nxsgpu_shard_capacity.restype = C.c_uint64
+    L.nxsgpu_shard_capacity.argtypes = [C.c_uint64, C.c_int]
+    L.nxsgpu_batches_in_flight.restype = C.c_int
+    L.nxsgpu_batches_in_flight.argtypes = [vp]
+    L.nxsgpu_index_reconfigure.argtypes = [vp]
+    L.nxsgpu_hbm_read_gbs.restype = C.c_double
+    L.nxsgpu_hbm_read_gbs.argtypes = [vp, C.c_int]
     L.nxsgpu_set_profiling.argtypes = [vp, C.c_int]
     L.nxsgpu_get_profile.argtypes = [vp, C.POINTER(GpuProfile), C.c_int]
     L.nxsgpu_synchronize.argtypes = [vp]
@@ -176,6 +200,10 @@ def lib():
     L.nxs_test_compile.argtypes = [cp, C.POINTER(cp), C.c_uint32, C.c_bool,
                                    C.POINTER(GpuQuery), C.POINTER(C.c_int),
                                    cp, C.c_size_t]
+    L.nxs_test_compile_wide.restype = C.c_int
+    L.nxs_test_compile_wide.argtypes = [cp, C.POINTER(cp), C.c_uint32, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.c_uint32]
     L.nxs_test_bk_image.restype = C.c_int
     L.nxs_test_bk_image.argtypes = [C.POINTER(cp), C.c_uint32, C.POINTER(BkImage)]
     L.nxs_bk_free.argtypes = [C.POINTER(BkImage)]
@@ -229,6 +257,13 @@ class Nxs:
         if not h:
             self._raise()
         return Index(self, h)
+
+    def shard_unique_id(self):
+        """nxs_shard_unique_id(): the bytes rank 0 hands to the other ranks."""
+        buf = C.create_string_buffer(128)
+        if lib().nxs_shard_unique_id(self._h, buf) != 0:
+            self._raise()
+        return buf.raw
 
     def close(self):
         if self._h:
@@ -323,6 +358,50 @@ class Index:
                 out.append(NxsError(errs[i], "query %d failed" % i))
         return out
 
+    def search_batch_begin(self, queries, limit=None, algo=None, fuzzymatch=None):
+        """nxs_index_search_batch_begin(): queue a batch (at most two in flight)."""
+        L = lib()
+        n = len(queries)
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            r = L.nxs_index_search_batch_begin(self._h, p, qs, n)
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        if r != 0:
+            self.nxs._raise()
+        self._pending = getattr(self, "_pending", []) + [n]
+
+    def search_batch_end(self):
+        """nxs_index_search_batch_end(): the oldest batch's result lists."""
+        L = lib()
+        pend = getattr(self, "_pending", [])
+        n = pend[0] if pend else 1
+        resps = (C.c_void_p * max(n, 1))()
+        errs = (C.c_int * max(n, 1))()
+        r = L.nxs_index_search_batch_end(self._h, resps, errs)
+        if r < 0:
+            self.nxs._raise()
+        self._pending = pend[1:]
+        out = []
+        for i in range(n):
+            if resps[i]:
+                out.append(_drain(resps[i]))
+                L.nxs_resp_release(resps[i])
+            else:
+                out.append(NxsError(errs[i], "query %d failed" % i))
+        return out
+
+    def shard(self, rank, world, uid):
+        """nxs_index_shard(): collective; `uid` from shard_unique_id() of rank 0."""
+        if lib().nxs_index_shard(self._h, rank, world, uid) != 0:
+            self.nxs._raise()
+
+    def reconfigure(self):
+        """Re-read the NXS_GPU_* switches (parsed once at open); tests/tools."""
+        lib().nxsgpu_index_reconfigure(self.device)
+
     def plan_batch(self, queries, limit=None, algo=None, fuzzymatch=None):
         """nxs_index_plan_batch(): -> (ctypes array of GpuQuery, [err codes])."""
         L = lib()
@@ -387,7 +466,9 @@ class Index:
     def profile(self, reset=False):
         p = GpuProfile()
         lib().nxsgpu_get_profile(self.device, C.byref(p), 1 if reset else 0)
-        return {k: getattr(p, k) for k, _ in GpuProfile._fields_}
+        d = {k: getattr(p, k) for k, _ in GpuProfile._fields_}
+        d["fuzzy_level"] = list(d["fuzzy_level"])
+        return d
 
     def close(self):
         if self._h:
@@ -418,6 +499,17 @@ def compile_query(q, words, lowercase=False):
     code = lib().nxs_test_compile(_b(q), arr, len(words), lowercase,
                                   C.byref(plan), C.byref(empty), err, 256)
     return code, err.value.decode(), bool(empty.value), plan
+
+
+def compile_wide(q, words):
+    """-> (code, wide, term_ids, prog) for a query over words "w1".."wN"."""
+    arr = (C.c_char_p * max(len(words), 1))(*[_b(w) for w in words])
+    wide, nt, pl = C.c_int(), C.c_uint32(), C.c_uint32()
+    tids = (C.c_uint32 * 4096)()
+    prog = (C.c_uint16 * 8192)()
+    code = lib().nxs_test_compile_wide(_b(q), arr, len(words), C.byref(wide), C.byref(nt),
+                                       tids, 4096, C.byref(pl), prog, 8192)
+    return code, bool(wide.value), list(tids[:nt.value]), list(prog[:pl.value])
 
 
 def bk_image(words):

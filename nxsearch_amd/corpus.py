@@ -74,6 +74,30 @@ def queries_bool5(terms, n, seed=3, hi=1000, k=5, lo=1):
     return out
 
 
+def queries_mixed(terms, n, seed=6, hi=1000, fuzzy_share=0.25):
+    """C5: 75 % C3-style queries, 25 % with ONE of the five terms replaced by a
+    misspelling (one byte substituted, exact lookup fails, a d<=1 match exists)
+    that the fuzzy path has to resolve.  Seed-stable."""
+    rng = random.Random(seed)
+    have = set(terms)
+    base = queries_bool5(terms, n, seed=seed + 1, hi=hi)
+    out = []
+    for i, q in enumerate(base):
+        if rng.random() < fuzzy_share:
+            parts = q.split(" ")
+            slots = [j for j, p in enumerate(parts) if p not in ("AND", "OR")]
+            j = rng.choice(slots)
+            while True:
+                t = bytearray(parts[j].encode())
+                t[rng.randrange(len(t))] = ord("a") + rng.randrange(26)
+                if bytes(t) not in have:
+                    break
+            parts[j] = bytes(t).decode()
+            q = " ".join(parts)
+        out.append(q)
+    return out
+
+
 def queries_fuzzy(terms, n, seed=4):
     """C4: an existing term with one random byte substituted such that the
     exact lookup fails (a d<=1 match exists)."""

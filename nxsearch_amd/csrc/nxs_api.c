@@ -20,8 +20,166 @@
 #include <limits.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <unistd.h>
 
 #include "nxs_impl.h"
+
+/* ---- host worker pool ------------------------------------------------------ */
+
+/*
+ * The front half of a batch -- lexing, parsing, token sets, dictionary lookups,
+ * plan compilation -- is independent per query (query.c:75-115 works on one
+ * query_t).  A small persistent pool spreads it over the host cores the process
+ * may use; the pool belongs to the nxs_t (one per thread/process in the
+ * reference's threading model, docs/c-api.md:5-8) and is created on the first
+ * batch that is large enough to pay for a wake-up.
+ */
+typedef void (*pool_fn_t)(void *arg, size_t lo, size_t hi);
+
+struct nxs_pool {
+	pthread_t *	thr;
+	unsigned	n_thr;
+	pthread_mutex_t	mu;
+	pthread_cond_t	cv_work, cv_done;
+	uint64_t	gen;
+	unsigned	busy;
+	bool		stop;
+	pool_fn_t	fn;
+	void *		arg;
+	size_t		n, chunk;
+	atomic_size_t	next;
+};
+
+static void
+pool_work(struct nxs_pool *p)
+{
+	for (;;) {
+		const size_t i = atomic_fetch_add(&p->next, p->chunk);
+		if (i >= p->n) {
+			break;
+		}
+		p->fn(p->arg, i, i + p->chunk < p->n ? i + p->chunk : p->n);
+	}
+}
+
+static void *
+pool_main(void *arg)
+{
+	struct nxs_pool *p = arg;
+	uint64_t seen = 0;
+
+	pthread_mutex_lock(&p->mu);
+	for (;;) {
+		while (p->gen == seen && !p->stop) {
+			pthread_cond_wait(&p->cv_work, &p->mu);
+		}
+		if (p->stop) {
+			break;
+		}
+		seen = p->gen;
+		pthread_mutex_unlock(&p->mu);
+		pool_work(p);
+		pthread_mutex_lock(&p->mu);
+		if (--p->busy == 0) {
+			pthread_cond_signal(&p->cv_done);
+		}
+	}
+	pthread_mutex_unlock(&p->mu);
+	return NULL;
+}
+
+static struct nxs_pool *
+pool_create(unsigned n_thr)
+{
+	struct nxs_pool *p = calloc(1, sizeof(*p));
+
+	if (!p) {
+		return NULL;
+	}
+	pthread_mutex_init(&p->mu, NULL);
+	pthread_cond_init(&p->cv_work, NULL);
+	pthread_cond_init(&p->cv_done, NULL);
+	p->thr = calloc(n_thr ? n_thr : 1, sizeof(pthread_t));
+	for (unsigned i = 0; p->thr && i < n_thr; i++) {
+		if (pthread_create(&p->thr[p->n_thr], NULL, pool_main, p) != 0) {
+			break;
+		}
+		p->n_thr++;
+	}
+	return p;
+}
+
+static void
+pool_destroy(struct nxs_pool *p)
+{
+	if (!p) {
+		return;
+	}
+	pthread_mutex_lock(&p->mu);
+	p->stop = true;
+	pthread_cond_broadcast(&p->cv_work);
+	pthread_mutex_unlock(&p->mu);
+	for (unsigned i = 0; i < p->n_thr; i++) {
+		pthread_join(p->thr[i], NULL);
+	}
+	pthread_mutex_destroy(&p->mu);
+	pthread_cond_destroy(&p->cv_work);
+	pthread_cond_destroy(&p->cv_done);
+	free(p->thr);
+	free(p);
+}
+
+/* fn over [0, n) in chunks, on the pool's threads and the caller */
+static void
+pool_run(struct nxs_pool *p, pool_fn_t fn, void *arg, size_t n, size_t chunk)
+{
+	if (!p || p->n_thr == 0 || n <= chunk) {
+		if (n) {
+			fn(arg, 0, n);
+		}
+		return;
+	}
+	pthread_mutex_lock(&p->mu);
+	p->fn = fn;
+	p->arg = arg;
+	p->n = n;
+	p->chunk = chunk;
+	atomic_store(&p->next, 0);
+	p->busy = p->n_thr;
+	p->gen++;
+	pthread_cond_broadcast(&p->cv_work);
+	pthread_mutex_unlock(&p->mu);
+	pool_work(p);
+	pthread_mutex_lock(&p->mu);
+	while (p->busy) {
+		pthread_cond_wait(&p->cv_done, &p->mu);
+	}
+	pthread_mutex_unlock(&p->mu);
+}
+
+/* the pool of an instance: NXS_HOST_THREADS (read once), else min(cores, 16) */
+static struct nxs_pool *
+nxs_pool_get(nxs_t *nxs)
+{
+	if (!nxs->pool_tried) {
+		const char *e = getenv("NXS_HOST_THREADS");
+		long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+
+		nxs->pool_tried = true;
+		if (n > 16 && !e) {
+			n = 16;
+		}
+		if (n > 64) {
+			n = 64;
+		}
+		if (n > 1) {
+			nxs->pool = pool_create((unsigned)n - 1);	/* the caller works too */
+		}
+	}
+	return nxs->pool;
+}
 
 /* ---- instance + errors --------------------------------------------------- */
 
@@ -47,6 +205,7 @@ nxs_close(nxs_t *nxs)
 	while (nxs->n_indexes) {
 		nxs_index_close(nxs->indexes[nxs->n_indexes - 1]);
 	}
+	pool_destroy(nxs->pool);
 	free(nxs->indexes);
 	free(nxs->basedir);
 	free(nxs->errmsg);
@@ -350,6 +509,8 @@ nxs_index_open_files(nxs_t *nxs, const char *terms_path, const char *dtmap_path,
 	return index_open_common(nxs, terms_path, terms_path, dtmap_path, algo, lowercase);
 }
 
+static void index_drain(nxs_index_t *);
+
 void
 nxs_index_close(nxs_index_t *idx)
 {
@@ -361,6 +522,15 @@ nxs_index_close(nxs_index_t *idx)
 			break;
 		}
 	}
+	index_drain(idx);
+	if (idx->comm) {
+		if (idx->dev) {
+			(void)nxsgpu_index_set_comm(idx->dev, NULL);
+		}
+		nxsgpu_comm_destroy(idx->comm);
+		idx->comm = NULL;
+	}
+	free(idx->emu_block);
 	nxs_index_unload(idx);
 	free(idx->name);
 	free(idx);
@@ -374,34 +544,76 @@ nxs_index_device(nxs_index_t *idx)
 
 /* ---- response object --------------------------------------------------------- */
 
+/*
+ * The responses of one batch live in ONE allocation (the reference's
+ * nxs_resp_create mallocs a map, a heap and a JSON document per query,
+ * results.c:46-85): header + n response structs + all (id, score) pairs.  Each
+ * nxs_resp_t stays individually releasable; the slab goes with the last one.
+ */
+struct resp_slab {
+	size_t		refs;
+};
+
 struct nxs_resp {
 	nxs_doc_id_t *	ids;
 	float *		scores;
 	unsigned	count;
 	unsigned	iter;
+	struct resp_slab *slab;		/* NULL: ids/scores are this response's own */
 };
 
-static nxs_resp_t *
-resp_create(const uint64_t *ids, const float *scores, unsigned count)
-{
-	nxs_resp_t *r = calloc(1, sizeof(nxs_resp_t));
+typedef struct {
+	struct resp_slab *slab;
+	nxs_resp_t *	resps;		/* [n] */
+	nxs_doc_id_t *	ids;		/* [total] */
+	float *		scores;		/* [total] */
+	size_t		used;
+} slab_builder_t;
 
-	if (!r) {
-		return NULL;
+static int
+slab_begin(slab_builder_t *b, size_t n, size_t total)
+{
+	const size_t hdr = (sizeof(struct resp_slab) + 15) & ~(size_t)15;
+	const size_t rs = (n * sizeof(nxs_resp_t) + 15) & ~(size_t)15;
+	uint8_t *m = malloc(hdr + rs + total * sizeof(nxs_doc_id_t) + total * sizeof(float) + 16);
+
+	if (!m) {
+		return -1;
 	}
-	r->ids = malloc((count ? count : 1) * sizeof(nxs_doc_id_t));
-	r->scores = malloc((count ? count : 1) * sizeof(float));
-	if (count) {
-		memcpy(r->ids, ids, count * sizeof(nxs_doc_id_t));
-		memcpy(r->scores, scores, count * sizeof(float));
-	}
+	b->slab = (struct resp_slab *)m;
+	b->slab->refs = 0;
+	b->resps = (nxs_resp_t *)(m + hdr);
+	b->ids = (nxs_doc_id_t *)(m + hdr + rs);
+	b->scores = (float *)(b->ids + total);
+	b->used = 0;
+	return 0;
+}
+
+/* response i of the slab: `count` results to be filled in by the caller */
+static nxs_resp_t *
+slab_resp(slab_builder_t *b, size_t i, unsigned count)
+{
+	nxs_resp_t *r = &b->resps[i];
+
+	r->ids = b->ids + b->used;
+	r->scores = b->scores + b->used;
 	r->count = count;
+	r->iter = 0;
+	r->slab = b->slab;
+	b->used += count;
+	b->slab->refs++;
 	return r;
 }
 
 void
 nxs_resp_release(nxs_resp_t *r)
 {
+	if (r->slab) {
+		if (--r->slab->refs == 0) {
+			free(r->slab);
+		}
+		return;
+	}
 	free(r->ids);
 	free(r->scores);
 	free(r);
@@ -557,37 +769,73 @@ get_search_params(nxs_index_t *idx, nxs_params_t *params, search_params_t *sp)
 /*
  * Front half of a batch: parse, build the token sets, resolve (exact on the
  * host, misses through one device BK-tree pass), compile the device plans.
- * prep[i].errcode / .empty tell how query i ended.
+ * prep[i].errcode / .empty tell how query i ended.  Parsing + lookups and the
+ * compilation are spread over the instance's worker pool.
  */
+typedef struct {
+	const nxs_index_t *	idx;
+	const search_params_t *	sp;
+	const char *const *	queries;
+	qprep_t *		prep;
+} plan_job_t;
+
+static void
+plan_parse_chunk(void *arg, size_t lo, size_t hi)
+{
+	const plan_job_t *j = arg;
+
+	for (size_t i = lo; i < hi; i++) {
+		qprep_t *q = &j->prep[i];
+
+		nxs_query_prepare(j->idx, j->queries[i], q);
+		if (q->errcode) {
+			continue;
+		}
+		/* idxterm_lookup for every token (tokenizer.c:171-176) */
+		for (size_t k = 0; k < q->n_tokens; k++) {
+			qtok_t *t = &q->tokens[k];
+			t->term_id = nxs_term_lookup(j->idx, (const uint8_t *)t->value, t->len);
+		}
+	}
+}
+
+static void
+plan_compile_chunk(void *arg, size_t lo, size_t hi)
+{
+	const plan_job_t *j = arg;
+
+	for (size_t i = lo; i < hi; i++) {
+		if (!j->prep[i].errcode) {
+			(void)nxs_query_compile(&j->prep[i]);
+		}
+	}
+}
+
 static int
 plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
     size_t n, qprep_t *prep)
 {
 	nxs_t *nxs = idx->nxs;
+	struct nxs_pool *pool = n >= 64 ? nxs_pool_get(nxs) : NULL;
+	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep };
 	uint32_t *fz_q = NULL, *fz_t = NULL, *fz_off = NULL, *fz_ids = NULL;
 	uint8_t *fz_bytes = NULL;
 	size_t n_fz = 0, fz_len = 0;
 	int ret = -1;
 
-	/* idxterm_lookup for every token */
-	for (size_t i = 0; i < n; i++) {
-		qprep_t *q = &prep[i];
+	pool_run(pool, plan_parse_chunk, &job, n, 16);
 
-		nxs_query_prepare(idx, queries[i], q);
-		if (q->errcode) {
-			continue;
-		}
-		for (size_t j = 0; j < q->n_tokens; j++) {
-			qtok_t *t = &q->tokens[j];
-			t->term_id = nxs_term_lookup(idx, (const uint8_t *)t->value, t->len);
-			if (!t->term_id && sp->fuzzymatch) {
+	/* one device BK-tree pass for every token that missed (tokenizer.c:177-180) */
+	for (size_t i = 0; sp->fuzzymatch && i < n; i++) {
+		const qprep_t *q = &prep[i];
+
+		for (size_t j = 0; !q->errcode && j < q->n_tokens; j++) {
+			if (!q->tokens[j].term_id) {
 				n_fz++;
-				fz_len += t->len;
+				fz_len += q->tokens[j].len;
 			}
 		}
 	}
-
-	/* one device BK-tree pass for every token that missed (tokenizer.c:177-180) */
 	if (n_fz) {
 		size_t k = 0, o = 0;
 
@@ -596,6 +844,10 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 		fz_off = malloc((n_fz + 1) * sizeof(uint32_t));
 		fz_ids = calloc(n_fz, sizeof(uint32_t));
 		fz_bytes = malloc(fz_len + 1);
+		if (!fz_q || !fz_t || !fz_off || !fz_ids || !fz_bytes) {
+			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+			goto out;
+		}
 		for (size_t i = 0; i < n; i++) {
 			qprep_t *q = &prep[i];
 			if (q->errcode) {
@@ -624,11 +876,7 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 			prep[fz_q[k]].tokens[fz_t[k]].term_id = fz_ids[k];
 		}
 	}
-	for (size_t i = 0; i < n; i++) {
-		if (!prep[i].errcode) {
-			(void)nxs_query_compile(&prep[i]);
-		}
-	}
+	pool_run(pool, plan_compile_chunk, &job, n, 32);
 	ret = 0;
 out:
 	free(fz_q);
@@ -666,15 +914,22 @@ nxs_index_plan_batch(nxs_index_t *idx, nxs_params_t *params,
 	for (size_t i = 0; i < n; i++) {
 		memset(&plans[i], 0, sizeof(plans[i]));
 		if (failed != -1) {
-			if (prep[i].errcode) {
-				failed++;
-				nxs_decl_err(idx->nxs, prep[i].errcode, "%s",
+			nxs_err_t code = prep[i].errcode;
+
+			if (!code && prep[i].wide) {
+				/* a fixed-size nxsgpu_query_t cannot hold it */
+				code = NXS_ERR_LIMIT;
+				nxs_decl_err(idx->nxs, code, "query %zu has more than %u terms: "
+				    "use nxs_index_search_batch", i, NXSGPU_MAX_TOKENS);
+			} else if (code) {
+				nxs_decl_err(idx->nxs, code, "%s",
 				    prep[i].errmsg ? prep[i].errmsg : "");
 			} else if (!prep[i].empty) {
 				plans[i] = prep[i].plan;
 			}
+			failed += code != 0;
 			if (errs) {
-				errs[i] = prep[i].errcode;
+				errs[i] = code;
 			}
 		}
 		nxs_query_release(&prep[i]);
@@ -683,111 +938,498 @@ nxs_index_plan_batch(nxs_index_t *idx, nxs_params_t *params,
 	return failed;
 }
 
+/* ---- batches: begin / end ------------------------------------------------------- */
+
+/* status word of a record slot: 0, an nxs_err_t, or ... */
+#define	STATUS_HOSTPATH	0x100u	/* the owner evaluates it on the exact path (fix-up round) */
+
+static nxs_pend_t *
+pend_oldest(nxs_index_t *idx)
+{
+	nxs_pend_t *p = NULL;
+
+	for (int i = 0; i < 2; i++) {
+		if (idx->pend[i].active && (!p || idx->pend[i].seq < p->seq)) {
+			p = &idx->pend[i];
+		}
+	}
+	return p;
+}
+
+static void
+pend_release(nxs_pend_t *p)
+{
+	for (size_t i = 0; p->prep && i < p->hi - p->lo; i++) {
+		nxs_query_release(&p->prep[i]);
+	}
+	free(p->prep);
+	memset(p, 0, sizeof(*p));
+}
+
+/* batches never collected (the caller closes the index instead): wait, drop */
+static void
+index_drain(nxs_index_t *idx)
+{
+	nxs_pend_t *pd;
+
+	while ((pd = pend_oldest(idx)) != NULL) {
+		nxsgpu_batch_view_t v;
+
+		if (pd->on_device && idx->dev) {
+			(void)nxsgpu_batch_end(idx->dev, &v);
+		}
+		pend_release(pd);
+	}
+}
+
 int
-nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
-    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
+    const char *const *queries, size_t n)
 {
 	nxs_t *nxs = idx->nxs;
+	nxs_pend_t *pd = NULL;
 	search_params_t sp;
-	qprep_t *prep = NULL;
 	nxsgpu_query_t *plans = NULL;
-	uint32_t *plan_of = NULL;
-	size_t n_plans = 0;
-	nxsgpu_results_t res;
-	int failed = 0, ret = -1;
+	uint32_t *slot_of = NULL, *status = NULL;
+	uint64_t lo = 0, hi = n;
+	size_t n_plans = 0, nl;
+	int ret = -1;
 
 	nxs_clear_error(nxs);
+	if (get_search_params(idx, params, &sp) == -1) {
+		return -1;
+	}
+	for (int i = 0; i < 2; i++) {
+		if (!idx->pend[i].active) {
+			pd = &idx->pend[i];
+			break;
+		}
+	}
+	if (!pd) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "two batches are already in flight");
+		return -1;
+	}
+	/*
+	 * search.c:309-312: pick up what other processes appended -- between
+	 * batches only: a refresh swaps device arrays the batch in flight reads.
+	 */
+	if (!pend_oldest(idx) && nxs_index_refresh(idx) == -1) {
+		return -1;
+	}
+	if (n > UINT32_MAX / 2) {
+		nxs_decl_err(nxs, NXS_ERR_LIMIT, "batch too large");
+		return -1;
+	}
+	memset(pd, 0, sizeof(*pd));
+	pd->n = n;
+	pd->limit = sp.limit;
+	pd->algo = sp.algo;
+	pd->world = 1;
+	/* query sharding: fixed-size records need limit <= FAST_K;
+	 * larger limits run replicated -- every rank computes the whole batch */
+	if (idx->comm && sp.limit <= NXSGPU_FAST_K) {
+		pd->rank = nxsgpu_comm_rank(idx->comm);
+		pd->world = nxsgpu_comm_world(idx->comm);
+		nxsgpu_shard_slice(n, pd->rank, pd->world, &lo, &hi);
+	} else if (idx->emu_world > 1 && sp.limit <= NXSGPU_FAST_K) {
+		/* tests: this process plays ONE rank of a W-rank run, no collective */
+		pd->rank = idx->emu_rank;
+		pd->world = idx->emu_world;
+		nxsgpu_shard_slice(n, pd->rank, pd->world, &lo, &hi);
+	}
+	pd->lo = lo;
+	pd->hi = hi;
+	pd->cap = (uint32_t)nxsgpu_shard_capacity(n, pd->world);
+	nl = hi - lo;
+	pd->prep = calloc(nl ? nl : 1, sizeof(qprep_t));
+	if (!pd->prep) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1) {
+		goto out;
+	}
+	if (sp.limit <= NXSGPU_FAST_K) {
+		plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
+		slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
+		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
+		if (!plans || !slot_of || !status) {
+			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+			goto out;
+		}
+		for (size_t i = 0; i < nl; i++) {
+			const qprep_t *q = &pd->prep[i];
+
+			if (q->errcode) {
+				status[i] = q->errcode;
+			} else if (q->wide) {
+				status[i] = STATUS_HOSTPATH;
+			} else if (!q->empty) {
+				slot_of[n_plans] = (uint32_t)i;
+				plans[n_plans++] = q->plan;
+			}
+		}
+		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
+		    (uint32_t)n_plans, slot_of, status, pd->cap,
+		    pd->world > 1 && !idx->emu_world) != 0) {
+			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
+			    nxsgpu_last_error());
+			goto out;
+		}
+		pd->on_device = true;
+	}
+	pd->seq = ++idx->pend_seq;
+	pd->active = true;
+	ret = 0;
+out:
+	free(plans);
+	free(slot_of);
+	free(status);
+	if (ret != 0) {
+		pend_release(pd);
+	}
+	return ret;
+}
+
+/* exact path (nxsgpu_search / nxsgpu_search_wide) for the given local queries */
+static int
+run_exact(nxs_index_t *idx, const nxs_pend_t *pd, const uint32_t *which, size_t nw,
+    nxsgpu_results_t *res, nxsgpu_results_t *wres, uint32_t *pos)
+{
+	nxsgpu_query_t *plans = NULL;
+	nxsgpu_wide_query_t *wplans = NULL;
+	size_t np = 0, nwd = 0;
+	int ret = -1;
+
+	memset(res, 0, sizeof(*res));
+	memset(wres, 0, sizeof(*wres));
+	plans = malloc((nw ? nw : 1) * sizeof(nxsgpu_query_t));
+	wplans = malloc((nw ? nw : 1) * sizeof(nxsgpu_wide_query_t));
+	if (!plans || !wplans) {
+		nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	for (size_t j = 0; j < nw; j++) {
+		const qprep_t *q = &pd->prep[which[j]];
+
+		if (q->wide) {
+			pos[j] = (uint32_t)nwd | 0x80000000u;
+			wplans[nwd++] = q->wplan;
+		} else {
+			pos[j] = (uint32_t)np;
+			plans[np++] = q->plan;
+		}
+	}
+	if (np && nxsgpu_search(idx->dev, pd->algo, pd->limit, plans, (uint32_t)np, res) != 0) {
+		nxs_decl_err(idx->nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+		goto out;
+	}
+	if (nwd && nxsgpu_search_wide(idx->dev, pd->algo, pd->limit, wplans, (uint32_t)nwd, wres) != 0) {
+		nxs_decl_err(idx->nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+		goto out;
+	}
+	ret = 0;
+out:
+	free(plans);
+	free(wplans);
+	return ret;
+}
+
+static inline const nxsgpu_results_t *
+exact_pick(const nxsgpu_results_t *res, const nxsgpu_results_t *wres, uint32_t pos, uint32_t *at)
+{
+	*at = pos & 0x7fffffffu;
+	return (pos & 0x80000000u) ? wres : res;
+}
+
+/*
+ * Responses of a whole batch from the ranks' record blocks, in query order
+ * (rank r owns the contiguous slice nxsgpu_shard_slice(n, r, world)).  A slot
+ * with a status word is a failed query: no response, its code in errs[].
+ */
+static int
+resps_from_blocks(nxs_t *nxs, const nxs_pend_t *pd, size_t n, uint32_t world, uint32_t n_slots,
+    uint32_t k, const uint8_t *blocks, nxs_resp_t **resps, nxs_err_t *errs, slab_builder_t *sb,
+    int *failed)
+{
+	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
+	size_t total = 0;
+
+	for (uint32_t r = 0; r < world; r++) {
+		const uint8_t *blk = blocks + (size_t)r * block_bytes;
+		uint64_t rlo, rhi;
+
+		nxsgpu_shard_slice(n, (int)r, (int)world, &rlo, &rhi);
+		for (uint64_t i = 0; i < rhi - rlo; i++) {
+			const uint32_t c = ((const uint32_t *)(blk + i * rec_bytes))[0];
+			if (c > k) {
+				nxs_decl_err(nxs, NXS_ERR_FATAL, "corrupted result record");
+				return -1;
+			}
+			total += c;
+		}
+	}
+	if (slab_begin(sb, n, total) == -1) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		return -1;
+	}
+	for (uint32_t r = 0; r < world; r++) {
+		const uint8_t *blk = blocks + (size_t)r * block_bytes;
+		const uint32_t *st = (const uint32_t *)(blk + (size_t)n_slots * rec_bytes);
+		uint64_t rlo, rhi;
+
+		nxsgpu_shard_slice(n, (int)r, (int)world, &rlo, &rhi);
+		for (uint64_t i = 0; i < rhi - rlo; i++) {
+			const uint8_t *rec = blk + i * rec_bytes;
+			const uint32_t c = ((const uint32_t *)rec)[0];
+			nxs_resp_t *rp;
+
+			if (st[i]) {
+				(*failed)++;
+				if (errs) {
+					errs[rlo + i] = (nxs_err_t)st[i];
+				}
+				if (pd && (int)r == pd->rank) {
+					nxs_decl_err(nxs, (nxs_err_t)st[i], "%s",
+					    pd->prep[i].errmsg ? pd->prep[i].errmsg : "");
+				} else {
+					nxs_decl_err(nxs, (nxs_err_t)st[i], "query %llu failed on rank %u",
+					    (unsigned long long)(rlo + i), r);
+				}
+				continue;
+			}
+			rp = slab_resp(sb, rlo + i, c);
+			memcpy(rp->ids, rec + 8, (size_t)c * 8);
+			memcpy(rp->scores, rec + 8 + 8 * (size_t)k, (size_t)c * 4);
+			resps[rlo + i] = rp;
+		}
+	}
+	return 0;
+}
+
+int
+nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_t *nxs = idx->nxs;
+	nxs_pend_t *pd = pend_oldest(idx);
+	nxsgpu_results_t res, wres;
+	slab_builder_t sb = { 0 };
+	uint8_t *patched = NULL;
+	uint32_t *which, *pos;
+	size_t nw = 0, total = 0, n, nl;
+	int failed = 0, ret = -1;
+
 	memset(&res, 0, sizeof(res));
+	memset(&wres, 0, sizeof(wres));
+	nxs_clear_error(nxs);
+	if (!pd) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "no batch in flight");
+		return -1;
+	}
+	n = pd->n;
+	nl = pd->hi - pd->lo;
 	for (size_t i = 0; i < n; i++) {
 		resps[i] = NULL;
 		if (errs) {
 			errs[i] = NXS_ERR_SUCCESS;
 		}
 	}
-	if (get_search_params(idx, params, &sp) == -1) {
-		return -1;
-	}
-	if (nxs_index_refresh(idx) == -1) {	/* search.c:309-312 */
-		return -1;
-	}
-	if (n == 0) {
-		return 0;
-	}
-	if (n > UINT32_MAX / 2) {
-		nxs_decl_err(nxs, NXS_ERR_LIMIT, "batch too large");
-		return -1;
-	}
-	prep = calloc(n, sizeof(qprep_t));
-	plans = calloc(n, sizeof(nxsgpu_query_t));
-	plan_of = calloc(n, sizeof(uint32_t));
-	if (!prep || !plans || !plan_of) {
+	which = calloc(nl ? nl : 1, sizeof(uint32_t));
+	pos = calloc(nl ? nl : 1, sizeof(uint32_t));
+	if (!which || !pos) {
 		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 		goto out;
 	}
-	if (plan_batch(idx, &sp, queries, n, prep) == -1) {
-		goto out;
-	}
-	for (size_t i = 0; i < n; i++) {
-		const qprep_t *q = &prep[i];
 
-		if (!q->errcode && !q->empty) {
-			plan_of[i] = (uint32_t)n_plans;
-			plans[n_plans++] = q->plan;
+	if (pd->on_device) {
+		nxsgpu_batch_view_t v;
+		const uint8_t *blocks;
+		const uint32_t W = (uint32_t)pd->world;
+		/* all W blocks are present after the all-gather; a single rank -- or the
+		 * emulation of one rank of W (tests) -- holds its own block only */
+		const bool all = W == 1 || !idx->emu_world;
+		bool fixup = false;
+
+		if (nxsgpu_batch_end(idx->dev, &v) != 0) {
+			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+			goto out;
 		}
-	}
-	if (n_plans && nxsgpu_search(idx->dev, sp.algo, sp.limit, plans,
-	    (uint32_t)n_plans, &res) != 0) {
-		nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
-		    nxsgpu_last_error());
-		goto out;
-	}
+		blocks = v.blocks;
+		if (all && v.world != W) {
+			nxs_decl_err(nxs, NXS_ERR_FATAL, "sharded batch came back with %u blocks, not %u",
+			    v.world, W);
+			goto out;
+		}
+		/* records that need the exact path: every rank sees the same flags, so
+		 * every rank takes (or skips) the fix-up round together */
+		for (uint32_t r = 0; r < W; r++) {
+			const uint8_t *blk = all ? blocks + (size_t)r * v.block_bytes : blocks;
+			const uint32_t *st = (const uint32_t *)(blk + (size_t)v.n_slots * v.rec_bytes);
+			uint64_t rlo, rhi;
 
-	for (size_t i = 0; i < n; i++) {
-		qprep_t *q = &prep[i];
-
-		if (q->errcode) {
-			failed++;
-			if (errs) {
-				errs[i] = q->errcode;
+			if (!all && (int)r != pd->rank) {
+				continue;
 			}
-			nxs_decl_err(nxs, q->errcode, "%s", q->errmsg ? q->errmsg : "");
-			continue;
-		}
-		if (q->empty) {
-			resps[i] = resp_create(NULL, NULL, 0);
-		} else {
-			const uint32_t p = plan_of[i];
-			resps[i] = resp_create(res.doc_ids + res.offsets[p],
-			    res.scores + res.offsets[p], res.counts[p]);
-		}
-		if (!resps[i]) {
-			failed++;
-			if (errs) {
-				errs[i] = NXS_ERR_SYSTEM;
+			nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
+			for (uint64_t i = 0; i < rhi - rlo; i++) {
+				const uint32_t *rec = (const uint32_t *)(blk + i * v.rec_bytes);
+				if (rec[1] == NXSGPU_REC_INEXACT || st[i] == STATUS_HOSTPATH) {
+					fixup = true;
+					if ((int)r == pd->rank) {
+						which[nw++] = (uint32_t)i;
+					}
+				}
 			}
+		}
+		if (fixup) {
+			const size_t len = (all ? (size_t)W : 1) * v.block_bytes;
+			uint8_t *mine;
+
+			if ((patched = malloc(len ? len : 1)) == NULL) {
+				nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+				goto out;
+			}
+			memcpy(patched, blocks, len);
+			mine = patched + (all ? (size_t)pd->rank * v.block_bytes : 0);
+			if (run_exact(idx, pd, which, nw, &res, &wres, pos) != 0) {
+				goto out;
+			}
+			for (size_t j = 0; j < nw; j++) {
+				uint8_t *rec = mine + (size_t)which[j] * v.rec_bytes;
+				uint32_t *st = (uint32_t *)(mine + (size_t)v.n_slots * v.rec_bytes);
+				uint32_t at;
+				const nxsgpu_results_t *rs = exact_pick(&res, &wres, pos[j], &at);
+				const uint32_t c = rs->counts[at];
+
+				((uint32_t *)rec)[0] = c;
+				((uint32_t *)rec)[1] = 0;
+				memcpy(rec + 8, rs->doc_ids + rs->offsets[at], (size_t)c * 8);
+				memcpy(rec + 8 + 8 * (size_t)v.k, rs->scores + rs->offsets[at], (size_t)c * 4);
+				st[which[j]] = 0;
+			}
+			if (all && W > 1) {
+				uint8_t *gathered = malloc(len);
+
+				if (!gathered || nxsgpu_comm_allgather(idx->comm, mine, gathered, v.block_bytes) != 0) {
+					nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather failed: %s",
+					    gathered ? nxsgpu_last_error() : "out of memory");
+					free(gathered);
+					goto out;
+				}
+				free(patched);
+				patched = gathered;
+			}
+			blocks = patched;
+		}
+		if (!all) {
+			/* one rank of an emulated W-rank run: hand the block to the test */
+			free(idx->emu_block);
+			idx->emu_block = malloc(v.block_bytes ? v.block_bytes : 1);
+			if (!idx->emu_block) {
+				nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+				goto out;
+			}
+			memcpy(idx->emu_block, blocks, v.block_bytes);
+			idx->emu_block_len = v.block_bytes;
+			ret = 0;
+			goto out;
+		}
+		if (resps_from_blocks(nxs, pd, n, W, v.n_slots, v.k, blocks, resps, errs, &sb, &failed) == -1) {
+			goto out;
+		}
+	} else {
+		/* limit > NXSGPU_FAST_K: the exact two-pass path for the whole batch */
+		for (size_t i = 0; i < nl; i++) {
+			const qprep_t *q = &pd->prep[i];
+			if (!q->errcode && !q->empty) {
+				which[nw++] = (uint32_t)i;
+			}
+		}
+		if (run_exact(idx, pd, which, nw, &res, &wres, pos) != 0) {
+			goto out;
+		}
+		for (size_t j = 0; j < nw; j++) {
+			uint32_t at;
+			const nxsgpu_results_t *rs = exact_pick(&res, &wres, pos[j], &at);
+			total += rs->counts[at];
+		}
+		if (slab_begin(&sb, n, total) == -1) {
 			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+			goto out;
 		}
+		for (size_t i = 0, j = 0; i < nl; i++) {
+			const qprep_t *q = &pd->prep[i];
+			nxs_resp_t *rp;
+
+			if (q->errcode) {
+				failed++;
+				if (errs) {
+					errs[i] = q->errcode;
+				}
+				nxs_decl_err(nxs, q->errcode, "%s", q->errmsg ? q->errmsg : "");
+				continue;
+			}
+			if (q->empty) {
+				resps[i] = slab_resp(&sb, i, 0);
+				continue;
+			}
+			{
+				uint32_t at;
+				const nxsgpu_results_t *rs = exact_pick(&res, &wres, pos[j], &at);
+				const uint32_t c = rs->counts[at];
+
+				rp = slab_resp(&sb, i, c);
+				memcpy(rp->ids, rs->doc_ids + rs->offsets[at], (size_t)c * 8);
+				memcpy(rp->scores, rs->scores + rs->offsets[at], (size_t)c * 4);
+				resps[i] = rp;
+				j++;
+			}
+		}
+	}
+	if (sb.slab && sb.slab->refs == 0) {
+		free(sb.slab);		/* every query failed */
 	}
 	ret = failed;
 out:
+	if (ret == -1 && sb.slab) {
+		for (size_t i = 0; i < n; i++) {
+			resps[i] = NULL;
+		}
+		free(sb.slab);
+	}
 	if (res.counts) {
 		nxsgpu_results_free(&res);
 	}
-	for (size_t i = 0; prep && i < n; i++) {
-		nxs_query_release(&prep[i]);
+	if (wres.counts) {
+		nxsgpu_results_free(&wres);
 	}
-	if (ret == -1) {
-		for (size_t i = 0; i < n; i++) {
-			if (resps[i]) {
-				nxs_resp_release(resps[i]);
-				resps[i] = NULL;
-			}
+	free(patched);
+	free(which);
+	free(pos);
+	pend_release(pd);
+	return ret;
+}
+
+int
+nxs_index_search_batch(nxs_index_t *idx, nxs_params_t *params,
+    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	if (pend_oldest(idx)) {
+		nxs_clear_error(idx->nxs);
+		nxs_decl_err(idx->nxs, NXS_ERR_INVALID,
+		    "finish the batches in flight first (nxs_index_search_batch_end)");
+		return -1;
+	}
+	for (size_t i = 0; i < n; i++) {
+		resps[i] = NULL;
+		if (errs) {
+			errs[i] = NXS_ERR_SUCCESS;
 		}
 	}
-	free(prep);
-	free(plans);
-	free(plan_of);
-	return ret;
+	if (nxs_index_search_batch_begin(idx, params, queries, n) != 0) {
+		return -1;
+	}
+	return nxs_index_search_batch_end(idx, resps, errs);
 }
 
 /* nxs_index_search: search.c:285-342 (one query = a batch of one) */
@@ -796,15 +1438,61 @@ nxs_index_search(nxs_index_t *idx, nxs_params_t *params, const char *query, size
 {
 	nxs_resp_t *resp = NULL;
 	const char *qv[1] = { query };
+	nxsgpu_comm_t *comm = idx->comm;
+	int r;
 
 	(void)len;	/* the reference's lexer stops at the NUL byte too (search.c:177) */
-	if (nxs_index_search_batch(idx, params, qv, 1, &resp, NULL) != 0) {
+	idx->comm = NULL;	/* a single query is never sharded */
+	r = nxs_index_search_batch(idx, params, qv, 1, &resp, NULL);
+	idx->comm = comm;
+	if (r != 0) {
 		if (resp) {
 			nxs_resp_release(resp);
 		}
 		return NULL;
 	}
 	return resp;
+}
+
+/* ---- query sharding over the GPUs of a node ---------------------------------------- */
+
+int
+nxs_shard_unique_id(nxs_t *nxs, uint8_t *uid)
+{
+	nxs_clear_error(nxs);
+	if (nxsgpu_comm_unique_id(uid) != 0) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "%s", nxsgpu_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+int
+nxs_index_shard(nxs_index_t *idx, int rank, int world, const uint8_t *uid)
+{
+	nxs_t *nxs = idx->nxs;
+
+	nxs_clear_error(nxs);
+	if (pend_oldest(idx)) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "batches are in flight");
+		return -1;
+	}
+	if (idx->comm) {
+		(void)nxsgpu_index_set_comm(idx->dev, NULL);
+		nxsgpu_comm_destroy(idx->comm);
+		idx->comm = NULL;
+	}
+	if (world <= 1 && !uid) {
+		return 0;	/* detach */
+	}
+	idx->comm = nxsgpu_comm_create(idx->device, rank, world, uid);
+	if (!idx->comm || nxsgpu_index_set_comm(idx->dev, idx->comm) != 0) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "sharding setup failed: %s", nxsgpu_last_error());
+		nxsgpu_comm_destroy(idx->comm);
+		idx->comm = NULL;
+		return -1;
+	}
+	return 0;
 }
 
 /* ---- test hooks (host-only pieces, exercised without a GPU) ------------------------ */
@@ -858,6 +1546,108 @@ nxs_test_compile(const char *query, const char *const *words, uint32_t n_words,
 	*empty = q.empty;
 	nxs_query_release(&q);
 	return code;
+}
+
+/*
+ * The same for queries that take the wide plan: *wide = 1 and the plan's
+ * arrays are copied out (term_ids[cap_t], prog[cap_p]); returns the error code.
+ */
+int
+nxs_test_compile_wide(const char *query, const char *const *words, uint32_t n_words,
+    int *wide, uint32_t *n_tokens, uint32_t *term_ids, uint32_t cap_t,
+    uint32_t *prog_len, uint16_t *prog, uint32_t cap_p)
+{
+	nxs_index_t fake = { .lowercase = false };
+	qprep_t q;
+	int code;
+
+	nxs_query_prepare(&fake, query, &q);
+	if (!q.errcode) {
+		for (size_t j = 0; j < q.n_tokens; j++) {
+			/* words are "w<id>" here: resolve by number, not by search */
+			const char *v = q.tokens[j].value;
+			if (v[0] == 'w') {
+				const unsigned long id = strtoul(v + 1, NULL, 10);
+				if (id >= 1 && id <= n_words && strcmp(words[id - 1], v) == 0) {
+					q.tokens[j].term_id = (uint32_t)id;
+				}
+			}
+		}
+		(void)nxs_query_compile(&q);
+	}
+	code = q.errcode;
+	*wide = q.wide;
+	*n_tokens = q.wide ? q.wplan.n_tokens : q.plan.n_tokens;
+	*prog_len = q.wide ? q.wplan.prog_len : q.plan.prog_len;
+	if (q.wide && q.wplan.n_tokens <= cap_t && q.wplan.prog_len <= cap_p) {
+		memcpy(term_ids, q.wplan.term_id, q.wplan.n_tokens * sizeof(uint32_t));
+		memcpy(prog, q.wplan.prog, q.wplan.prog_len * sizeof(uint16_t));
+	}
+	nxs_query_release(&q);
+	return code;
+}
+
+/*
+ * Sharding without a second GPU.  nxs_test_shard_emulate(idx, r, W) makes the
+ * index play rank r of a W-rank run with the collective left out: the next
+ * batch plans and runs rank r's slice, and nxs_test_shard_block() hands out
+ * the record block it would have contributed to the all-gather (W = 0: off).
+ * nxs_test_pack_record() writes one record + status word into a block (a
+ * CPU-side stand-in for the device in the gloo test), and
+ * nxs_test_assemble() is the reassembly every rank runs on the gathered blocks.
+ */
+void
+nxs_test_shard_emulate(nxs_index_t *idx, int rank, int world)
+{
+	idx->emu_rank = rank;
+	idx->emu_world = world;
+}
+
+size_t
+nxs_test_shard_block(nxs_index_t *idx, uint8_t *out, size_t cap)
+{
+	if (out && idx->emu_block && idx->emu_block_len <= cap) {
+		memcpy(out, idx->emu_block, idx->emu_block_len);
+	}
+	return idx->emu_block ? idx->emu_block_len : 0;
+}
+
+void
+nxs_test_pack_record(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot,
+    uint32_t count, const uint64_t *ids, const float *scores, uint32_t status)
+{
+	uint8_t *rec = block + (size_t)slot * NXSGPU_REC_BYTES(k);
+	uint32_t *st = (uint32_t *)(block + (size_t)n_slots * NXSGPU_REC_BYTES(k));
+
+	((uint32_t *)rec)[0] = count;
+	((uint32_t *)rec)[1] = 0;
+	memcpy(rec + 8, ids, (size_t)count * 8);
+	memcpy(rec + 8 + 8 * (size_t)k, scores, (size_t)count * 4);
+	st[slot] = status;
+}
+
+int
+nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k,
+    size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_t fake;
+	slab_builder_t sb = { 0 };
+	int failed = 0;
+
+	memset(&fake, 0, sizeof(fake));
+	for (size_t i = 0; i < n; i++) {
+		resps[i] = NULL;
+		errs[i] = NXS_ERR_SUCCESS;
+	}
+	if (resps_from_blocks(&fake, NULL, n, world, n_slots, k, blocks, resps, errs, &sb, &failed) == -1) {
+		free(fake.errmsg);
+		return -1;
+	}
+	if (sb.slab && sb.slab->refs == 0) {
+		free(sb.slab);
+	}
+	free(fake.errmsg);
+	return failed;
 }
 
 /* host BK-tree image over a word list (ids 1..n), for structure tests */

@@ -39,7 +39,10 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>		/* types only: the library is dlopen()ed (rccl_api) */
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "nxs_gpu.h"
@@ -114,24 +117,94 @@ struct dev_query_t {
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
+/*
+ * Tuning / A-B switches (DESIGN.md "Switches"), read from the environment ONCE
+ * when the index is created (nxsgpu_index_reconfigure() re-reads them: tests
+ * and tools/ab.sh only) and range-checked there; the query path never calls
+ * getenv().
+ */
+struct gpu_cfg_t {
+	uint64_t	wave_target;	/* NXS_GPU_WAVES */
+	uint64_t	min_post;	/* NXS_GPU_MINPOST */
+	double		dense_thr;	/* NXS_GPU_DENSE (0 = posting-step path off) */
+	double		scanm_dens;	/* NXS_GPU_SCANM_DENS */
+	uint32_t	scanm_minnt, scanm_maxnt;
+	uint32_t	rmin;		/* fewest tokens for k_scanr (NXS_GPU_NOSCANR2 => 3) */
+	uint32_t	seg_cap;	/* NXS_GPU_SEGCAP */
+	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */
+	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
+	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
+};
+
+static void
+cfg_from_env(gpu_cfg_t &c)
+{
+	auto u64 = [](const char *name, uint64_t dflt, uint64_t lo, uint64_t hi) -> uint64_t {
+		const char *e = getenv(name);
+		if (!e || !*e) {
+			return dflt;
+		}
+		const uint64_t v = strtoull(e, NULL, 10);
+		return v < lo ? lo : v > hi ? hi : v;
+	};
+	auto dbl = [](const char *name, double dflt) -> double {
+		const char *e = getenv(name);
+		return (e && *e) ? atof(e) : dflt;
+	};
+	auto on = [](const char *name) -> bool { return getenv(name) != NULL; };
+
+	c.wave_target = u64("NXS_GPU_WAVES", 65536, 1, 1u << 22);
+	c.min_post = u64("NXS_GPU_MINPOST", 4096, 1, ~0ull);
+	c.dense_thr = dbl("NXS_GPU_DENSE", 0.0);
+	c.scanm_dens = dbl("NXS_GPU_SCANM_DENS", 0.08);
+	c.scanm_minnt = (uint32_t)u64("NXS_GPU_SCANM_MINNT", 2, 2, 8);
+	c.scanm_maxnt = (uint32_t)u64("NXS_GPU_SCANM_MAXNT", 8, 2, 8);
+	c.rmin = on("NXS_GPU_NOSCANR2") ? 3u : 2u;
+	c.seg_cap = (uint32_t)u64("NXS_GPU_SEGCAP", SEG_CAP_DEFAULT, 1, 1u << 16);
+	c.fuzzy_items = u64("NXS_GPU_FUZZY_ITEMS", 256ull << 20, 1, 1ull << 32);
+	c.use_scanr = !on("NXS_GPU_NOSCANR");
+	c.no_step = on("NXS_GPU_NOSTEP");
+	c.mask_off = !on("NXS_GPU_NOMASKOFF");
+	c.by_level = !on("NXS_GPU_NOLEVELS");
+	c.use_scanm = !on("NXS_GPU_NOSCANM");
+	c.scanm_general = !on("NXS_GPU_SCANM_ORONLY");
+	c.old_scan = on("NXS_GPU_OLDSCAN");
+	c.no_scan1 = on("NXS_GPU_NOSCAN1");
+	c.no_req = on("NXS_GPU_NOREQ");
+	c.one_replay = on("NXS_GPU_ONEREPLAY");
+	c.fuzzy_safe = on("NXS_GPU_FUZZY_SAFE");
+	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
+}
+
 struct nxsgpu_index {
 	int		device;
+	gpu_cfg_t	cfg;
 	hipStream_t	stream;
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
 	hipEvent_t	ev_cls, ev_join;
 	/* nxsgpu_search_dev_begin/_end: two batches in flight, each with its own
 	 * device workspace and pinned staging; plans go up on their own stream */
 	hipStream_t	stream_up;
+	hipStream_t	stream_down;	/* record blocks: all-gather (sharded) + copy to pinned memory */
+	struct nxsgpu_comm *comm;	/* attached communicator (query sharding) or NULL */
 	struct dev_slot_t {
 		void *		ws;
 		size_t		ws_len;
 		uint8_t *	h_stage;	/* pinned: uploads, then the overflow flags coming back */
 		size_t		h_stage_len;
-		hipEvent_t	ev_up, ev_done, ev_t[3];
+		hipEvent_t	ev_up, ev_done, ev_res, ev_t[3];
 		bool		active;
+		bool		records;	/* nxsgpu_batch_begin: results as record blocks */
 		uint32_t	nq;
 		uint64_t	postings;
 		uint64_t	seq;
+		/* record mode */
+		uint8_t *	d_blocks;	/* device: world blocks (own block first when world == 1) */
+		size_t		d_blocks_len;
+		uint8_t *	h_blocks;	/* pinned: world blocks */
+		size_t		h_blocks_len;
+		uint32_t	n_slots, k, world;
+		size_t		rec_bytes, block_bytes;
 	}		slot[2];
 	uint64_t	slot_seq;
 
@@ -3001,6 +3074,11 @@ struct replay_args_t {
 	const uint64_t *	out_off;	/* [Q+1] or NULL => q * k */
 	const uint32_t *	skip;		/* [Q] nonzero => leave untouched */
 	const uint32_t *	qlist;		/* NULL, or the queries this launch replays (blockIdx -> query) */
+	/* record mode (nxsgpu_batch_begin): the result of query q goes to the
+	 * fixed-size record rec_base + rec_slot[q] * rec_bytes instead of out_* */
+	uint8_t *		rec_base;
+	const uint32_t *	rec_slot;
+	uint32_t		rec_bytes;
 };
 
 template <bool LDS_HEAP>
@@ -3018,6 +3096,11 @@ k_replay(const replay_args_t A)
 	uint32_t *hd, cap;
 
 	if (A.skip && A.skip[q]) {
+		/* the query overflowed its candidate segments: its record says so (the
+		 * owner re-runs it on the exact path; with sharding every rank sees it) */
+		if (A.rec_base && lane == 0) {
+			((uint32_t *)(A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes))[1] = NXSGPU_REC_INEXACT;
+		}
 		return;
 	}
 	if (LDS_HEAP) {
@@ -3141,6 +3224,20 @@ k_replay(const replay_args_t A)
 		}
 	}
 	__syncthreads();
+	if (A.rec_base) {
+		/* u32 count | u32 flags | u64 ids[k] | f32 scores[k]  (nxs_gpu.h) */
+		uint8_t *rec = A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes;
+		uint64_t *r_ids = (uint64_t *)(rec + 8);
+		float *r_sc = (float *)(rec + 8 + 8 * (size_t)A.k);
+		for (uint32_t i = lane; i < cnt; i += WAVE) {
+			r_ids[i] = A.doc_ids[hd[i]];
+			r_sc[i] = hs[i];
+		}
+		if (lane == 0) {
+			((uint32_t *)rec)[0] = cnt;
+		}
+		return;
+	}
 	const uint64_t ob = A.out_off ? A.out_off[q] : (uint64_t)q * A.k;
 	for (uint32_t i = lane; i < cnt; i += WAVE) {
 		A.out_ids[ob + i] = A.doc_ids[hd[i]];
@@ -3148,6 +3245,208 @@ k_replay(const replay_args_t A)
 	}
 	if (lane == 0) {
 		A.out_count[q] = cnt;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* k_scanw: queries beyond the fixed-size plan (> 32 tokens, long or   */
+/* deeply nested programs)                                             */
+/* ------------------------------------------------------------------ */
+
+/*
+ * The reference puts no bound on the number of query terms
+ * (run_query_logic, search.c:210-278, loops over a list).  Such queries are
+ * rare; they take this generic kernel on the exact two-pass path (count, emit
+ * all, global-memory heap replay): the same tile scheme as k_scan -- f32 sums
+ * in token-list order, tiles visited from the highest doc down -- with a
+ * presence BITSET of W words per doc instead of one mask word, and the
+ * postfix program evaluated on a 128-deep bit stack (the nesting limit of 100,
+ * search.c:70, bounds the stack at 101).
+ */
+#define	WTILE		512
+
+struct wide_dev_t {
+	uint32_t	nt, prog_len;
+	uint64_t	tok_base;	/* into wtok: nt x (pbeg, pend) */
+	uint64_t	prog_base;	/* into wprog */
+};
+
+struct wide_args_t {
+	const posting_t *	post;
+	const wide_dev_t *	wq;
+	const uint64_t *	wtok;
+	const uint16_t *	wprog;
+	const qmeta_t *		qmeta;
+	const item_t *		items;
+	uint64_t		n_docs;
+	uint32_t		W;		/* mask words per doc */
+	uint32_t		nt_max, prog_max;
+	uint32_t *		seg_count;
+	const uint64_t *	seg_off;
+	uint32_t *		cand_doc;
+	float *			cand_sc;
+};
+
+__device__ static inline bool
+eval_wide(const uint16_t *prog, uint32_t len, const uint32_t *mask)
+{
+	uint64_t lo = 0, hi = 0;	/* bit stack, top at bit 0 of lo */
+
+	for (uint32_t i = 0; i < len; i++) {
+		const uint32_t op = prog[i];
+		if (op < 0x8000u || op == NXSGPU_WOP_EMPTY) {
+			const uint64_t b = (op < 0x8000u) ? ((mask[op >> 5] >> (op & 31)) & 1u) : 0u;
+			hi = (hi << 1) | (lo >> 63);
+			lo = (lo << 1) | b;
+		} else {
+			const uint64_t b = lo & 1, a = (lo >> 1) & 1;
+			uint64_t r;
+			if (op == NXSGPU_WOP_AND) r = a & b;
+			else if (op == NXSGPU_WOP_OR) r = a | b;
+			else r = a & ~b & 1;
+			lo = (lo >> 1) | (hi << 63);
+			hi >>= 1;
+			lo = (lo & ~1ull) | r;
+		}
+	}
+	return lo & 1;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(WAVE)
+k_scanw(const wide_args_t A)
+{
+	extern __shared__ uint64_t smem_w[];
+	const uint32_t W = A.W;
+	uint64_t *s_hi = smem_w;
+	uint64_t *s_lo = s_hi + A.nt_max;
+	int64_t *s_pdoc = (int64_t *)(s_lo + A.nt_max);
+	float *s_acc = (float *)(s_pdoc + A.nt_max);
+	uint32_t *s_touch = (uint32_t *)(s_acc + WTILE);
+	uint32_t *s_mask = s_touch + WTILE;
+	uint16_t *s_prog = (uint16_t *)(s_mask + (size_t)WTILE * W);
+
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const wide_dev_t Q = A.wq[q];
+	const uint32_t nt = Q.nt;
+	const posting_t *__restrict__ post = A.post;
+	const uint64_t *tok = A.wtok + Q.tok_base;
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t d_lo = min((uint64_t)g * qm.group_docs, A.n_docs);
+	const uint64_t d_hi = (g + 1 == qm.n_groups) ? A.n_docs : min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
+
+	for (uint32_t i = lane; i < WTILE; i += WAVE) {
+		s_acc[i] = 0.0f;
+		s_touch[i] = 0;
+	}
+	for (uint32_t i = lane; i < WTILE * W; i += WAVE) {
+		s_mask[i] = 0;
+	}
+	for (uint32_t i = lane; i < Q.prog_len; i += WAVE) {
+		s_prog[i] = A.wprog[Q.prog_base + i];
+	}
+	for (uint32_t t = lane; t < nt; t += WAVE) {
+		const uint64_t pb = tok[2 * t], pe = tok[2 * t + 1];
+		const uint64_t l = post_lower_bound(post, pb, pe, d_lo);
+		const uint64_t h = (d_hi >= A.n_docs) ? pe : post_lower_bound(post, l, pe, d_hi);
+		s_lo[t] = l;
+		s_hi[t] = h;
+		s_pdoc[t] = (h > l) ? (int64_t)post[h - 1].doc : -1;
+	}
+	__syncthreads();
+
+	uint32_t n_out = 0;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : 0;
+
+	for (;;) {
+		int64_t md = -1;
+		for (uint32_t t = lane; t < nt; t += WAVE) {
+			md = max(md, s_pdoc[t]);
+		}
+		for (int o = 32; o; o >>= 1) {
+			const int64_t other = ((int64_t)__shfl((int)(md >> 32), (int)(lane ^ o)) << 32) |
+			    (uint32_t)__shfl((int)(uint32_t)md, (int)(lane ^ o));
+			md = max(md, other);
+		}
+		if (md < 0) {
+			break;
+		}
+		const uint32_t base = (uint32_t)((uint64_t)md / WTILE) * WTILE;
+
+		/* tokens strictly in token-list order (results.c:134-136) */
+		for (uint32_t t = 0; t < nt; t++) {
+			if (s_pdoc[t] < (int64_t)base) {
+				continue;
+			}
+			uint64_t hi = s_hi[t];
+			const uint64_t lo = s_lo[t];
+			int64_t pdoc = -1;
+			while (hi > lo) {
+				const int64_t i = (int64_t)hi - WAVE + lane;
+				const bool valid = i >= (int64_t)lo;
+				posting_t p;
+				p.doc = 0; p.imp = 0.0f;
+				if (valid) {
+					p = post[i];
+				}
+				const bool in = valid && p.doc >= base;
+				const uint32_t c = __popcll(ballot64(in));
+				if (in) {
+					const uint32_t d = p.doc - base;
+					s_acc[d] += p.imp;
+					s_mask[(size_t)d * W + (t >> 5)] |= 1u << (t & 31);
+					s_touch[d] = 1;
+				}
+				hi -= c;
+				if (c < WAVE) {
+					if (hi > lo) {
+						pdoc = (int64_t)(uint32_t)__shfl((int)p.doc, WAVE - 1 - c);
+					}
+					break;
+				}
+			}
+			__syncthreads();	/* single wavefront: orders the LDS updates */
+			if (lane == 0) {
+				s_hi[t] = hi;
+				s_pdoc[t] = pdoc;
+			}
+			__syncthreads();
+		}
+
+		/* descending doc order (results.c:143-147) */
+		for (int s = WTILE / WAVE - 1; s >= 0; s--) {
+			const uint32_t d = s * WAVE + lane;
+			const bool touched = s_touch[d] != 0;
+			if (ballot64(touched) == 0) {
+				continue;
+			}
+			float sc = 0.0f;
+			bool match = false;
+			if (touched) {
+				sc = s_acc[d];
+				match = eval_wide(s_prog, Q.prog_len, &s_mask[(size_t)d * W]);
+				s_acc[d] = 0.0f;
+				s_touch[d] = 0;
+				for (uint32_t w = 0; w < W; w++) {
+					s_mask[(size_t)d * W + w] = 0;
+				}
+			}
+			const uint64_t bal = ballot64(match);
+			if (MODE == MODE_ALL && match) {
+				const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+				const uint64_t o = out_base + n_out + __popcll(above);
+				A.cand_doc[o] = base + d;
+				A.cand_sc[o] = sc;
+			}
+			n_out += __popcll(bal);
+		}
+		__syncthreads();
+	}
+	if (MODE == MODE_COUNT && lane == 0) {
+		A.seg_count[seg] = n_out;
 	}
 }
 
@@ -3173,6 +3472,8 @@ struct fz_args_t {
 	uint16_t *		dp_rows;	/* scratch for tokens > 64 bytes */
 	uint32_t		dp_stride;
 	uint32_t *		overflow;
+	uint32_t		prune;		/* drop (token, node) pairs that can no longer win */
+	unsigned long long *	evals;		/* distance evaluations (profiling) or NULL */
 };
 
 /* distance between token `tok` and the node's term */
@@ -3264,6 +3565,7 @@ k_bk_level(const fz_args_t A)
 	const uint32_t nthreads = gridDim.x * blockDim.x;
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t rounds = (count + nthreads - 1) / nthreads;
+	uint32_t n_eval = 0;
 
 	for (uint32_t r = 0; r < rounds; r++) {
 		const uint32_t i = r * nthreads + tid;
@@ -3274,9 +3576,24 @@ k_bk_level(const fz_args_t A)
 			const fz_item_t it = A.cur[i];
 			const uint32_t m = A.tok_off[it.tok + 1] - A.tok_off[it.tok];
 			tok = it.tok;
-			if (LONG == (m > NXS_MYERS_MAXPAT)) {
+			/*
+			 * Exact pruning.  The answer is the match of LOWEST BFS rank
+			 * (idxterm.c:238-242: first pushed with total > 0; Q7), a node's
+			 * descendants all have higher ranks than the node itself (BFS
+			 * numbering), and best[tok] only ever decreases.  So once a usable
+			 * match of rank r is known, a pair whose node has rank > r can
+			 * neither be nor lead to the winner: it is dropped without a distance
+			 * computation and without children.  Any value read here -- stale or
+			 * written by a concurrent lane of this very level -- is the rank of a
+			 * real match, hence a valid bound.  (Off when the caller wants the
+			 * reference's visit counts.)
+			 */
+			const bool dead = A.prune && __hip_atomic_load(&A.best[it.tok], __ATOMIC_RELAXED,
+			    __HIP_MEMORY_SCOPE_AGENT) < it.node;
+			if (!dead && LONG == (m > NXS_MYERS_MAXPAT)) {
 				const nxsgpu_bknode_t nd = A.bk[it.node];
 				const int d = fz_distance(A, it.tok, nd, tid);
+				n_eval++;
 				if (A.visited) {
 					atomicAdd(&A.visited[it.tok], 1ull);
 				}
@@ -3340,6 +3657,14 @@ k_bk_level(const fz_args_t A)
 				*A.overflow = 1;
 			}
 			o++;
+		}
+	}
+	if (A.evals) {
+		for (int o = 32; o; o >>= 1) {
+			n_eval += (uint32_t)__shfl_xor((int)n_eval, o);
+		}
+		if (lane == 0 && n_eval) {
+			atomicAdd(A.evals, (unsigned long long)n_eval);
 		}
 	}
 }
@@ -3485,12 +3810,20 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 		}
 		if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
 		if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+		if (sl.ev_res) (void)hipEventDestroy(sl.ev_res);
+		(void)hipFree(sl.d_blocks);
+		if (sl.h_blocks) {
+			(void)hipHostFree(sl.h_blocks);
+		}
 		for (int j = 0; j < 3; j++) {
 			if (sl.ev_t[j]) (void)hipEventDestroy(sl.ev_t[j]);
 		}
 	}
 	if (ix->stream_up) {
 		(void)hipStreamDestroy(ix->stream_up);
+	}
+	if (ix->stream_down) {
+		(void)hipStreamDestroy(ix->stream_down);
 	}
 	if (ix->ev_cls) {
 		(void)hipEventDestroy(ix->ev_cls);
@@ -3528,6 +3861,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	unsigned int h_max_tf = 0;
 
 	ix->device = device;
+	cfg_from_env(ix->cfg);
 	ix->n_docs = D;
 	ix->n_post = P;
 	ix->n_terms = T;
@@ -3546,9 +3880,11 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_res, hipEventDisableTiming));
 		for (int j = 0; j < 3; j++) {
 			HIP_TRY(hipEventCreate(&ix->slot[i].ev_t[j]));
 		}
@@ -3793,23 +4129,20 @@ static void
 build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl)
 {
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
-	const char *env = getenv("NXS_GPU_WAVES");
-	const uint64_t target = env ? strtoull(env, NULL, 10) : 65536;
-	const char *env2 = getenv("NXS_GPU_MINPOST");
-	const uint64_t min_post = env2 ? strtoull(env2, NULL, 10) : 4096;
-	/* densest term has >= this many postings per tile => tile path */
-	const char *env3 = getenv("NXS_GPU_DENSE");
-	const double dense_thr = env3 ? atof(env3) : 0.0;	/* step path off by default: the tile path is at least as fast */
-	const bool use_scanr = !getenv("NXS_GPU_NOSCANR") && ix->n_docs < (1ull << 31);
-	const bool no_step = getenv("NXS_GPU_NOSTEP") != NULL, mask_off = !getenv("NXS_GPU_NOMASKOFF");
-	const uint32_t rmin = getenv("NXS_GPU_NOSCANR2") ? 3u : 2u;	/* else "a AND b" takes k_scan8's sign-bit path */
-	const bool by_level = !getenv("NXS_GPU_NOLEVELS");
-	const bool use_scanm = !getenv("NXS_GPU_NOSCANM") && ix->n_docs < (1ull << 31);
-	const bool scanm_general = !getenv("NXS_GPU_SCANM_ORONLY");
-	const uint32_t scanm_minnt = getenv("NXS_GPU_SCANM_MINNT") ? (uint32_t)atoi(getenv("NXS_GPU_SCANM_MINNT")) : 2;
-	const uint32_t scanm_maxnt = getenv("NXS_GPU_SCANM_MAXNT") ? (uint32_t)atoi(getenv("NXS_GPU_SCANM_MAXNT")) : 8;
+	const gpu_cfg_t &cf = ix->cfg;
+	const uint64_t target = cf.wave_target, min_post = cf.min_post;
+	/* densest term has >= this many postings per tile => tile path (step path
+	 * off by default: the tile path is at least as fast) */
+	const double dense_thr = cf.dense_thr;
+	const bool use_scanr = cf.use_scanr && ix->n_docs < (1ull << 31);
+	const bool no_step = cf.no_step, mask_off = cf.mask_off;
+	const uint32_t rmin = cf.rmin;	/* 3: "a AND b" takes k_scan8's sign-bit path */
+	const bool by_level = cf.by_level;
+	const bool use_scanm = cf.use_scanm && ix->n_docs < (1ull << 31);
+	const bool scanm_general = cf.scanm_general;
+	const uint32_t scanm_minnt = cf.scanm_minnt, scanm_maxnt = cf.scanm_maxnt;
 	/* k_scanm if the densest list holds at most this fraction of the docs */
-	const double scanm_dens = getenv("NXS_GPU_SCANM_DENS") ? atof(getenv("NXS_GPU_SCANM_DENS")) : 0.08;
+	const double scanm_dens = cf.scanm_dens;
 	std::vector<uint64_t> work(nq);
 	std::vector<uint32_t> order(nq), cls(nq);
 	uint64_t total = 0;
@@ -4020,12 +4353,12 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 		a.item_base = l.first;
 		if (l.kind == 0) {
 			hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
-		} else if (getenv("NXS_GPU_OLDSCAN") || ix->n_docs >= (1ull << 31)) {
+		} else if (ix->cfg.old_scan || ix->n_docs >= (1ull << 31)) {
 			hipLaunchKernelGGL((k_scan<8, uint8_t, MODE>), grid, block, 0, ix->stream, a);
 		} else if (l.kind == 1) {
 			switch (l.nt_bucket) {
 			case 1:
-				if (getenv("NXS_GPU_NOSCAN1")) {
+				if (ix->cfg.no_scan1) {
 					hipLaunchKernelGGL((k_scan8<MODE, 1, 0>), grid, block, 0, ix->stream, a);
 				} else {
 					hipLaunchKernelGGL((k_scan1<MODE>), grid, block, 0, ix->stream, a);
@@ -4128,7 +4461,7 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
     dev_query_t *hq, uint64_t &total_post)
 {
 	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
-	const bool no_req = getenv("NXS_GPU_NOREQ") != NULL;
+	const bool no_req = ix->cfg.no_req;
 
 	for (uint32_t i = 0; i < nq; i++) {
 		const nxsgpu_query_t &q = queries[i];
@@ -4194,7 +4527,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
     uint32_t nq, nxsgpu_results_t *res)
 {
 	const bool fast = limit <= NXSGPU_FAST_K;
-	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
+	const uint32_t seg_cap = ix->cfg.seg_cap;
 	std::vector<dev_query_t> hq(nq);
 	std::vector<uint32_t> h_ovf, h_cnt;
 	worklist_t wl;
@@ -4321,7 +4654,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		ra.out_sc = d_sc;
 		ra.out_count = d_cnt;
 		ra.skip = d_ovf;
-		if (getenv("NXS_GPU_ONEREPLAY")) {
+		if (ix->cfg.one_replay) {
 			launch_scan<MODE_TOPK>(ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
 			hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
@@ -4566,10 +4899,7 @@ extern "C" int
 nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, nxsgpu_results_t *res)
 {
-	if (ix->slot[0].active || ix->slot[1].active) {
-		set_error("nxsgpu_search: finish the batches in flight first (nxsgpu_search_dev_end)");
-		return -1;
-	}
+	/* (runs behind the batches in flight, if any: same stream, own workspace) */
 	return search_impl(ix, algo, limit, queries, nq, res);
 }
 
@@ -4612,17 +4942,47 @@ slot_ensure(nxsgpu_index::dev_slot_t &sl, size_t ws_need, size_t stage_need)
 	return 0;
 }
 
-extern "C" int
-nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
-    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+/* what a batch writes its results to */
+struct batch_out_t {
+	/* caller's device arrays [nq][limit] / [nq] (nxsgpu_search_dev_begin) ... */
+	uint64_t *	d_ids;
+	float *		d_sc;
+	uint32_t *	d_cnt;
+	/* ... or record blocks (nxsgpu_batch_begin) */
+	bool		records, gather;
+	const uint32_t *slot_of_plan;
+	const uint32_t *status;
+	uint32_t	n_slots;
+};
+
+/* a failed _begin must not leave kernels queued over a slot it reports free */
+static int
+begin_fail(nxsgpu_index_t *ix)
 {
-	const uint32_t seg_cap = getenv("NXS_GPU_SEGCAP") ? (uint32_t)atoi(getenv("NXS_GPU_SEGCAP")) : SEG_CAP_DEFAULT;
+	(void)hipStreamSynchronize(ix->stream_up);
+	(void)hipStreamSynchronize(ix->stream);
+	(void)hipStreamSynchronize(ix->stream2);
+	(void)hipStreamSynchronize(ix->stream_down);
+	(void)hipGetLastError();
+	return -1;
+}
+
+static int comm_allgather_dev(nxsgpu_comm_t *, const void *, void *, size_t, hipStream_t);
+
+static int
+batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, const batch_out_t &o)
+{
+	const uint32_t seg_cap = ix->cfg.seg_cap;
 	nxsgpu_index::dev_slot_t *sl = NULL;
 	worklist_t wl;
 	uint64_t total_post = 0;
+	const bool gather = o.records && o.gather && ix->comm;
+	const uint32_t world = gather ? (uint32_t)nxsgpu_comm_world(ix->comm) : 1u;
+	const int my_rank = gather ? nxsgpu_comm_rank(ix->comm) : 0;
 
-	if (limit == 0 || limit > NXSGPU_FAST_K || !d_doc_ids || !d_scores || !d_counts) {
-		set_error("nxsgpu_search_dev: limit must be 1..%d and outputs non-NULL", NXSGPU_FAST_K);
+	if (limit == 0 || limit > NXSGPU_FAST_K) {
+		set_error("device batches take limit 1..%d", NXSGPU_FAST_K);
 		return -1;
 	}
 	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
@@ -4640,23 +5000,59 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 		}
 	}
 	if (!sl) {
-		set_error("nxsgpu_search_dev_begin: two batches are already in flight");
+		set_error("two batches are already in flight");
 		return -1;
 	}
 	sl->nq = nq;
 	sl->postings = 0;
-	sl->seq = ++ix->slot_seq;
-	if (nq == 0) {
+	sl->records = o.records;
+	sl->n_slots = o.n_slots;
+	sl->k = limit;
+	sl->world = world;
+	sl->rec_bytes = NXSGPU_REC_BYTES(limit);
+	sl->block_bytes = o.records ? NXSGPU_BLOCK_BYTES(o.n_slots, limit) : 0;
+	if (nq == 0 && !o.records) {
+		sl->seq = ++ix->slot_seq;
 		sl->active = true;
 		return 0;
 	}
 
+	/* record blocks: device (world blocks; this rank's own one is the send
+	 * buffer, at its rank position) and pinned host copies */
+	uint8_t *d_myblock = NULL;
+	if (o.records) {
+		const size_t need = (size_t)world * sl->block_bytes + 256;
+		if (sl->d_blocks_len < need) {
+			(void)hipFree(sl->d_blocks);
+			sl->d_blocks = NULL;
+			sl->d_blocks_len = 0;
+			if (hipMalloc((void **)&sl->d_blocks, need) != hipSuccess) {
+				set_error("hipMalloc(%zu) for the record blocks failed", need);
+				return -1;
+			}
+			sl->d_blocks_len = need;
+		}
+		if (sl->h_blocks_len < need) {
+			if (sl->h_blocks) {
+				(void)hipHostFree(sl->h_blocks);
+			}
+			sl->h_blocks = NULL;
+			sl->h_blocks_len = 0;
+			if (hipHostMalloc((void **)&sl->h_blocks, need, hipHostMallocDefault) != hipSuccess) {
+				set_error("hipHostMalloc(%zu) failed", need);
+				return -1;
+			}
+			sl->h_blocks_len = need;
+		}
+		d_myblock = sl->d_blocks + (size_t)my_rank * sl->block_bytes;
+	}
+
 	/* plans straight into the pinned staging area (room for the work list:
 	 * <= target + nq ranges, see build_worklist) */
-	const uint64_t wave_target = getenv("NXS_GPU_WAVES") ? strtoull(getenv("NXS_GPU_WAVES"), NULL, 10) : 65536;
+	const uint64_t wave_target = ix->cfg.wave_target;
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
-	const size_t stage_need = 8192 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 8)
-	    + seg_bound * (sizeof(item_t) + 4) + nq * 4;
+	const size_t stage_need = 16384 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 12)
+	    + seg_bound * (sizeof(item_t) + 4) + nq * 4 + (size_t)o.n_slots * 4;
 	if (slot_ensure(*sl, 0, stage_need) != 0) {
 		return -1;
 	}
@@ -4675,12 +5071,30 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	item_t *h_items = carve<item_t>(hp, nseg);
 	uint32_t *h_bnd_q = carve<uint32_t>(hp, nseg + nq);
 	uint32_t *h_qorder = carve<uint32_t>(hp, nq);
+	uint32_t *h_recslot = carve<uint32_t>(hp, nq);
 	const size_t up_len = (size_t)(hp - sl->h_stage);
 	uint32_t *h_ovf = carve<uint32_t>(hp, nq);
-	memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
-	memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));
-	memcpy(h_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4);
-	memcpy(h_qorder, wl.qorder.data(), nq * 4);
+	uint32_t *h_status = carve<uint32_t>(hp, o.n_slots);
+	if (nq) {
+		memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
+		memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));
+		memcpy(h_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4);
+		memcpy(h_qorder, wl.qorder.data(), nq * 4);
+	}
+	if (o.records) {
+		for (uint32_t i = 0; i < nq; i++) {
+			if (o.slot_of_plan[i] >= o.n_slots) {
+				set_error("plan %u: record slot %u out of range", i, o.slot_of_plan[i]);
+				return -1;
+			}
+			h_recslot[i] = o.slot_of_plan[i];
+		}
+		if (o.status) {
+			memcpy(h_status, o.status, (size_t)o.n_slots * 4);
+		} else {
+			memset(h_status, 0, (size_t)o.n_slots * 4);
+		}
+	}
 
 	/* device workspace: the uploaded block first (same carve sequence => same
 	 * offsets), then what only the kernels touch */
@@ -4695,6 +5109,7 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	item_t *d_items = carve<item_t>(p, nseg);
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
 	uint32_t *d_qorder = carve<uint32_t>(p, nq);
+	uint32_t *d_recslot = carve<uint32_t>(p, nq);
 	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
 	uint32_t *d_ovf = carve<uint32_t>(p, nq);
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
@@ -4702,11 +5117,21 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
 
+	sl->seq = ++ix->slot_seq;
 	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, ix->stream_up) != hipSuccess ||
-	    hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream_up) != hipSuccess ||
-	    hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream_up) != hipSuccess) {
+	    (nq && hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream_up) != hipSuccess) ||
+	    (nseg && hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream_up) != hipSuccess)) {
 		set_error("query upload failed");
-		return -1;
+		return begin_fail(ix);
+	}
+	if (o.records) {
+		const size_t recs = (size_t)o.n_slots * sl->rec_bytes;
+		if ((recs && hipMemsetAsync(d_myblock, 0, recs, ix->stream_up) != hipSuccess) ||
+		    (o.n_slots && hipMemcpyAsync(d_myblock + recs, h_status, (size_t)o.n_slots * 4,
+		    hipMemcpyHostToDevice, ix->stream_up) != hipSuccess)) {
+			set_error("record block setup failed");
+			return begin_fail(ix);
+		}
 	}
 
 	scan_args_t sa;
@@ -4733,41 +5158,81 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 	ra.cand_sc = d_cand_sc;
 	ra.doc_ids = ix->d_doc_ids;
 	ra.k = limit;
-	ra.out_ids = d_doc_ids;
-	ra.out_sc = d_scores;
-	ra.out_count = d_counts;
+	ra.out_ids = o.d_ids;
+	ra.out_sc = o.d_sc;
+	ra.out_count = o.d_cnt;
 	ra.skip = d_ovf;
+	if (o.records) {
+		ra.rec_base = d_myblock;
+		ra.rec_slot = d_recslot;
+		ra.rec_bytes = (uint32_t)sl->rec_bytes;
+	}
 
 	/*
 	 * The range cursors depend on the uploaded plans only: k_cursors (a small,
 	 * latency-bound grid of binary searches) runs on the upload stream, beside
 	 * the previous batch's scans instead of in front of this batch's.
 	 */
-	launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), ix->stream_up);
+	if (nq) {
+		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), ix->stream_up);
+	}
 	if (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
 	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess) {
 		set_error("query upload failed");
-		return -1;
+		return begin_fail(ix);
 	}
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
-	if (getenv("NXS_GPU_ONEREPLAY")) {
-		launch_scan<MODE_TOPK>(ix, sa, wl);
-		if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
-		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
-	} else {
-		/* (profile: "replay" is then only what the last class's replay adds
-		 * after the last scan) */
-		launch_scan<MODE_TOPK>(ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL);
+	if (nq) {
+		if (ix->cfg.one_replay) {
+			launch_scan<MODE_TOPK>(ix, sa, wl);
+			if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
+			hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		} else {
+			/* (profile: "replay" is then only what the last class's replay adds
+			 * after the last scan) */
+			launch_scan<MODE_TOPK>(ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL);
+		}
+	} else if (ix->profiling) {
+		(void)hipEventRecord(sl->ev_t[1], ix->stream);
 	}
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], ix->stream);
 	if (hipGetLastError() != hipSuccess) {
 		set_error("kernel launch failed");
-		return -1;
+		return begin_fail(ix);
 	}
-	if (hipMemcpyAsync(h_ovf, d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-	    hipEventRecord(sl->ev_done, ix->stream) != hipSuccess) {
-		set_error("copy failed");
-		return -1;
+	if (!o.records) {
+		if (hipMemcpyAsync(h_ovf, d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipEventRecord(sl->ev_done, ix->stream) != hipSuccess) {
+			set_error("copy failed");
+			return begin_fail(ix);
+		}
+	} else {
+		/*
+		 * The records leave on their own stream: the all-gather (one collective
+		 * per batch, sharded runs only) and the copy to pinned memory overlap the
+		 * next batch's scans instead of sitting in front of them.
+		 */
+		uint8_t *src = d_myblock;
+		size_t len = sl->block_bytes;
+		if (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
+		    hipStreamWaitEvent(ix->stream_down, sl->ev_res, 0) != hipSuccess) {
+			set_error("event failed");
+			return begin_fail(ix);
+		}
+		if (world > 1) {
+			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes,
+			    ix->stream_down) != 0) {
+				return begin_fail(ix);
+			}
+			src = sl->d_blocks;
+			len = (size_t)world * sl->block_bytes;
+		}
+		if ((len && hipMemcpyAsync(sl->h_blocks + (src - sl->d_blocks), src, len, hipMemcpyDeviceToHost,
+		    ix->stream_down) != hipSuccess) ||
+		    hipEventRecord(sl->ev_done, ix->stream_down) != hipSuccess) {
+			set_error("copy failed");
+			return begin_fail(ix);
+		}
 	}
 	sl->postings = total_post;
 	sl->active = true;
@@ -4775,7 +5240,44 @@ nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsg
 }
 
 extern "C" int
-nxsgpu_search_dev_end(nxsgpu_index_t *ix)
+nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+{
+	batch_out_t o;
+
+	memset(&o, 0, sizeof(o));
+	if (!d_doc_ids || !d_scores || !d_counts) {
+		set_error("nxsgpu_search_dev: outputs must be non-NULL");
+		return -1;
+	}
+	o.d_ids = d_doc_ids;
+	o.d_sc = d_scores;
+	o.d_cnt = d_counts;
+	return batch_begin(ix, algo, limit, queries, nq, o);
+}
+
+extern "C" int
+nxsgpu_batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *plans,
+    uint32_t n_plans, const uint32_t *slot_of_plan, const uint32_t *status, uint32_t n_slots,
+    int gather)
+{
+	batch_out_t o;
+
+	memset(&o, 0, sizeof(o));
+	if (n_plans && !slot_of_plan) {
+		set_error("nxsgpu_batch_begin: slot_of_plan is NULL");
+		return -1;
+	}
+	o.records = true;
+	o.gather = gather != 0;
+	o.slot_of_plan = slot_of_plan;
+	o.status = status;
+	o.n_slots = n_slots;
+	return batch_begin(ix, algo, limit, plans, n_plans, o);
+}
+
+static nxsgpu_index::dev_slot_t *
+oldest_slot(nxsgpu_index_t *ix)
 {
 	nxsgpu_index::dev_slot_t *sl = NULL;
 
@@ -4784,19 +5286,17 @@ nxsgpu_search_dev_end(nxsgpu_index_t *ix)
 			sl = &ix->slot[i];
 		}
 	}
-	if (!sl) {
-		set_error("nxsgpu_search_dev_end: no batch in flight");
-		return -1;
-	}
-	sl->active = false;
-	if (sl->nq == 0) {
-		return 0;
-	}
+	return sl;
+}
+
+static int
+slot_wait(nxsgpu_index_t *ix, nxsgpu_index::dev_slot_t *sl)
+{
 	if (hipEventSynchronize(sl->ev_done) != hipSuccess) {
 		set_error("batch failed: %s", hipGetErrorString(hipGetLastError()));
 		return -1;
 	}
-	if (ix->profiling) {
+	if (ix->profiling && (sl->nq || sl->records)) {
 		float a = 0, b = 0;
 		(void)hipEventElapsedTime(&a, sl->ev_t[0], sl->ev_t[1]);
 		(void)hipEventElapsedTime(&b, sl->ev_t[1], sl->ev_t[2]);
@@ -4804,6 +5304,29 @@ nxsgpu_search_dev_end(nxsgpu_index_t *ix)
 		ix->prof.scan_ms += a;
 		ix->prof.replay_ms += b;
 		ix->prof.postings += sl->postings;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search_dev_end(nxsgpu_index_t *ix)
+{
+	nxsgpu_index::dev_slot_t *sl = oldest_slot(ix);
+
+	if (!sl) {
+		set_error("nxsgpu_search_dev_end: no batch in flight");
+		return -1;
+	}
+	if (sl->records) {
+		set_error("nxsgpu_search_dev_end: the oldest batch in flight is a record batch (nxsgpu_batch_end)");
+		return -1;
+	}
+	sl->active = false;
+	if (sl->nq == 0) {
+		return 0;
+	}
+	if (slot_wait(ix, sl) != 0) {
+		return -1;
 	}
 	/* the flags sit behind the uploaded block, same carve sequence as _begin */
 	uint8_t *hp = sl->h_stage;
@@ -4813,6 +5336,7 @@ nxsgpu_search_dev_end(nxsgpu_index_t *ix)
 	(void)carve<item_t>(hp, nseg);
 	(void)carve<uint32_t>(hp, nseg + sl->nq);
 	(void)carve<uint32_t>(hp, sl->nq);
+	(void)carve<uint32_t>(hp, sl->nq);
 	const uint32_t *h_ovf = carve<uint32_t>(hp, sl->nq);
 	for (uint32_t i = 0; i < sl->nq; i++) {
 		if (h_ovf[i]) {
@@ -4820,6 +5344,45 @@ nxsgpu_search_dev_end(nxsgpu_index_t *ix)
 		}
 	}
 	return 0;
+}
+
+extern "C" int
+nxsgpu_batch_end(nxsgpu_index_t *ix, nxsgpu_batch_view_t *view)
+{
+	nxsgpu_index::dev_slot_t *sl = oldest_slot(ix);
+
+	if (!sl) {
+		set_error("nxsgpu_batch_end: no batch in flight");
+		return -1;
+	}
+	if (!sl->records) {
+		set_error("nxsgpu_batch_end: the oldest batch in flight is a device batch (nxsgpu_search_dev_end)");
+		return -1;
+	}
+	sl->active = false;
+	if (slot_wait(ix, sl) != 0) {
+		return -1;
+	}
+	view->n_slots = sl->n_slots;
+	view->k = sl->k;
+	view->world = sl->world;
+	view->rec_bytes = sl->rec_bytes;
+	view->block_bytes = sl->block_bytes;
+	/* with one rank the own block sits at position 0 of both copies */
+	view->blocks = sl->h_blocks;
+	return 0;
+}
+
+extern "C" int
+nxsgpu_batches_in_flight(const nxsgpu_index_t *ix)
+{
+	return (ix->slot[0].active ? 1 : 0) + (ix->slot[1].active ? 1 : 0);
+}
+
+extern "C" void
+nxsgpu_index_reconfigure(nxsgpu_index_t *ix)
+{
+	cfg_from_env(ix->cfg);
 }
 
 extern "C" int
@@ -4836,6 +5399,247 @@ nxsgpu_search_dev(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_que
 	return nxsgpu_search_dev_end(ix);
 }
 
+/* ---- query sharding: slices and the RCCL communicator ---------------------------- */
+
+extern "C" void
+nxsgpu_shard_slice(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi)
+{
+	if (world < 1) {
+		world = 1;
+	}
+	*lo = n * (uint64_t)rank / (uint64_t)world;
+	*hi = n * ((uint64_t)rank + 1) / (uint64_t)world;
+}
+
+extern "C" uint64_t
+nxsgpu_shard_capacity(uint64_t n, int world)
+{
+	uint64_t cap = 0, lo, hi;
+
+	for (int r = 0; r < (world < 1 ? 1 : world); r++) {
+		nxsgpu_shard_slice(n, r, world, &lo, &hi);
+		cap = std::max(cap, hi - lo);
+	}
+	return cap;
+}
+
+/*
+ * RCCL is loaded at first use (dlopen), so that a single-GPU consumer has no
+ * link-time dependency on it and a process that already holds an RCCL (PyTorch
+ * ships its own copy) keeps using that one.
+ */
+struct rccl_api_t {
+	void *		handle;
+	ncclResult_t	(*GetUniqueId)(ncclUniqueId *);
+	ncclResult_t	(*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+	ncclResult_t	(*CommDestroy)(ncclComm_t);
+	ncclResult_t	(*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+	const char *	(*GetErrorString)(ncclResult_t);
+};
+
+static rccl_api_t *
+rccl_api(void)
+{
+	static rccl_api_t api;
+	static bool tried = false;
+
+	if (tried) {
+		return api.handle ? &api : NULL;
+	}
+	tried = true;
+	static const char *const names[] = { "librccl.so.1", "librccl.so" };
+	void *h = NULL;
+	for (int pass = 0; pass < 2 && !h; pass++) {
+		for (size_t i = 0; i < 2 && !h; i++) {
+			h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+		}
+	}
+	if (!h) {
+		h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	}
+	if (!h) {
+		set_error("cannot load librccl: %s", dlerror());
+		return NULL;
+	}
+	api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+	api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+	api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+	api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+	api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+	if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+		set_error("librccl lacks an expected symbol");
+		return NULL;
+	}
+	api.handle = h;
+	return &api;
+}
+
+struct nxsgpu_comm {
+	int		device, rank, world;
+	ncclComm_t	comm;
+	hipStream_t	stream;		/* blocking helper's own stream */
+	void *		d_buf;
+	size_t		d_len;
+};
+
+static const char *
+rccl_err(rccl_api_t *R, ncclResult_t r)
+{
+	return R->GetErrorString ? R->GetErrorString(r) : "rccl error";
+}
+
+extern "C" int
+nxsgpu_comm_unique_id(uint8_t uid[NXSGPU_UID_BYTES])
+{
+	rccl_api_t *R = rccl_api();
+	ncclUniqueId id;
+	ncclResult_t r;
+
+	static_assert(sizeof(ncclUniqueId) == NXSGPU_UID_BYTES, "uid size");
+	if (!R) {
+		return -1;
+	}
+	if ((r = R->GetUniqueId(&id)) != ncclSuccess) {
+		set_error("ncclGetUniqueId: %s", rccl_err(R, r));
+		return -1;
+	}
+	memcpy(uid, &id, NXSGPU_UID_BYTES);
+	return 0;
+}
+
+extern "C" nxsgpu_comm_t *
+nxsgpu_comm_create(int device, int rank, int world, const uint8_t uid[NXSGPU_UID_BYTES])
+{
+	rccl_api_t *R = rccl_api();
+	nxsgpu_comm_t *c;
+	ncclUniqueId id;
+	ncclResult_t r;
+
+	if (!R) {
+		return NULL;
+	}
+	if (world < 1 || rank < 0 || rank >= world) {
+		set_error("bad rank %d of %d", rank, world);
+		return NULL;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		set_error("hipSetDevice(%d) failed", device);
+		return NULL;
+	}
+	c = new nxsgpu_comm();
+	memset(c, 0, sizeof(*c));
+	c->device = device;
+	c->rank = rank;
+	c->world = world;
+	memcpy(&id, uid, NXSGPU_UID_BYTES);
+	if ((r = R->CommInitRank(&c->comm, world, id, rank)) != ncclSuccess) {
+		set_error("ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(R, r));
+		delete c;
+		return NULL;
+	}
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+		set_error("hipStreamCreate failed");
+		(void)R->CommDestroy(c->comm);
+		delete c;
+		return NULL;
+	}
+	return c;
+}
+
+extern "C" void
+nxsgpu_comm_destroy(nxsgpu_comm_t *c)
+{
+	rccl_api_t *R = rccl_api();
+
+	if (!c) {
+		return;
+	}
+	(void)hipSetDevice(c->device);
+	if (c->stream) {
+		(void)hipStreamSynchronize(c->stream);
+		(void)hipStreamDestroy(c->stream);
+	}
+	(void)hipFree(c->d_buf);
+	if (R && c->comm) {
+		(void)R->CommDestroy(c->comm);
+	}
+	delete c;
+}
+
+extern "C" int nxsgpu_comm_rank(const nxsgpu_comm_t *c) { return c ? c->rank : 0; }
+extern "C" int nxsgpu_comm_world(const nxsgpu_comm_t *c) { return c ? c->world : 1; }
+
+/* device buffers, asynchronous on `stream`; recv holds world x bytes */
+static int
+comm_allgather_dev(nxsgpu_comm_t *c, const void *send, void *recv, size_t bytes, hipStream_t stream)
+{
+	rccl_api_t *R = rccl_api();
+	ncclResult_t r;
+
+	if (!R || !c) {
+		set_error("no communicator");
+		return -1;
+	}
+	if ((r = R->AllGather(send, recv, bytes, ncclChar, c->comm, stream)) != ncclSuccess) {
+		set_error("ncclAllGather: %s", rccl_err(R, r));
+		return -1;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_comm_allgather(nxsgpu_comm_t *c, const void *send, void *recv, size_t bytes)
+{
+	const size_t need = (size_t)(c->world + 1) * bytes + 512;
+	uint8_t *d_send, *d_recv;
+
+	if (hipSetDevice(c->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (bytes == 0) {
+		return 0;
+	}
+	if (c->d_len < need) {
+		(void)hipFree(c->d_buf);
+		c->d_buf = NULL;
+		c->d_len = 0;
+		if (hipMalloc(&c->d_buf, need) != hipSuccess) {
+			set_error("hipMalloc(%zu) failed", need);
+			return -1;
+		}
+		c->d_len = need;
+	}
+	d_send = (uint8_t *)c->d_buf;
+	d_recv = d_send + ((bytes + 255) & ~(size_t)255);
+	g_err[0] = '\0';
+	if (hipMemcpyAsync(d_send, send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+	    comm_allgather_dev(c, d_send, d_recv, bytes, c->stream) != 0 ||
+	    hipMemcpyAsync(recv, d_recv, (size_t)c->world * bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+	    hipStreamSynchronize(c->stream) != hipSuccess) {
+		if (!g_err[0]) {
+			set_error("all-gather failed");
+		}
+		return -1;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_index_set_comm(nxsgpu_index_t *ix, nxsgpu_comm_t *c)
+{
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_index_set_comm: batches are in flight");
+		return -1;
+	}
+	if (c && c->device != ix->device) {
+		set_error("communicator and index live on different devices (%d, %d)", c->device, ix->device);
+		return -1;
+	}
+	ix->comm = c;
+	return 0;
+}
+
 extern "C" void
 nxsgpu_results_free(nxsgpu_results_t *res)
 {
@@ -4846,14 +5650,304 @@ nxsgpu_results_free(nxsgpu_results_t *res)
 	memset(res, 0, sizeof(*res));
 }
 
+/* ---- measured HBM read bandwidth ----------------------------------------------------- */
+
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+k_hbm_read(const v4u_t *__restrict__ src, uint64_t n16, uint32_t *__restrict__ sink)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t acc = 0;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+	/* four independent 16-byte loads in flight per lane */
+	for (; i + 3 * stride < n16; i += 4 * stride) {
+		const v4u_t a = __builtin_nontemporal_load(&src[i]);
+		const v4u_t b = __builtin_nontemporal_load(&src[i + stride]);
+		const v4u_t c = __builtin_nontemporal_load(&src[i + 2 * stride]);
+		const v4u_t d = __builtin_nontemporal_load(&src[i + 3 * stride]);
+		acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+	}
+	for (; i < n16; i += stride) {
+		const v4u_t a = __builtin_nontemporal_load(&src[i]);
+		acc ^= a.x ^ a.y ^ a.z ^ a.w;
+	}
+	if (acc == 0x9e3779b9u) {	/* keeps the loads alive; practically never taken */
+		atomicAdd(sink, 1u);
+	}
+}
+
+extern "C" double
+nxsgpu_hbm_read_gbs(nxsgpu_index_t *ix, int reps)
+{
+	/* at most 4 GiB of the BM25 posting array: far beyond the 256 MiB Infinity Cache */
+	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 4ull << 30) & ~(uint64_t)15;
+	uint32_t *d_sink = NULL;
+	hipEvent_t e0 = NULL, e1 = NULL;
+	double best = 0.0;
+
+	if (bytes < (64u << 20) || hipSetDevice(ix->device) != hipSuccess) {
+		return 0.0;
+	}
+	if (hipMalloc((void **)&d_sink, 4) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+	    hipEventCreate(&e1) != hipSuccess) {
+		goto out;
+	}
+	(void)hipMemsetAsync(d_sink, 0, 4, ix->stream);
+	for (int r = 0; r < (reps < 1 ? 1 : reps) + 1; r++) {
+		float ms = 0;
+		(void)hipEventRecord(e0, ix->stream);
+		hipLaunchKernelGGL(k_hbm_read, dim3(256 * 16), dim3(256), 0, ix->stream,
+		    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+		(void)hipEventRecord(e1, ix->stream);
+		if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+			break;
+		}
+		if (r && ms > 0) {	/* first launch warms up */
+			best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+		}
+	}
+out:
+	(void)hipFree(d_sink);
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return best;
+}
+
+/* ---- wide queries (beyond nxsgpu_query_t) ------------------------------------------ */
+
+extern "C" int
+nxsgpu_search_wide(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_wide_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res)
+{
+	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
+	std::vector<wide_dev_t> hq(nq);
+	std::vector<uint64_t> wtok;
+	std::vector<uint16_t> wprog;
+	std::vector<qmeta_t> qmeta(nq);
+	std::vector<item_t> items;
+	uint32_t nt_max = 1, prog_max = 1, nseg = 0;
+	void *ws = NULL, *ws2 = NULL;
+	int rc = -1;
+
+	memset(res, 0, sizeof(*res));
+	res->n_queries = nq;
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (limit == 0) {
+		set_error("invalid limit");
+		return -1;
+	}
+	if (nq == 0) {
+		return 0;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + WTILE - 1) / WTILE);
+	for (uint32_t i = 0; i < nq; i++) {
+		const nxsgpu_wide_query_t &q = queries[i];
+		uint64_t work = 0;
+
+		if (q.n_tokens > NXSGPU_WIDE_MAX_TOKENS || q.prog_len > 2 * NXSGPU_WIDE_MAX_TOKENS) {
+			set_error("wide query %u exceeds %d tokens", i, NXSGPU_WIDE_MAX_TOKENS);
+			return -1;
+		}
+		hq[i].nt = valid ? q.n_tokens : 0;	/* ranking.c:86-88,156-166 */
+		hq[i].prog_len = q.prog_len;
+		hq[i].tok_base = wtok.size();
+		hq[i].prog_base = wprog.size();
+		for (uint32_t t = 0; t < q.n_tokens; t++) {
+			const uint32_t tid = q.term_id[t];
+			if (tid == 0 || tid > ix->n_terms) {
+				set_error("wide query %u: bad term id %u", i, tid);
+				return -1;
+			}
+			wtok.push_back(ix->h_post_off[tid]);
+			wtok.push_back(ix->h_post_off[tid + 1]);
+			work += ix->h_post_off[tid + 1] - ix->h_post_off[tid];
+		}
+		for (uint32_t k = 0; k < q.prog_len; k++) {
+			const uint16_t op = q.prog[k];
+			if (op < 0x8000u && op >= q.n_tokens) {
+				set_error("wide query %u: bad program", i);
+				return -1;
+			}
+			wprog.push_back(op);
+		}
+		nt_max = std::max(nt_max, q.n_tokens);
+		prog_max = std::max(prog_max, q.prog_len);
+		/* one wavefront per ~64k postings */
+		uint64_t g = std::max<uint64_t>(1, work / 65536);
+		g = std::min<uint64_t>(std::min<uint64_t>(g, tiles), 4096);
+		const uint64_t tiles_per = (tiles + g - 1) / g;
+		g = (tiles + tiles_per - 1) / tiles_per;
+		qmeta[i].seg_first = nseg;
+		qmeta[i].n_groups = (uint32_t)g;
+		qmeta[i].group_docs = (uint32_t)std::min<uint64_t>(tiles_per * WTILE, 0xffffffffu & ~(uint64_t)(WTILE - 1));
+		qmeta[i].pad = 0;
+		for (uint32_t gg = (uint32_t)g; gg-- > 0; ) {
+			item_t it;
+			it.q = i;
+			it.g = gg;
+			items.push_back(it);
+		}
+		nseg += (uint32_t)g;
+	}
+	if (wtok.empty()) wtok.push_back(0);
+	if (wprog.empty()) wprog.push_back(0);
+	const uint32_t W = (nt_max + 31) / 32;
+	const size_t lds = (size_t)nt_max * 24 + (size_t)WTILE * 4 * (2 + W) + (size_t)prog_max * 2 + 16;
+	if (lds > 160 * 1024 - 512) {
+		set_error("wide query does not fit the LDS (%zu bytes)", lds);
+		return -1;
+	}
+
+	std::vector<uint32_t> sc_cnt(nseg), x_cnt(nq, 0);
+	std::vector<uint64_t> sc_off((size_t)nseg + 1, 0), hp_off((size_t)nq + 1, 0);
+	std::vector<uint64_t> x_ids;
+	std::vector<float> x_sc;
+	do {
+		const size_t need = 8192 + nq * sizeof(wide_dev_t) + wtok.size() * 8 + wprog.size() * 2
+		    + nq * sizeof(qmeta_t) + nseg * sizeof(item_t) + nseg * 4;
+		if (hipMalloc(&ws, need) != hipSuccess) {
+			set_error("hipMalloc(%zu) failed", need);
+			break;
+		}
+		uint8_t *p = (uint8_t *)ws;
+		wide_dev_t *d_wq = carve<wide_dev_t>(p, nq);
+		uint64_t *d_wtok = carve<uint64_t>(p, wtok.size());
+		uint16_t *d_wprog = carve<uint16_t>(p, wprog.size());
+		qmeta_t *d_qmeta = carve<qmeta_t>(p, nq);
+		item_t *d_items = carve<item_t>(p, nseg);
+		uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
+		if (hipMemcpyAsync(d_wq, hq.data(), nq * sizeof(wide_dev_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_wtok, wtok.data(), wtok.size() * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_wprog, wprog.data(), wprog.size() * 2, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_qmeta, qmeta.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_items, items.data(), nseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+			set_error("wide query upload failed");
+			break;
+		}
+		wide_args_t wa;
+		memset(&wa, 0, sizeof(wa));
+		wa.post = ix->d_post[algo];
+		wa.wq = d_wq;
+		wa.wtok = d_wtok;
+		wa.wprog = d_wprog;
+		wa.qmeta = d_qmeta;
+		wa.items = d_items;
+		wa.n_docs = ix->n_docs;
+		wa.W = W;
+		wa.nt_max = nt_max;
+		wa.prog_max = prog_max;
+		wa.seg_count = d_seg_count;
+		if (hipFuncSetAttribute((const void *)k_scanw<MODE_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_scanw<MODE_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+			set_error("hipFuncSetAttribute(%zu bytes of LDS) failed", lds);
+			break;
+		}
+		hipLaunchKernelGGL(k_scanw<MODE_COUNT>, dim3(nseg), dim3(WAVE), lds, ix->stream, wa);
+		if (hipGetLastError() != hipSuccess ||
+		    hipMemcpyAsync(sc_cnt.data(), d_seg_count, nseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("wide count pass failed: %s", hipGetErrorString(hipGetLastError()));
+			break;
+		}
+		for (uint32_t s = 0; s < nseg; s++) {
+			sc_off[s + 1] = sc_off[s] + sc_cnt[s];
+		}
+		for (uint32_t j = 0; j < nq; j++) {
+			const uint64_t matched = sc_off[(size_t)qmeta[j].seg_first + qmeta[j].n_groups] - sc_off[qmeta[j].seg_first];
+			hp_off[j + 1] = hp_off[j] + std::min<uint64_t>(limit, matched);
+		}
+		const uint64_t tot_c = sc_off[nseg], tot_o = hp_off[nq];
+		const size_t need2 = 8192 + ((size_t)nseg + 1) * 8 + tot_c * 8 + tot_o * 8 + tot_o * 12 + ((size_t)nq + 1) * 8 + nq * 4;
+		if (hipMalloc(&ws2, need2) != hipSuccess) {
+			set_error("hipMalloc(%zu) failed", need2);
+			break;
+		}
+		p = (uint8_t *)ws2;
+		uint64_t *d_seg_off = carve<uint64_t>(p, (size_t)nseg + 1);
+		uint32_t *d_cdoc = carve<uint32_t>(p, tot_c + 1);
+		float *d_csc = carve<float>(p, tot_c + 1);
+		float *d_hs = carve<float>(p, tot_o + 1);
+		uint32_t *d_hd = carve<uint32_t>(p, tot_o + 1);
+		uint64_t *d_hoff = carve<uint64_t>(p, (size_t)nq + 1);
+		uint64_t *d_ids = carve<uint64_t>(p, tot_o + 1);
+		float *d_sc = carve<float>(p, tot_o + 1);
+		uint32_t *d_cnt = carve<uint32_t>(p, nq);
+		if (hipMemcpyAsync(d_seg_off, sc_off.data(), ((size_t)nseg + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(d_hoff, hp_off.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+			set_error("upload failed");
+			break;
+		}
+		wa.seg_off = d_seg_off;
+		wa.cand_doc = d_cdoc;
+		wa.cand_sc = d_csc;
+		hipLaunchKernelGGL(k_scanw<MODE_ALL>, dim3(nseg), dim3(WAVE), lds, ix->stream, wa);
+		replay_args_t ra;
+		memset(&ra, 0, sizeof(ra));
+		ra.qmeta = d_qmeta;
+		ra.seg_cap = 0;
+		ra.seg_off = d_seg_off;
+		ra.cand_doc = d_cdoc;
+		ra.cand_sc = d_csc;
+		ra.doc_ids = ix->d_doc_ids;
+		ra.k = (uint32_t)std::min<uint64_t>(limit, 0xffffffffu);
+		ra.gheap_s = d_hs;
+		ra.gheap_d = d_hd;
+		ra.heap_off = d_hoff;
+		ra.out_ids = d_ids;
+		ra.out_sc = d_sc;
+		ra.out_count = d_cnt;
+		ra.out_off = d_hoff;
+		hipLaunchKernelGGL(k_replay<false>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		x_ids.resize(tot_o);
+		x_sc.resize(tot_o);
+		if (hipGetLastError() != hipSuccess ||
+		    hipMemcpyAsync(x_cnt.data(), d_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    (tot_o && hipMemcpyAsync(x_ids.data(), d_ids, tot_o * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+		    (tot_o && hipMemcpyAsync(x_sc.data(), d_sc, tot_o * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("wide emit pass failed: %s", hipGetErrorString(hipGetLastError()));
+			break;
+		}
+		rc = 0;
+	} while (0);
+	(void)hipFree(ws);
+	(void)hipFree(ws2);
+	if (rc != 0) {
+		return -1;
+	}
+	res->counts = (uint32_t *)calloc(nq, sizeof(uint32_t));
+	res->offsets = (uint64_t *)calloc((size_t)nq + 1, sizeof(uint64_t));
+	for (uint32_t i = 0; i < nq; i++) {
+		res->counts[i] = x_cnt[i];
+		res->offsets[i + 1] = res->offsets[i] + x_cnt[i];
+	}
+	const uint64_t total = res->offsets[nq];
+	res->doc_ids = (uint64_t *)malloc((total ? total : 1) * 8);
+	res->scores = (float *)malloc((total ? total : 1) * 4);
+	for (uint32_t i = 0; i < nq; i++) {
+		memcpy(res->doc_ids + res->offsets[i], x_ids.data() + hp_off[i], (size_t)x_cnt[i] * 8);
+		memcpy(res->scores + res->offsets[i], x_sc.data() + hp_off[i], (size_t)x_cnt[i] * 4);
+	}
+	res->exact_requeries = nq;
+	return 0;
+}
+
 /* ---- fuzzy ----------------------------------------------------------- */
 
 extern "C" int
 nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off,
     uint32_t n_tok, uint32_t *term_ids, uint64_t *visited)
 {
-	const uint64_t budget = getenv("NXS_GPU_FUZZY_ITEMS") ?
-	    strtoull(getenv("NXS_GPU_FUZZY_ITEMS"), NULL, 10) : (256ull << 20);
+	const uint64_t budget = ix->cfg.fuzzy_items;
 	const uint32_t n_bk = ix->n_bk;
 	uint32_t chunk, max_len = 0;
 	bool any_long = false;
@@ -4886,13 +5980,13 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 	 * the safe size.
 	 */
 	const uint32_t safe_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tok, budget / n_bk));
-	chunk = getenv("NXS_GPU_FUZZY_SAFE") ? safe_chunk : n_tok;
+	chunk = ix->cfg.fuzzy_safe ? safe_chunk : n_tok;
 
 	const uint32_t LONG_THREADS = 64 * 64;
 	const uint64_t cap = std::max<uint64_t>((uint64_t)safe_chunk * n_bk, std::min<uint64_t>(budget, (uint64_t)chunk * n_bk));
 	const size_t levels = (size_t)ix->bk_depth + 2;
 	size_t need = 4096 + cap * sizeof(fz_item_t) * 2 + levels * 4 + 256
-	    + (size_t)chunk * (256 * 8 + 4 + 8 + 4) + tok_off[n_tok] + 16 + ((size_t)chunk + 1) * 4
+	    + (size_t)chunk * (256 * 8 + 4 + 8 + 4) + tok_off[n_tok] + 16 + ((size_t)chunk + 1) * 4 + 512
 	    + (any_long ? (size_t)LONG_THREADS * ((size_t)max_len + 2) * 2 : 0) + 16 * 256;
 	if (ix->fz_len < need) {
 		if (ix->fz) {
@@ -4919,6 +6013,7 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 		uint64_t *d_peq = carve<uint64_t>(p, (size_t)nc * 256);
 		uint32_t *d_best = carve<uint32_t>(p, nc);
 		unsigned long long *d_vis = carve<unsigned long long>(p, nc);
+		unsigned long long *d_evals = carve<unsigned long long>(p, 1);
 		uint32_t *d_tids = carve<uint32_t>(p, nc);
 		uint8_t *d_bytes = carve<uint8_t>(p, blen + 16);
 		uint32_t *d_off = carve<uint32_t>(p, nc + 1);
@@ -4932,7 +6027,8 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 		if (hipMemcpyAsync(d_bytes, tok_bytes + boff, blen, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(d_off, roff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemsetAsync(counts, 0, levels * 4, ix->stream) != hipSuccess ||
-		    hipMemsetAsync(d_ovf, 0, 4, ix->stream) != hipSuccess) {
+		    hipMemsetAsync(d_ovf, 0, 4, ix->stream) != hipSuccess ||
+		    hipMemsetAsync(d_evals, 0, 8, ix->stream) != hipSuccess) {
 			set_error("fuzzy upload failed");
 			return -1;
 		}
@@ -4953,6 +6049,8 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 		fa.dp_rows = d_rows;
 		fa.dp_stride = max_len + 2;
 		fa.overflow = d_ovf;
+		fa.prune = (!visited && !ix->cfg.fuzzy_noprune) ? 1u : 0u;
+		fa.evals = ix->profiling ? d_evals : NULL;
 		for (uint32_t lvl = 0; lvl < ix->bk_depth; lvl++) {
 			fa.cur = (lvl & 1) ? qb : qa;
 			fa.next = (lvl & 1) ? qa : qb;
@@ -4972,7 +6070,9 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			return -1;
 		}
 		std::vector<uint32_t> h_counts(levels);
+		unsigned long long h_evals = 0;
 		if (hipMemcpyAsync(term_ids + c0, d_tids, nc * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(&h_evals, d_evals, 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    (visited && hipMemcpyAsync(visited + c0, d_vis, nc * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
 		    hipMemcpyAsync(&h_ovf, d_ovf, 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(h_counts.data(), counts, levels * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
@@ -4994,8 +6094,14 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			continue;		/* same tokens again, fewer at a time */
 		}
 		if (ix->profiling) {
+			/* distance evaluations; (token, node) pairs dequeued, pruned ones
+			 * included, are the level counts */
+			ix->prof.fuzzy_visits += h_evals;
 			for (size_t l = 0; l < levels; l++) {
-				ix->prof.fuzzy_visits += h_counts[l];
+				ix->prof.fuzzy_pairs += h_counts[l];
+				if (l < 40) {
+					ix->prof.fuzzy_level[l] += h_counts[l];
+				}
 			}
 		}
 		c0 += nc;

@@ -21,12 +21,16 @@
 #define	NXS_QUERY_RLIMIT		100	/* search.c:70 */
 #define	LEVDIST_TOLERANCE		2	/* index.h:26 */
 
+struct nxs_pool;
+
 struct nxs {
 	char *		basedir;
 	char *		errmsg;
 	nxs_err_t	errcode;
 	nxs_index_t **	indexes;
 	size_t		n_indexes;
+	struct nxs_pool *pool;		/* host workers of the batch front half */
+	bool		pool_tried;
 };
 
 void	nxs_clear_error(nxs_t *);
@@ -62,6 +66,22 @@ typedef struct {
 	uint16_t	len;
 } hterm_t;
 
+struct qprep;
+
+/* one batch between nxs_index_search_batch_begin and _end */
+typedef struct nxs_pend {
+	bool		active;
+	bool		on_device;	/* queued through nxsgpu_batch_begin */
+	size_t		n;		/* queries of the whole batch */
+	size_t		lo, hi;		/* this rank's slice */
+	uint32_t	cap;		/* record slots per rank */
+	int		rank, world;
+	uint64_t	limit;
+	int		algo;
+	struct qprep *	prep;		/* [hi - lo] */
+	uint64_t	seq;
+} nxs_pend_t;
+
 struct nxs_index {
 	nxs_t *		nxs;
 	char *		name;
@@ -80,6 +100,16 @@ struct nxs_index {
 
 	uint64_t	n_docs;
 	nxsgpu_index_t *dev;
+	int		device;		/* HIP device of the index (NXS_GPU_DEVICE at open) */
+
+	/* query sharding (nxs_index_shard) and the batches in flight */
+	nxsgpu_comm_t *	comm;
+	struct nxs_pend	pend[2];
+	uint64_t	pend_seq;
+	/* tests: play one rank of emu_world (nxs_test_shard_emulate) */
+	int		emu_rank, emu_world;
+	uint8_t *	emu_block;
+	size_t		emu_block_len;
 
 	/* snapshot identity: what idx_terms_sync/idx_dtmap_sync had consumed */
 	char *		terms_path;
@@ -138,14 +168,16 @@ typedef struct {
 	uint32_t	term_id;	/* 0 = unresolved */
 } qtok_t;
 
-typedef struct {
+typedef struct qprep {
 	qparse_t	parse;
 	qtok_t *	tokens;		/* token-list order (query.c:89-95) */
 	size_t		n_tokens;
 	nxs_err_t	errcode;	/* set when the query cannot run */
 	char *		errmsg;
 	bool		empty;		/* no live tokens: empty result */
+	bool		wide;		/* does not fit nxsgpu_query_t: wplan is its plan */
 	nxsgpu_query_t	plan;
+	nxsgpu_wide_query_t wplan;	/* arrays owned by this object */
 } qprep_t;
 
 void	nxs_query_prepare(const nxs_index_t *, const char *query, qprep_t *out);

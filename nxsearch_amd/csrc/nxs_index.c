@@ -654,7 +654,8 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 		src.bk_bytes = bk.bytes;
 		src.bk_bytes_len = bk.bytes_len;
 
-		idx->dev = nxsgpu_index_create(dev_env ? atoi(dev_env) : 0, &src);
+		idx->device = dev_env ? atoi(dev_env) : 0;
+		idx->dev = nxsgpu_index_create(idx->device, &src);
 		free(blk_off);
 		free(doc_ids);
 		free(pair_base);
@@ -739,15 +740,50 @@ nxs_index_refresh(nxs_index_t *idx)
 	if (t_now == idx->terms_seen && d_now == idx->dt_seen) {
 		return 0;
 	}
+	/*
+	 * Build the new snapshot FIRST and swap on success: if the files cannot be
+	 * consumed right now (a writer in the middle of an append) the old
+	 * snapshot keeps serving, as the reference's partial sync does
+	 * (DTMAP_PARTIAL_SYNC, dtmap.c:527-535); the next search tries again.
+	 */
 	{
-		char *tp = strdup(idx->terms_path), *dp = strdup(idx->dtmap_path);
-		int r;
+		nxs_index_t tmp;
+		nxs_err_t saved_code = idx->nxs->errcode;
 
+		memset(&tmp, 0, sizeof(tmp));
+		tmp.nxs = idx->nxs;
+		tmp.algo = idx->algo;
+		tmp.lowercase = idx->lowercase;
+		tmp.terms_path = idx->terms_path;
+		tmp.dtmap_path = idx->dtmap_path;
+		if (nxs_index_load(&tmp, idx->terms_path, idx->dtmap_path) != 0) {
+			unload_snapshot(&tmp);
+			if (saved_code == NXS_ERR_SUCCESS) {
+				nxs_clear_error(idx->nxs);
+			}
+			return 0;
+		}
+		if (idx->comm && nxsgpu_index_set_comm(idx->dev, NULL) != 0) {
+			unload_snapshot(&tmp);
+			return 0;	/* batches in flight: not now */
+		}
 		unload_snapshot(idx);
-		r = nxs_index_load(idx, tp, dp);
-		free(tp);
-		free(dp);
-		return r;
+		idx->tmap = tmp.tmap;	idx->tmap_len = tmp.tmap_len;
+		idx->dmap = tmp.dmap;	idx->dmap_len = tmp.dmap_len;
+		idx->terms = tmp.terms;
+		idx->last_id = tmp.last_id;
+		idx->term_count = tmp.term_count;
+		idx->thash = tmp.thash;
+		idx->thash_cap = tmp.thash_cap;
+		idx->n_docs = tmp.n_docs;
+		idx->dev = tmp.dev;
+		idx->device = tmp.device;
+		idx->terms_seen = tmp.terms_seen;
+		idx->dt_seen = tmp.dt_seen;
+		if (idx->comm) {
+			(void)nxsgpu_index_set_comm(idx->dev, idx->comm);
+		}
+		return 0;
 	}
 }
 

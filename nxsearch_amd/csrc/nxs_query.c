@@ -463,17 +463,11 @@ nxs_query_compile(qprep_t *q)
 		ret = 0;
 		goto out;
 	}
-	if (live > NXSGPU_MAX_TOKENS) {
+	if (live > NXSGPU_WIDE_MAX_TOKENS) {
 		q->errcode = NXS_ERR_LIMIT;
 		if (asprintf(&q->errmsg, "too many query terms for the device path "
-		    "(%u, limit %u)", live, NXSGPU_MAX_TOKENS) == -1) q->errmsg = NULL;
+		    "(%u, limit %u)", live, NXSGPU_WIDE_MAX_TOKENS) == -1) q->errmsg = NULL;
 		goto out;
-	}
-	pl->n_tokens = live;
-	for (size_t j = 0; j < q->n_tokens; j++) {
-		if (bit[j] >= 0) {
-			pl->term_id[bit[j]] = q->tokens[j].term_id;
-		}
 	}
 	/* height of the tree first (get_expr_bitmap recursion: search.c:126-131) */
 	for (size_t i = 0; i < pr->n; i++) {
@@ -493,11 +487,53 @@ nxs_query_compile(qprep_t *q)
 		    NXS_QUERY_RLIMIT) == -1) q->errmsg = NULL;
 		goto out;
 	}
-	if (pr->n > NXSGPU_MAX_PROG) {
-		q->errcode = NXS_ERR_LIMIT;
-		if (asprintf(&q->errmsg, "query too long for the device path "
-		    "(%zu items, limit %u)", pr->n, NXSGPU_MAX_PROG) == -1) q->errmsg = NULL;
+	/*
+	 * More than the fixed-size plan holds (run_query_logic, search.c:210-278,
+	 * has no bound on terms): a variable-size "wide" plan for the generic
+	 * kernel (k_scanw) on the exact path.  Its evaluation stack is 128 deep; the
+	 * nesting limit above keeps any program at 101 or less.
+	 */
+	if (live > NXSGPU_MAX_TOKENS || pr->n > NXSGPU_MAX_PROG || maxsp > 64) {
+		uint32_t *wt = calloc(live, sizeof(uint32_t));
+		uint16_t *wp = calloc(pr->n, sizeof(uint16_t));
+
+		if (!wt || !wp || pr->n > 2 * NXSGPU_WIDE_MAX_TOKENS || maxsp > 128) {
+			free(wt);
+			free(wp);
+			q->errcode = NXS_ERR_LIMIT;
+			if (asprintf(&q->errmsg, "query too long for the device path "
+			    "(%zu items)", pr->n) == -1) q->errmsg = NULL;
+			goto out;
+		}
+		for (size_t j = 0; j < q->n_tokens; j++) {
+			if (bit[j] >= 0) {
+				wt[bit[j]] = q->tokens[j].term_id;
+			}
+		}
+		for (size_t i = 0; i < pr->n; i++) {
+			const qitem_t *it = &pr->items[i];
+
+			if (it->op == 0) {
+				const int b = it->token >= 0 ? bit[it->token] : -1;
+				wp[i] = b >= 0 ? (uint16_t)b : NXSGPU_WOP_EMPTY;
+			} else {
+				wp[i] = it->op == NXSGPU_OP_AND ? NXSGPU_WOP_AND :
+				    it->op == NXSGPU_OP_OR ? NXSGPU_WOP_OR : NXSGPU_WOP_ANDNOT;
+			}
+		}
+		q->wide = true;
+		q->wplan.n_tokens = live;
+		q->wplan.term_id = wt;
+		q->wplan.prog_len = (uint32_t)pr->n;
+		q->wplan.prog = wp;
+		ret = 0;
 		goto out;
+	}
+	pl->n_tokens = live;
+	for (size_t j = 0; j < q->n_tokens; j++) {
+		if (bit[j] >= 0) {
+			pl->term_id[bit[j]] = q->tokens[j].term_id;
+		}
 	}
 	for (size_t i = 0; i < pr->n; i++) {
 		const qitem_t *it = &pr->items[i];
@@ -508,12 +544,6 @@ nxs_query_compile(qprep_t *q)
 		} else {
 			pl->prog[pl->prog_len++] = it->op;
 		}
-	}
-	if (maxsp > 64) {
-		q->errcode = NXS_ERR_LIMIT;
-		if (asprintf(&q->errmsg, "query too deeply right-nested for the "
-		    "device path (%zu)", maxsp) == -1) q->errmsg = NULL;
-		goto out;
 	}
 	/* truth table over the presence mask for the 8-token fast path */
 	if (live <= 8) {
@@ -552,6 +582,8 @@ nxs_query_release(qprep_t *q)
 	}
 	free(q->tokens);
 	free(q->errmsg);
+	free((void *)q->wplan.term_id);
+	free((void *)q->wplan.prog);
 	nxs_query_free(&q->parse);
 	memset(q, 0, sizeof(*q));
 }

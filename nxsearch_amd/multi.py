@@ -1,84 +1,111 @@
-"""Query-sharded multi-GPU execution.
+"""Query-sharded multi-GPU execution -- a binding of the
+library's own sharding (include/nxs.h: nxs_shard_unique_id, nxs_index_shard).
 
 Queries are independent and the index is read-only during a batch, so a batch
 shards BY QUERY: rank r of W takes the contiguous slice
-[n*r//W, n*(r+1)//W) of the batch, every rank holds a full replica of the
-device index (N, token_count and df are identical on all replicas, so no
-statistics are exchanged), and ONE all-gather of the fixed-size per-query
-records -- count + k x (u64 doc id, f32 score), 124 B at k = 10 -- reassembles
-the batch on every rank.  On ROCm the "nccl" backend is RCCL; the records
-travel over xGMI.  The reference has no counterpart: it scales by running
-independent worker processes (compose/nginx.conf:2).
+[n*r//W, n*(r+1)//W), every rank holds a full replica of the device index (N,
+token_count and df are identical on all replicas, so no statistics are
+exchanged), and ONE RCCL all-gather of the ranks' record blocks -- fixed-size
+per-query records `count u32 | flags u32 | k x u64 doc id | k x f32 score`,
+128 B at k = 10 -- reassembles the batch on every rank over xGMI.  All of it
+lives behind the C ABI (csrc/nxs_api.c, nxs_gpu.hip); this module only
+distributes the communicator's unique id with whatever channel the
+application already has (here: torch.distributed) and wraps the test hooks.
+The reference has no counterpart: it scales by running independent worker
+processes (compose/nginx.conf:2).
 """
-import torch
+import ctypes as C
+
+from . import lib, NxsError
 
 
 def shard_slice(n, rank, world):
-    """Contiguous slice of an n-query batch owned by `rank`."""
-    return n * rank // world, n * (rank + 1) // world
+    """Contiguous slice of an n-query batch owned by `rank` (nxsgpu_shard_slice)."""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    lib().nxsgpu_shard_slice(n, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def shard_capacity(n, world):
-    """Largest shard size (the all-gather needs equal-sized contributions)."""
-    return max(shard_slice(n, r, world)[1] - shard_slice(n, r, world)[0]
-               for r in range(world))
+    """Largest slice = record slots per rank's block (nxsgpu_shard_capacity)."""
+    return lib().nxsgpu_shard_capacity(n, world)
 
 
-class ShardedBatch:
-    """Buffers of one sharded batch: local [cap, k] + gathered [W*cap, k]."""
+def rec_bytes(k):
+    return (8 + 12 * k + 7) & ~7
 
-    def __init__(self, n, k, rank, world, device):
-        self.n, self.k, self.rank, self.world = n, k, rank, world
-        self.lo, self.hi = shard_slice(n, rank, world)
-        self.cap = shard_capacity(n, world)
-        z = dict(device=device)
-        self.ids = torch.zeros((self.cap, k), dtype=torch.int64, **z)
-        self.scores = torch.zeros((self.cap, k), dtype=torch.float32, **z)
-        self.counts = torch.zeros((self.cap,), dtype=torch.int32, **z)
-        if world > 1:
-            self.g_ids = torch.empty((world * self.cap, k), dtype=torch.int64, **z)
-            self.g_scores = torch.empty((world * self.cap, k), dtype=torch.float32, **z)
-            self.g_counts = torch.empty((world * self.cap,), dtype=torch.int32, **z)
+
+def block_bytes(n_slots, k):
+    return n_slots * rec_bytes(k) + ((n_slots * 4 + 7) & ~7)
+
+
+def attach(nxs, index, rank, world, dist=None, device=None):
+    """Collective: rank 0 creates the RCCL unique id, torch.distributed carries
+    its 128 bytes to the other ranks, every rank builds the communicator."""
+    import torch
+    if world <= 1 and dist is None:
+        uid = nxs.shard_unique_id()
+    else:
+        t = torch.zeros(128, dtype=torch.uint8, device=device or "cpu")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(nxs.shard_unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        uid = bytes(t.cpu().numpy().tobytes())
+    index.shard(rank, world, uid)
+
+
+# ---- test hooks (CPU-side stand-ins; see nxs_api.c "Sharding without a second GPU")
+
+def emulate(index, rank, world):
+    """The index plays rank `rank` of `world` without a collective (0: off)."""
+    L = lib()
+    L.nxs_test_shard_emulate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.nxs_test_shard_emulate(index._h, rank, world)
+
+
+def emulated_block(index):
+    """The record block the last emulated batch would have contributed."""
+    L = lib()
+    L.nxs_test_shard_block.restype = C.c_size_t
+    L.nxs_test_shard_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    n = L.nxs_test_shard_block(index._h, None, 0)
+    buf = C.create_string_buffer(max(n, 1))
+    L.nxs_test_shard_block(index._h, buf, n)
+    return buf.raw[:n]
+
+
+def pack_block(results, n_slots, k):
+    """Host stand-in for the device: [(status, [(doc, score), ...]), ...] for
+    the slice's queries -> one record block."""
+    L = lib()
+    L.nxs_test_pack_record.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.c_uint32]
+    buf = C.create_string_buffer(max(block_bytes(n_slots, k), 1))
+    for slot, (status, rs) in enumerate(results):
+        rs = [] if status else rs[:k]
+        ids = (C.c_uint64 * max(len(rs), 1))(*[d for d, _ in rs])
+        sc = (C.c_float * max(len(rs), 1))(*[s for _, s in rs])
+        L.nxs_test_pack_record(buf, n_slots, k, slot, len(rs), ids, sc, status)
+    return buf.raw[:block_bytes(n_slots, k)]
+
+
+def assemble(blocks, world, n_slots, k, n):
+    """What every rank does with the gathered blocks (resps_from_blocks):
+    -> list of result lists; a failed query is an NxsError in its slot."""
+    from . import _drain
+    L = lib()
+    L.nxs_test_assemble.restype = C.c_int
+    L.nxs_test_assemble.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    resps = (C.c_void_p * max(n, 1))()
+    errs = (C.c_int * max(n, 1))()
+    if L.nxs_test_assemble(blocks, world, n_slots, k, n, resps, errs) < 0:
+        raise NxsError(1, "assemble failed")
+    out = []
+    for i in range(n):
+        if resps[i]:
+            out.append(_drain(resps[i]))
+            L.nxs_resp_release(resps[i])
         else:
-            self.g_ids, self.g_scores, self.g_counts = self.ids, self.scores, self.counts
-
-    def gather(self, dist=None, group=None):
-        """All-gather the per-rank top-k records (RCCL over xGMI on GPUs)."""
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.g_ids, self.ids, group=group)
-            dist.all_gather_into_tensor(self.g_scores, self.scores, group=group)
-            dist.all_gather_into_tensor(self.g_counts, self.counts, group=group)
-
-    def assemble(self):
-        """-> (ids [n,k], scores [n,k], counts [n]) in original query order."""
-        if self.world == 1:
-            return self.ids[:self.n], self.scores[:self.n], self.counts[:self.n]
-        parts = []
-        for r in range(self.world):
-            lo, hi = shard_slice(self.n, r, self.world)
-            parts.append(slice(r * self.cap, r * self.cap + (hi - lo)))
-        cat = lambda t: torch.cat([t[p] for p in parts], dim=0)
-        return cat(self.g_ids), cat(self.g_scores), cat(self.g_counts)
-
-
-def search_sharded(index, queries, limit=10, algo="BM25", fuzzymatch=False,
-                   rank=0, world=1, device=None, dist=None, group=None):
-    """Run `queries` (the same list on every rank) sharded by query over the
-    ranks' GPUs; every rank returns the full (ids, scores, counts) tensors."""
-    from . import BM25, TF_IDF
-    sb = ShardedBatch(len(queries), limit, rank, world, device)
-    mine = queries[sb.lo:sb.hi]
-    if mine:
-        plans, errs = index.plan_batch(mine, limit=limit, algo=algo, fuzzymatch=fuzzymatch)
-        r = index.search_dev(plans, len(mine), limit, BM25 if algo.upper() == "BM25" else TF_IDF,
-                             sb.ids.data_ptr(), sb.scores.data_ptr(), sb.counts.data_ptr())
-        if r != 0:
-            # a query overflowed its candidate segments: exact host-copy path
-            res = index.search_batch(mine, limit=limit, algo=algo, fuzzymatch=fuzzymatch)
-            for i, rs in enumerate(res):
-                sb.counts[i] = len(rs)
-                for j, (d, s) in enumerate(rs):
-                    sb.ids[i, j] = d if d < (1 << 63) else d - (1 << 64)
-                    sb.scores[i, j] = s
-    sb.gather(dist, group)
-    return sb.assemble()
+            out.append(NxsError(errs[i], "query %d failed" % i))
+    return out

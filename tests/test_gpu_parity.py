@@ -171,9 +171,56 @@ def test_many_tokens_use_the_wide_path(nxs, tmp_path):
         for limit in (10, 100):
             assert_same(gidx.search(q, limit=limit, fuzzymatch=False),
                         oidx.search(q, limit=limit, fuzzymatch=False), q)
-    with pytest.raises(N.NxsError) as e:
-        gidx.search(" OR ".join("x%d" % i for i in range(40)).replace("x", "t"))
-    assert e.value.code in (0, 6) or True
+    gidx.close()
+
+
+def test_queries_beyond_the_fixed_size_plan(nxs, tmp_path):
+    """run_query_logic (search.c:210-278) has no bound on the number of terms:
+    33 / 40 / 100 / 300 distinct tokens, a program of more than 256 items and an
+    evaluation stack deeper than 64 take the wide plan (k_scanw, exact path)."""
+    rng = random.Random(19)
+    vocab = ["t%d" % i for i in range(320)]
+    weights = [1.0 / (i + 1) for i in range(len(vocab))]
+    pool = rng.choices(vocab, weights, k=8192)
+    docs = random_corpus(rng, 6000, pool, max_len=14, sparse=True)
+    gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
+    qs = [" OR ".join(vocab[:33]), " OR ".join(vocab[:40]), " ".join(vocab[:100]),
+          " OR ".join(vocab[:300]),
+          "(" + " OR ".join(vocab[:50]) + ") AND (" + " OR ".join(vocab[40:95]) + ") AND NOT " + vocab[3],
+          # 140 leaves of 20 distinct tokens: > 256 program items, <= 32 tokens
+          " OR ".join("(%s AND %s)" % (vocab[i % 20], vocab[(i * 7 + 3) % 20]) for i in range(70)),
+          # right-nested: evaluation stack of 70
+          "".join("%s AND (" % vocab[i] for i in range(69)) + vocab[69] + ")" * 69,
+          " OR ".join(vocab[:35]) + " OR nosuchterm"]
+    for limit in (10, 64, 1000):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = gidx.search_batch(qs + [vocab[0] + " AND " + vocab[1]], limit=limit, algo=name,
+                                    fuzzymatch=False)
+            for q, g in zip(qs + [vocab[0] + " AND " + vocab[1]], got):
+                assert_same(g, oidx.search(q, algo=algo, limit=limit, fuzzymatch=False), (q[:40], limit, name))
+    assert_same(gidx.search(qs[1], fuzzymatch=False), oidx.search(qs[1], fuzzymatch=False))
+    gidx.close()
+
+
+def test_two_strings_resolving_to_one_term_score_twice(nxs, golden, tmp_path):
+    """Q6: different token strings that fuzzy-resolve to the SAME term stay two
+    tokens (tokenizer.c:100-107 merges identical strings only): the term's score
+    is added twice.  Exercises duplicate term ids in two slots of k_scanm /
+    k_scanr / k_scan8."""
+    rng = random.Random(23)
+    vocab = ["linux", "unix", "erlang", "python", "kernel", "shell", "driver", "thread"]
+    docs = random_corpus(rng, 5000, vocab + ["pad%d" % i for i in range(30)], max_len=9)
+    gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
+    qs = ["linus OR linuz", "linus AND linuz", "linus OR linuz OR unix", "linus AND linuz AND kernel",
+          "linus linuz linvx", "(linus OR erlang) AND linuz", "linux OR linus", "linux AND linus AND NOT shell",
+          "pythan OR pythom OR pithon OR python OR kernel"]
+    assert gidx.fuzzy(["linus", "linuz"]) == [oidx.fuzzy(b"linus")[0], oidx.fuzzy(b"linuz")[0]]
+    assert len(set(gidx.fuzzy(["linus", "linuz", "linvx"]))) == 1
+    for limit in (3, 10, 64, 1000):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = gidx.search_batch(qs, limit=limit, algo=name)
+            for q, g in zip(qs, got):
+                assert_same(g, oidx.search(q, algo=algo, limit=limit), (q, limit, name))
     gidx.close()
 
 
@@ -185,6 +232,7 @@ def test_candidate_overflow_falls_back_to_exact_path(nxs, tmp_path, monkeypatch)
     gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
     monkeypatch.setenv("NXS_GPU_SEGCAP", "16")
     monkeypatch.setenv("NXS_GPU_WAVES", "2")
+    gidx.reconfigure()      # the switches are parsed once, at open
     for limit in (5, 10):
         assert_same(gidx.search("x", limit=limit), oidx.search("x", limit=limit), limit)
     gidx.close()
@@ -267,10 +315,16 @@ def test_fuzzy_matches_oracle(nxs, tmp_path, seed, n_terms, alphabet):
     # overflows and is repeated with fewer tokens at a time, same answers
     os.environ["NXS_GPU_FUZZY_ITEMS"] = str(3 * n_terms)
     try:
+        gidx.reconfigure()
         got2, vis2 = gidx.fuzzy(toks, want_visited=True)
+        assert gidx.fuzzy(toks) == got
     finally:
         del os.environ["NXS_GPU_FUZZY_ITEMS"]
+        gidx.reconfigure()
     assert (got2, vis2) == (got, vis)
+    # production form (no visit counts): pairs that can no longer win are pruned
+    # -- the same winners
+    assert gidx.fuzzy(toks) == got
     gidx.close()
 
 
@@ -449,19 +503,126 @@ def test_pipelined_device_batches(nxs, tmp_path):
     gidx.close()
 
 
-def test_sharded_search_single_rank(nxs, tmp_path):
-    import torch
-    from nxsearch_amd import multi
-    c = corpus.write_corpus(str(tmp_path), 30_000, 2000, seed=8)
-    terms = corpus.term_strings(2000, seed=8)
+def test_pipelined_string_batches(nxs, tmp_path):
+    """nxs_index_search_batch_begin/_end: strings in, responses out, two batches
+    in flight; per-step DISTINCT batches (a stale buffer would show)."""
+    c = corpus.write_corpus(str(tmp_path), 200_000, 8000, seed=43)
+    terms = corpus.term_strings(8000, seed=43)
     gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
-    qs = corpus.queries_bool5(terms, 33, seed=9, hi=300)
-    ids, sc, cnt = multi.search_sharded(gidx, qs, limit=10, device=torch.device("cuda", 0))
-    for i, q in enumerate(qs):
-        want = oidx.search(q, limit=10, fuzzymatch=False)
-        n = int(cnt[i])
-        got = list(zip(ids[i, :n].tolist(), sc[i, :n].tolist()))
-        assert_same(got, want, q)
+    batches = [corpus.queries_bool5(terms, 40 + 7 * s_, seed=10 + s_, hi=600) for s_ in range(6)]
+    batches[2] = batches[2][:5] + ["broken AND", "zzzzqqqq"] + batches[2][5:]
+    with pytest.raises(N.NxsError):
+        gidx.search_batch_end()                       # nothing in flight
+    gidx.search_batch_begin(batches[0], limit=10, fuzzymatch=False)
+    gidx.search_batch_begin(batches[1], limit=10, fuzzymatch=False)
+    with pytest.raises(N.NxsError):
+        gidx.search_batch_begin(batches[2], limit=10, fuzzymatch=False)   # two is the limit
+    gidx._pending = gidx._pending[:2]
+    with pytest.raises(N.NxsError):
+        gidx.search_batch(batches[2], limit=10, fuzzymatch=False)         # blocking call refuses meanwhile
+    outs = []
+    for i in range(2, len(batches)):
+        outs.append(gidx.search_batch_end())
+        gidx.search_batch_begin(batches[i], limit=10, fuzzymatch=False)
+    outs.append(gidx.search_batch_end())
+    outs.append(gidx.search_batch_end())
+    for b, got in zip(batches, outs):
+        assert len(got) == len(b)
+        for q, g in zip(b, got):
+            try:
+                want = oidx.search(q, limit=10, fuzzymatch=False)
+            except O.SearchError as e:
+                assert isinstance(g, N.NxsError) and g.code == e.code
+                continue
+            assert_same(g, want, q)
+    # limit > 64 through the same entry points (exact two-pass path at _end)
+    gidx.search_batch_begin(batches[0][:9], limit=200, fuzzymatch=False)
+    for q, g in zip(batches[0][:9], gidx.search_batch_end()):
+        assert_same(g, oidx.search(q, limit=200, fuzzymatch=False), q)
+    gidx.close()
+
+
+def _mixed_workload(tmp_path, docs=200_000, n_terms=8000, n=192, seed=47):
+    c = corpus.write_corpus(str(tmp_path), docs, n_terms, seed=seed)
+    terms = corpus.term_strings(n_terms, seed=seed)
+    qs = corpus.queries_mixed(terms, n, seed=5, hi=600)
+    assert sum(1 for q in qs if any(w.encode() not in set(terms) for w in q.split() if w not in ("AND", "OR"))) > n // 8
+    return c, terms, qs
+
+
+def test_sharded_single_rank_through_rccl(nxs, tmp_path):
+    """C5-style mixed BM25 + fuzzy batch through the sharded entry on ONE rank:
+    a real RCCL communicator (ncclCommInitRank, world 1), the record path and
+    the library's reassembly, against the oracle."""
+    from nxsearch_amd import multi
+    c, terms, qs = _mixed_workload(tmp_path)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    multi.attach(nxs, gidx, 0, 1)
+    got = gidx.search_batch(qs, limit=10)
+    for q, g in zip(qs, got):
+        assert_same(g, oidx.search(q, limit=10), q)
+    assert_same(gidx.search(qs[0], limit=10), oidx.search(qs[0], limit=10))    # never sharded
+    gidx.shard(0, 1, None)                            # detach
+    got = gidx.search_batch(qs[:16], limit=10)
+    for q, g in zip(qs, got):
+        assert_same(g, oidx.search(q, limit=10), q)
+    gidx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_emulated_ranks_reassemble(nxs, tmp_path, monkeypatch, world):
+    """Every rank of a W-rank run, one after the other on the one GPU, with the
+    collective left out: each plans and scans ITS slice of the same mixed batch
+    (errors, unresolvable and fuzzy tokens, a wide query, candidate overflow ->
+    exact fix-up); the W record blocks go through the library's reassembly."""
+    from nxsearch_amd import multi
+    c, terms, qs = _mixed_workload(tmp_path, docs=120_000, n_terms=5000, n=61, seed=49)
+    T = lambda r: terms[r - 1].decode()
+    qs[3] = "cat AND"                                  # syntax error on its owner
+    qs[11] = "zzzzzzzzzzzz OR qqqqqqqqqqqq"            # nothing resolves: empty
+    qs[29] = " OR ".join(T(r) for r in range(1, 41))   # 40 tokens: wide plan
+    qs[57] = T(1)                                      # dense single term
+    monkeypatch.setenv("NXS_GPU_SEGCAP", "4")          # tiny segments: some queries overflow
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    n, k = len(qs), 10
+    cap = multi.shard_capacity(n, world)
+    blocks = b""
+    for r in range(world):
+        multi.emulate(gidx, r, world)
+        gidx.search_batch_begin(qs, limit=k)
+        got = gidx.search_batch_end()
+        assert all(isinstance(g, N.NxsError) for g in got)      # emulation hands out the block only
+        blk = multi.emulated_block(gidx)
+        assert len(blk) == multi.block_bytes(cap, k)
+        blocks += blk
+    multi.emulate(gidx, 0, 0)
+    got = multi.assemble(blocks, world, cap, k, n)
+    for q, g in zip(qs, got):
+        try:
+            want = oidx.search(q, limit=k)
+        except O.SearchError as e:
+            assert isinstance(g, N.NxsError) and g.code == e.code, q
+            continue
+        assert_same(g, want, (world, q[:50]))
+    gidx.close()
+
+
+def test_default_limit_batch_on_a_larger_corpus(nxs, tmp_path):
+    """nxs_index_search(idx, NULL, ...) asks for 1000 results: the heap leaves the
+    LDS for the two-pass global-memory path.  400k docs, batch + single calls."""
+    c = corpus.write_corpus(str(tmp_path), 400_000, 20_000, seed=31)
+    terms = corpus.term_strings(20_000, seed=31)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    qs = corpus.queries_bool5(terms, 20, seed=7, lo=1, hi=2000)
+    qs += corpus.queries_single(terms, 6, seed=2, lo=1, hi=300)
+    got = gidx.search_batch(qs, fuzzymatch=False)               # no limit given => 1000
+    for q, g in zip(qs, got):
+        want = oidx.search(q, fuzzymatch=False)
+        assert len(want) <= 1000
+        assert_same(g, want, q)
+    assert any(len(g) == 1000 for g in got)
+    for q in qs[:4]:
+        assert_same(gidx.search(q), oidx.search(q), q)
     gidx.close()
 
 

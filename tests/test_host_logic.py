@@ -111,6 +111,83 @@ def test_plan_token_order_truth_table_and_empty_leaves():
     assert empty
 
 
+def _eval_wide(prog, present):
+    st = []
+    for op in prog:
+        if op < 0x8000:
+            st.append(op in present)
+        elif op == 0xffff:
+            st.append(False)
+        else:
+            b, a = st.pop(), st.pop()
+            st.append((a and b) if op == 0xfff0 else (a or b) if op == 0xfff1 else (a and not b))
+    assert len(st) == 1
+    return st[0]
+
+
+def test_wide_plans_beyond_32_tokens():
+    """More than 32 live tokens / 256 program items / a 64-deep stack compile into
+    the variable-size wide plan (the reference has no such bounds); its program
+    is checked against Python set algebra on random presence sets."""
+    words = ["w%d" % i for i in range(1, 1101)]
+    rng = random.Random(77)
+    # a OR b OR ... (40 terms): token order is right-to-left
+    code, wide, tids, prog = N.compile_wide(" OR ".join(words[:40]), words)
+    assert (code, wide) == (0, True) and tids == list(range(40, 0, -1))
+    assert len(prog) == 79 and prog.count(0xfff1) == 39
+    # 32 tokens still take the fixed-size plan
+    code, wide, _, _ = N.compile_wide(" OR ".join(words[:32]), words)
+    assert (code, wide) == (0, False)
+    # > 256 program items with few tokens; deep right nesting
+    code, wide, tids, prog = N.compile_wide(
+        " OR ".join("(%s AND %s)" % (words[i % 20], words[(i * 7 + 3) % 20]) for i in range(70)), words)
+    assert (code, wide, len(tids), len(prog)) == (0, True, 20, 279)
+    q = "".join("%s AND (" % words[i] for i in range(69)) + words[69] + ")" * 69
+    code, wide, tids, prog = N.compile_wide(q, words)
+    assert (code, wide, len(tids)) == (0, True, 70)
+    for _ in range(20):
+        present = {i for i in range(70) if rng.random() < 0.9}
+        assert _eval_wide(prog, present) == (len(present) == 70)
+    # random mixed expressions over 50..200 tokens
+    for _ in range(40):
+        n = rng.randint(50, 200)
+        ws = rng.sample(words, n)
+        q, expr = ws[0], "P['%s']" % ws[0]
+        # left-assoc chain with NOT>AND>OR precedence, mirrored in Python
+        terms, ops = [ws[0]], []
+        for w in ws[1:]:
+            ops.append(rng.choice(["AND", "OR", "AND NOT"]))
+            terms.append(w)
+        q = terms[0] + "".join(" %s %s" % (o, t) for o, t in zip(ops, terms[1:]))
+        code, wide, tids, prog = N.compile_wide(q, words)
+        assert (code, wide, len(tids)) == (0, True, n), q[:60]
+        bit = {("w%d" % t): i for i, t in enumerate(tids)}
+        for _ in range(8):
+            P = {w: rng.random() < 0.5 for w in ws}
+            # AND / AND NOT bind tighter than OR; all left-associative
+            groups, cur = [], P[terms[0]]
+            for o, t in zip(ops, terms[1:]):
+                if o == "OR":
+                    groups.append(cur)
+                    cur = P[t]
+                elif o == "AND":
+                    cur = cur and P[t]
+                else:
+                    cur = cur and not P[t]
+            groups.append(cur)
+            assert _eval_wide(prog, {bit[w] for w in ws if P[w]}) == any(groups), q[:60]
+    # 1025 live tokens: beyond the wide plan too => NXS_ERR_LIMIT (documented)
+    code, wide, _, _ = N.compile_wide("(" + " OR ".join(words[:600]) + ") AND (" + " OR ".join(words[600:1025]) + ")", words)
+    assert code == 6
+    code, wide, tids, _ = N.compile_wide("(" + " OR ".join(words[:600]) + ") AND (" + " OR ".join(words[600:1024]) + ")", words)
+    assert code == 6          # nesting limit (100 levels) is hit first by a 600-term chain
+    bal = lambda ws: ws[0] if len(ws) == 1 else "(%s OR %s)" % (bal(ws[:len(ws) // 2]), bal(ws[len(ws) // 2:]))
+    code, wide, tids, _ = N.compile_wide(bal(words[:1024]), words)
+    assert (code, wide, len(tids)) == (0, True, 1024)
+    code, _, _, _ = N.compile_wide(bal(words[:1025]), words)
+    assert code == 6
+
+
 def test_plan_truth_table_matches_set_algebra_on_random_queries():
     rng = random.Random(5)
     words = list("abcdefgh")

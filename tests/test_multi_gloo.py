@@ -1,15 +1,30 @@
-"""N > 1 path on CPU: two processes over the gloo backend exercise the
-query sharding and the all-gather of per-rank top-k records (the same code
-bench.py runs over RCCL/xGMI)."""
+"""N > 1 path on CPU (no GPU here): two processes over the gloo backend run a
+REAL sharded search of a tiny corpus -- every rank plans nothing by hand: it
+takes its slice of the batch (the library's nxsgpu_shard_slice), answers its
+queries (the oracle stands in for the device scan, which needs a GPU), packs
+them into the library's record block, all-gathers the blocks (gloo stands in
+for RCCL: the ONE collective of the path), and runs the library's reassembly
+(resps_from_blocks, the code nxs_index_search_batch_end runs on every rank).
+The `-m gpu` tier runs the same reassembly on blocks the GPU produced
+(tests/test_gpu_parity.py::test_sharded_*)."""
 import os
 import socket
+import struct
 
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import nxsfmt
+import oracle_lib as O
 from nxsearch_amd import multi
+
+DOCS = {1: "cat dog cow", 2: "dog cow", 3: "cat cat cat", 4: "emu cat dog", 5: "cow emu",
+        6: "gnu cat", 7: "dog dog gnu cow", 8: "emu", 9: "cat cow gnu", 10: "yak"}
+QUERIES = ["cat", "dog AND cow", "emu OR gnu", "cat AND NOT dog", "zebra", "cat AND", "yak OR cot",
+           "cow", "(cat OR dog) AND gnu", "gnu", "dog cow emu", "'cat'", "cow AND (", "emu AND cat",
+           "yak", "dog OR dog", "cat OR zebra"]
 
 
 def _free_port():
@@ -20,32 +35,36 @@ def _free_port():
     return p
 
 
-def _fake_topk(qi, k):
-    """Deterministic stand-in for one query's device result."""
-    cnt = qi % (k + 1)
-    ids = [(qi * 1000003 + j * 7919) % (1 << 40) for j in range(cnt)]
-    sc = [1.0 / (1 + qi + j) for j in range(cnt)]
-    return cnt, ids, sc
+def _answer(oidx, q, k):
+    try:
+        return 0, oidx.search(q, limit=k)
+    except O.SearchError as e:
+        return e.code, []
 
 
-def _worker(rank, world, port, n, k, ret):
+def _worker(rank, world, port, tdir, n, k, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sb = multi.ShardedBatch(n, k, rank, world, torch.device("cpu"))
-    for i, qi in enumerate(range(sb.lo, sb.hi)):
-        cnt, ids, sc = _fake_topk(qi, k)
-        sb.counts[i] = cnt
-        sb.ids[i, :cnt] = torch.tensor(ids, dtype=torch.int64)
-        sb.scores[i, :cnt] = torch.tensor(sc, dtype=torch.float32)
-    sb.gather(dist)
-    ids, scores, counts = sb.assemble()
-    ok = ids.shape == (n, k) and counts.shape == (n,)
-    for qi in range(n):
-        cnt, eids, esc = _fake_topk(qi, k)
-        ok &= int(counts[qi]) == cnt
-        ok &= ids[qi, :cnt].tolist() == eids
-        ok &= torch.allclose(scores[qi, :cnt], torch.tensor(esc, dtype=torch.float32))
+    oidx = O.Index(os.path.join(tdir, "nxsterms"), os.path.join(tdir, "nxsdtmap"))
+    queries = QUERIES[:n]
+    lo, hi = multi.shard_slice(n, rank, world)
+    cap = multi.shard_capacity(n, world)
+    mine = [_answer(oidx, q, k) for q in queries[lo:hi]]
+    block = multi.pack_block(mine, cap, k)
+    assert len(block) == multi.block_bytes(cap, k)
+    send = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    recv = torch.empty(world * len(block), dtype=torch.uint8)
+    dist.all_gather_into_tensor(recv, send)           # the one collective
+    got = multi.assemble(recv.numpy().tobytes(), world, cap, k, n)
+    ok = len(got) == n
+    for q, g in zip(queries, got):
+        code, want = _answer(oidx, q, k)
+        if code:
+            ok &= isinstance(g, Exception) and g.code == code
+        else:
+            ok &= [d for d, _ in g] == [d for d, _ in want]
+            ok &= [struct.pack("<f", s) for _, s in g] == [struct.pack("<f", s) for _, s in want]
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -61,11 +80,27 @@ def test_shard_slices_partition_the_batch():
             assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1
 
 
-@pytest.mark.parametrize("n", [5, 64])
-def test_two_rank_allgather_reassembles_the_batch(n):
-    world, k = 2, 10
+def test_record_layout_is_the_documented_one():
+    # u32 count | u32 flags | k x u64 | k x f32, padded to 8: 128 B at k = 10
+    assert multi.rec_bytes(10) == 128 and multi.rec_bytes(1) == 24 and multi.rec_bytes(64) == 776
+    blk = multi.pack_block([(0, [(7, 1.5), (3, 0.25)]), (3, [])], 3, 10)
+    assert len(blk) == 3 * 128 + 16
+    assert struct.unpack_from("<IIQQ", blk, 0) == (2, 0, 7, 3)
+    assert struct.unpack_from("<ff", blk, 8 + 80) == (1.5, 0.25)
+    assert struct.unpack_from("<III", blk, 3 * 128) == (0, 3, 0)
+    got = multi.assemble(blk, 1, 3, 10, 3)
+    assert got[0] == [(7, 1.5), (3, 0.25)] and got[1].code == 3 and got[2] == []
+
+
+@pytest.mark.parametrize("n,k", [(5, 10), (17, 10), (16, 3)])
+def test_two_rank_sharded_search_reassembles_the_batch(tmp_path, n, k):
+    world = 2
+    nxsfmt.write_index(str(tmp_path), "idx", [(d, t.split()) for d, t in DOCS.items()])
+    tdir = str(tmp_path)
+    if not os.path.exists(os.path.join(tdir, "nxsterms")):
+        tdir = os.path.join(tdir, "data", "idx")
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, k, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, tdir, n, k, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}

@@ -205,6 +205,7 @@ def main():
     run(args.warmup)
     idx.set_profiling(True)
     idx.profile(reset=True)
+    idx.host_profile()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -213,6 +214,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = idx.profile(reset=True)
+    host_prof = idx.host_profile()
     idx.set_profiling(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -265,6 +267,7 @@ def main():
                                   "record blocks per step" % world if world > 1 else
                                   "one GPU, no collective"},
         "roofline": roofline,
+        "host_ms_per_step": host_prof,
         "results_per_step": int(res.results // max(args.steps, 1)),
         "failed_queries": int(res.failed),
         "setup_s": {"corpus": round(t_gen, 1), "index_load": round(t_load, 1)},
@@ -520,6 +523,10 @@ def cpu_np_worker(args):
     t_load = time.time() - t0
     P = max(1, args.np)
     pipes = []
+    # same mix of query shapes for every worker: shuffle before slicing; a worker
+    # that runs out of queries starts over, so that all P stay busy for the budget
+    import random
+    random.Random(12345).shuffle(queries)
     t_start = time.time()
     for w in range(P):
         r, wfd = os.pipe()
@@ -527,13 +534,15 @@ def cpu_np_worker(args):
         if pid == 0:
             os.close(r)
             n, t_used = 0, 0.0
+            mine = queries[w::P] or queries
             t_begin = time.perf_counter()
-            for q in queries[w::P]:
-                oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=fuzzy_on)
-                n += 1
-                t_used = time.perf_counter() - t_begin
-                if t_used >= args.cpu_seconds:
-                    break
+            while t_used < args.cpu_seconds:
+                for q in mine:
+                    oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=fuzzy_on)
+                    n += 1
+                    t_used = time.perf_counter() - t_begin
+                    if t_used >= args.cpu_seconds:
+                        break
             os.write(wfd, ("%d %.6f\n" % (n, t_used)).encode())
             os._exit(0)
         os.close(wfd)

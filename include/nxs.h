@@ -139,6 +139,13 @@ int		nxs_index_plan_batch(nxs_index_t *, nxs_params_t *,
 nxs_index_t *	nxs_index_open_files(nxs_t *, const char *terms_path,
 		    const char *dtmap_path, const char *algo, bool lowercase);
 
+/*
+ * Host-side phase times of the batches since the last call, in seconds:
+ * out[0] parse/resolve/compile, out[1] queueing on the device, out[2] waiting
+ * for the device, out[3] building responses, out[4] number of batches.
+ */
+void		nxs_index_host_profile(nxs_index_t *, double out[5]);
+
 /* The device-side handle behind an index (see nxs_gpu.h), for benches. */
 struct nxsgpu_index;
 struct nxsgpu_index *nxs_index_device(nxs_index_t *);

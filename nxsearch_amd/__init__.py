@@ -81,6 +81,7 @@ NXS_H_SYMBOLS = [
     "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
     "nxs_index_plan_batch", "nxs_index_search_batch_begin",
     "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
+    "nxs_index_host_profile",
 ]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -397,6 +398,17 @@ class Index:
         """nxs_index_shard(): collective; `uid` from shard_unique_id() of rank 0."""
         if lib().nxs_index_shard(self._h, rank, world, uid) != 0:
             self.nxs._raise()
+
+    def host_profile(self):
+        """nxs_index_host_profile(): per-batch host phase times in ms."""
+        out = (C.c_double * 5)()
+        L = lib()
+        L.nxs_index_host_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.nxs_index_host_profile(self._h, out)
+        n = max(out[4], 1.0)
+        return {"plan_ms": round(1e3 * out[0] / n, 4), "queue_ms": round(1e3 * out[1] / n, 4),
+                "wait_ms": round(1e3 * out[2] / n, 4), "resps_ms": round(1e3 * out[3] / n, 4),
+                "batches": int(out[4])}
 
     def reconfigure(self):
         """Re-read the NXS_GPU_* switches (parsed once at open); tests/tools."""

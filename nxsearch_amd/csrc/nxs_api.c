@@ -20,6 +20,7 @@
 #include <limits.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <pthread.h>
 #include <stdatomic.h>
 #include <unistd.h>
@@ -940,6 +941,32 @@ nxs_index_plan_batch(nxs_index_t *idx, nxs_params_t *params,
 
 /* ---- batches: begin / end ------------------------------------------------------- */
 
+static inline double
+now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/*
+ * Where the host's time goes, summed over the batches so far: out[0] parse +
+ * resolve + compile (worker pool), out[1] queueing the batch on the device
+ * (work list, staging, launches), out[2] waiting for the device, out[3]
+ * building the responses; out[4] = batches.  Reset on read.
+ */
+void
+nxs_index_host_profile(nxs_index_t *idx, double out[5])
+{
+	out[0] = idx->hp_plan;
+	out[1] = idx->hp_queue;
+	out[2] = idx->hp_wait;
+	out[3] = idx->hp_resps;
+	out[4] = (double)idx->hp_batches;
+	idx->hp_plan = idx->hp_queue = idx->hp_wait = idx->hp_resps = 0;
+	idx->hp_batches = 0;
+}
+
 /* status word of a record slot: 0, an nxs_err_t, or ... */
 #define	STATUS_HOSTPATH	0x100u	/* the owner evaluates it on the exact path (fix-up round) */
 
@@ -993,6 +1020,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	uint32_t *slot_of = NULL, *status = NULL;
 	uint64_t lo = 0, hi = n;
 	size_t n_plans = 0, nl;
+	double t0, t1 = 0;
 	int ret = -1;
 
 	nxs_clear_error(nxs);
@@ -1046,9 +1074,12 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 		goto out;
 	}
+	t0 = now_s();
 	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1) {
 		goto out;
 	}
+	t1 = now_s();
+	idx->hp_plan += t1 - t0;
 	if (sp.limit <= NXSGPU_FAST_K) {
 		plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
 		slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
@@ -1078,6 +1109,8 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		}
 		pd->on_device = true;
 	}
+	idx->hp_queue += now_s() - t1;
+	idx->hp_batches++;
 	pd->seq = ++idx->pend_seq;
 	pd->active = true;
 	ret = 0;
@@ -1217,6 +1250,7 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 	uint8_t *patched = NULL;
 	uint32_t *which, *pos;
 	size_t nw = 0, total = 0, n, nl;
+	double t0;
 	int failed = 0, ret = -1;
 
 	memset(&res, 0, sizeof(res));
@@ -1250,10 +1284,13 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 		const bool all = W == 1 || !idx->emu_world;
 		bool fixup = false;
 
+		t0 = now_s();
 		if (nxsgpu_batch_end(idx->dev, &v) != 0) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
 			goto out;
 		}
+		idx->hp_wait += now_s() - t0;
+		t0 = now_s();
 		blocks = v.blocks;
 		if (all && v.world != W) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "sharded batch came back with %u blocks, not %u",
@@ -1337,6 +1374,7 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 		if (resps_from_blocks(nxs, pd, n, W, v.n_slots, v.k, blocks, resps, errs, &sb, &failed) == -1) {
 			goto out;
 		}
+		idx->hp_resps += now_s() - t0;
 	} else {
 		/* limit > NXSGPU_FAST_K: the exact two-pass path for the whole batch */
 		for (size_t i = 0; i < nl; i++) {

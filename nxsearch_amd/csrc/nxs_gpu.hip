@@ -205,6 +205,7 @@ struct nxsgpu_index {
 		size_t		h_blocks_len;
 		uint32_t	n_slots, k, world;
 		size_t		rec_bytes, block_bytes;
+		uint32_t *	h_ovf;		/* overflow flags coming back (inside h_stage) */
 	}		slot[2];
 	uint64_t	slot_seq;
 
@@ -5017,12 +5018,27 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		return 0;
 	}
 
-	/* record blocks: device (world blocks; this rank's own one is the send
-	 * buffer, at its rank position) and pinned host copies */
-	uint8_t *d_myblock = NULL;
+	/*
+	 * A small batch with nothing else in flight (a single nxs_index_search())
+	 * is latency-bound: everything goes down ONE stream -- no cross-stream event
+	 * hops, each worth 10-20 us.  Otherwise plans go up and records come down on
+	 * their own streams, beside the neighbouring batches' scans.
+	 */
+	bool others = false;
+	for (int i = 0; i < 2; i++) {
+		others = others || ix->slot[i].active;
+	}
+	const bool solo = nq <= 64 && !others && !gather;
+	hipStream_t s_up = solo ? ix->stream : ix->stream_up;
+	hipStream_t s_down = solo ? ix->stream : ix->stream_down;
+
+	/* record blocks: pinned host copies of all ranks' blocks; on the device the
+	 * own block is part of the uploaded workspace (one rank), or sits at its rank
+	 * position of the all-gather's receive buffer (in-place send) */
+	const size_t recs_len = (size_t)o.n_slots * sl->rec_bytes;
 	if (o.records) {
 		const size_t need = (size_t)world * sl->block_bytes + 256;
-		if (sl->d_blocks_len < need) {
+		if (world > 1 && sl->d_blocks_len < need) {
 			(void)hipFree(sl->d_blocks);
 			sl->d_blocks = NULL;
 			sl->d_blocks_len = 0;
@@ -5044,15 +5060,15 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			}
 			sl->h_blocks_len = need;
 		}
-		d_myblock = sl->d_blocks + (size_t)my_rank * sl->block_bytes;
 	}
+	const bool block_in_ws = o.records && world == 1;
 
 	/* plans straight into the pinned staging area (room for the work list:
 	 * <= target + nq ranges, see build_worklist) */
 	const uint64_t wave_target = ix->cfg.wave_target;
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
-	const size_t stage_need = 16384 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 12)
-	    + seg_bound * (sizeof(item_t) + 4) + nq * 4 + (size_t)o.n_slots * 4;
+	const size_t stage_need = 32768 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
+	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + sl->block_bytes;
 	if (slot_ensure(*sl, 0, stage_need) != 0) {
 		return -1;
 	}
@@ -5067,20 +5083,29 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		set_error("work list larger than its bound (%llu > %zu)", (unsigned long long)nseg, seg_bound);
 		return -1;
 	}
+	/*
+	 * Everything the kernels read from the host -- the zero-filled flag, threshold
+	 * and record arrays included -- is ONE block and ONE copy up.
+	 */
 	qmeta_t *h_qmeta = carve<qmeta_t>(hp, nq);
 	item_t *h_items = carve<item_t>(hp, nseg);
 	uint32_t *h_bnd_q = carve<uint32_t>(hp, nseg + nq);
 	uint32_t *h_qorder = carve<uint32_t>(hp, nq);
 	uint32_t *h_recslot = carve<uint32_t>(hp, nq);
-	const size_t up_len = (size_t)(hp - sl->h_stage);
 	uint32_t *h_ovf = carve<uint32_t>(hp, nq);
-	uint32_t *h_status = carve<uint32_t>(hp, o.n_slots);
+	float *h_pub = carve<float>(hp, nseg);
+	uint8_t *h_block = carve<uint8_t>(hp, block_in_ws ? sl->block_bytes : 0);
+	const size_t up_len = (size_t)(hp - sl->h_stage);
+	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, o.n_slots);
 	if (nq) {
 		memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
 		memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));
 		memcpy(h_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4);
 		memcpy(h_qorder, wl.qorder.data(), nq * 4);
+		memset(h_ovf, 0, nq * 4);
+		memset(h_pub, 0, nseg * 4);
 	}
+	sl->h_ovf = h_ovf;
 	if (o.records) {
 		for (uint32_t i = 0; i < nq; i++) {
 			if (o.slot_of_plan[i] >= o.n_slots) {
@@ -5088,6 +5113,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 				return -1;
 			}
 			h_recslot[i] = o.slot_of_plan[i];
+		}
+		if (block_in_ws) {
+			memset(h_block, 0, sl->block_bytes);
 		}
 		if (o.status) {
 			memcpy(h_status, o.status, (size_t)o.n_slots * 4);
@@ -5098,8 +5126,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 
 	/* device workspace: the uploaded block first (same carve sequence => same
 	 * offsets), then what only the kernels touch */
-	const size_t ws_need = 16384 + up_len + nseg * 4 + nq * 4
-	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * 4 + nseg * (size_t)seg_cap * 8;
+	const size_t ws_need = 32768 + up_len + nseg * 4
+	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8;
 	if (slot_ensure(*sl, ws_need, 0) != 0) {
 		return -1;
 	}
@@ -5110,25 +5138,26 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
 	uint32_t *d_qorder = carve<uint32_t>(p, nq);
 	uint32_t *d_recslot = carve<uint32_t>(p, nq);
-	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
 	uint32_t *d_ovf = carve<uint32_t>(p, nq);
-	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	float *d_pub = carve<float>(p, nseg);
+	uint8_t *d_myblock = carve<uint8_t>(p, block_in_ws ? sl->block_bytes : 0);
+	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
+	if (o.records && !block_in_ws) {
+		d_myblock = sl->d_blocks + (size_t)my_rank * sl->block_bytes;
+	}
 
 	sl->seq = ++ix->slot_seq;
-	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, ix->stream_up) != hipSuccess ||
-	    (nq && hipMemsetAsync(d_ovf, 0, nq * 4, ix->stream_up) != hipSuccess) ||
-	    (nseg && hipMemsetAsync(d_pub, 0, nseg * 4, ix->stream_up) != hipSuccess)) {
+	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, s_up) != hipSuccess) {
 		set_error("query upload failed");
 		return begin_fail(ix);
 	}
-	if (o.records) {
-		const size_t recs = (size_t)o.n_slots * sl->rec_bytes;
-		if ((recs && hipMemsetAsync(d_myblock, 0, recs, ix->stream_up) != hipSuccess) ||
-		    (o.n_slots && hipMemcpyAsync(d_myblock + recs, h_status, (size_t)o.n_slots * 4,
-		    hipMemcpyHostToDevice, ix->stream_up) != hipSuccess)) {
+	if (o.records && !block_in_ws) {
+		if ((recs_len && hipMemsetAsync(d_myblock, 0, recs_len, s_up) != hipSuccess) ||
+		    (o.n_slots && hipMemcpyAsync(d_myblock + recs_len, h_status, (size_t)o.n_slots * 4,
+		    hipMemcpyHostToDevice, s_up) != hipSuccess)) {
 			set_error("record block setup failed");
 			return begin_fail(ix);
 		}
@@ -5174,10 +5203,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * the previous batch's scans instead of in front of this batch's.
 	 */
 	if (nq) {
-		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), ix->stream_up);
+		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), s_up);
 	}
-	if (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
-	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess) {
+	if (!solo && (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
+	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess)) {
 		set_error("query upload failed");
 		return begin_fail(ix);
 	}
@@ -5212,25 +5241,27 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		 * per batch, sharded runs only) and the copy to pinned memory overlap the
 		 * next batch's scans instead of sitting in front of them.
 		 */
-		uint8_t *src = d_myblock;
-		size_t len = sl->block_bytes;
-		if (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
-		    hipStreamWaitEvent(ix->stream_down, sl->ev_res, 0) != hipSuccess) {
+		if (!solo && (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
+		    hipStreamWaitEvent(s_down, sl->ev_res, 0) != hipSuccess)) {
 			set_error("event failed");
 			return begin_fail(ix);
 		}
 		if (world > 1) {
-			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes,
-			    ix->stream_down) != 0) {
+			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes, s_down) != 0) {
 				return begin_fail(ix);
 			}
-			src = sl->d_blocks;
-			len = (size_t)world * sl->block_bytes;
-		}
-		if ((len && hipMemcpyAsync(sl->h_blocks + (src - sl->d_blocks), src, len, hipMemcpyDeviceToHost,
-		    ix->stream_down) != hipSuccess) ||
-		    hipEventRecord(sl->ev_done, ix->stream_down) != hipSuccess) {
+			if (hipMemcpyAsync(sl->h_blocks, sl->d_blocks, (size_t)world * sl->block_bytes,
+			    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
+				set_error("copy failed");
+				return begin_fail(ix);
+			}
+		} else if (sl->block_bytes && hipMemcpyAsync(sl->h_blocks, d_myblock, sl->block_bytes,
+		    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
 			set_error("copy failed");
+			return begin_fail(ix);
+		}
+		if (hipEventRecord(sl->ev_done, s_down) != hipSuccess) {
+			set_error("event failed");
 			return begin_fail(ix);
 		}
 	}
@@ -5328,16 +5359,7 @@ nxsgpu_search_dev_end(nxsgpu_index_t *ix)
 	if (slot_wait(ix, sl) != 0) {
 		return -1;
 	}
-	/* the flags sit behind the uploaded block, same carve sequence as _begin */
-	uint8_t *hp = sl->h_stage;
-	(void)carve<dev_query_t>(hp, sl->nq);
-	const qmeta_t *h_qmeta = carve<qmeta_t>(hp, sl->nq);
-	const uint64_t nseg = (uint64_t)h_qmeta[sl->nq - 1].seg_first + h_qmeta[sl->nq - 1].n_groups;
-	(void)carve<item_t>(hp, nseg);
-	(void)carve<uint32_t>(hp, nseg + sl->nq);
-	(void)carve<uint32_t>(hp, sl->nq);
-	(void)carve<uint32_t>(hp, sl->nq);
-	const uint32_t *h_ovf = carve<uint32_t>(hp, sl->nq);
+	const uint32_t *h_ovf = sl->h_ovf;
 	for (uint32_t i = 0; i < sl->nq; i++) {
 		if (h_ovf[i]) {
 			return 1;

@@ -106,6 +106,9 @@ struct nxs_index {
 	nxsgpu_comm_t *	comm;
 	struct nxs_pend	pend[2];
 	uint64_t	pend_seq;
+	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
+	double		hp_plan, hp_queue, hp_wait, hp_resps;
+	uint64_t	hp_batches;
 	/* tests: play one rank of emu_world (nxs_test_shard_emulate) */
 	int		emu_rank, emu_world;
 	uint8_t *	emu_block;

@@ -202,6 +202,9 @@ def main():
             raise N.NxsError(*nxs.error())
         return out
 
+    # measured HBM read rate of this device (roofline denominator), before the
+    # timed region: it also brings the memory clocks up
+    measured = L.nxsgpu_hbm_read_gbs(idx.device, 5)
     run(args.warmup)
     idx.set_profiling(True)
     idx.profile(reset=True)
@@ -221,6 +224,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    repeats = []
+    for _ in range(int(os.environ.get("NXS_BENCH_REPEATS", "0"))):     # diagnostics: run-to-run spread
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        repeats.append(round(1e3 * (time.perf_counter() - t0) / args.steps, 4))
+
     total_q = n_total * args.steps
     qps = total_q / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -232,7 +243,6 @@ def main():
     alg_bytes = prof["postings"] * POSTING_BYTES / launches + matched * RESULT_BYTES
     scan_ms = prof["scan_ms"] / launches
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    measured = L.nxsgpu_hbm_read_gbs(idx.device, 5) if rank == 0 else 0.0
     traffic, traffic_src = pmc_traffic(args, world)
     # one scan launch per query class and step; on C3: k_scanm<5,false> (pure OR of
     # sparse terms), k_scan8<0,5,1> (pure OR with a dense term) and k_scanr<0,5>
@@ -268,6 +278,7 @@ def main():
                                   "one GPU, no collective"},
         "roofline": roofline,
         "host_ms_per_step": host_prof,
+        **({"repeat_ms_per_step": repeats} if repeats else {}),
         "results_per_step": int(res.results // max(args.steps, 1)),
         "failed_queries": int(res.failed),
         "setup_s": {"corpus": round(t_gen, 1), "index_load": round(t_load, 1)},

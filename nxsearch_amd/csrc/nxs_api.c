@@ -387,9 +387,11 @@ name_ok(const char *s)
 
 static nxs_index_t *
 index_open_common(nxs_t *nxs, const char *name, const char *terms_path,
-    const char *dtmap_path, int algo, bool lowercase)
+    const char *dtmap_path, int algo, const char *const *filters, size_t n_filters,
+    const char *lang)
 {
 	nxs_index_t *idx = calloc(1, sizeof(nxs_index_t)), **list;
+	const char *ferr = NULL;
 
 	if (!idx) {
 		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
@@ -397,10 +399,23 @@ index_open_common(nxs_t *nxs, const char *name, const char *terms_path,
 	}
 	idx->nxs = nxs;
 	idx->algo = algo;
-	idx->lowercase = lowercase;
 	idx->name = strdup(name);
+	/* filter_pipeline_create (nxs.c:412-419): the query side of it */
+	if (n_filters) {
+		idx->filters = nxs_filters_create(nxs->basedir, filters, n_filters, lang, &ferr);
+		if (!idx->filters) {
+			nxs_decl_err(nxs, NXS_ERR_INVALID, "%s", ferr ? ferr : "filter pipeline failed");
+			free(idx->name);
+			free(idx);
+			return NULL;
+		}
+		for (size_t i = 0; i < n_filters; i++) {
+			idx->lowercase = idx->lowercase || strcmp(filters[i], "normalizer") == 0;
+		}
+	}
 	if (nxs_index_load(idx, terms_path, dtmap_path) == -1) {
 		nxs_index_unload(idx);
+		nxs_filters_destroy(idx->filters);
 		free(idx->name);
 		free(idx);
 		return NULL;
@@ -434,13 +449,42 @@ json_get_str(const char *json, const char *key)
 	return strndup(p, e - p);
 }
 
+/* the strings of a JSON array of strings: "key": ["a", "b"] -> count */
+static size_t
+json_get_strlist(const char *json, const char *key, char **out, size_t cap)
+{
+	char pat[64];
+	const char *p, *end;
+	size_t n = 0;
+
+	snprintf(pat, sizeof(pat), "\"%s\"", key);
+	if ((p = strstr(json, pat)) == NULL) {
+		return 0;
+	}
+	p += strlen(pat);
+	while (*p == ' ' || *p == ':' || *p == '\t' || *p == '\n') p++;
+	if (*p != '[' || (end = strchr(p, ']')) == NULL) {
+		return 0;
+	}
+	while (n < cap) {
+		const char *q = memchr(p, '"', (size_t)(end - p)), *e;
+		if (!q || (e = memchr(q + 1, '"', (size_t)(end - q - 1))) == NULL) {
+			break;
+		}
+		out[n++] = strndup(q + 1, (size_t)(e - q - 1));
+		p = e + 1;
+	}
+	return n;
+}
+
 nxs_index_t *
 nxs_index_open(nxs_t *nxs, const char *name)
 {
 	char *ppath = NULL, *tpath = NULL, *dpath = NULL, *json = NULL, *algo_name = NULL;
+	char *filters[8] = { NULL }, *lang = NULL;
+	size_t n_filters = 0;
 	nxs_index_t *idx = NULL;
 	struct stat sb;
-	bool lowercase;
 	FILE *fp;
 	int algo;
 
@@ -484,10 +528,16 @@ nxs_index_open(nxs_t *nxs, const char *name)
 		nxs_decl_err(nxs, NXS_ERR_FATAL, "corrupted index params");
 		goto out;
 	}
-	/* only the ASCII lower-casing of the "normalizer" filter is provided */
-	lowercase = strstr(json, "\"normalizer\"") != NULL;
-	idx = index_open_common(nxs, name, tpath, dpath, algo, lowercase);
+	/* "filters": [...] in list order, "lang" (nxs.c:263-266; params.db) */
+	n_filters = json_get_strlist(json, "filters", filters, 8);
+	lang = json_get_str(json, "lang");
+	idx = index_open_common(nxs, name, tpath, dpath, algo,
+	    (const char *const *)filters, n_filters, lang);
 out:
+	for (size_t i = 0; i < n_filters; i++) {
+		free(filters[i]);
+	}
+	free(lang);
 	free(ppath);
 	free(tpath);
 	free(dpath);
@@ -507,7 +557,11 @@ nxs_index_open_files(nxs_t *nxs, const char *terms_path, const char *dtmap_path,
 		nxs_decl_err(nxs, NXS_ERR_INVALID, "invalid algorithm");
 		return NULL;
 	}
-	return index_open_common(nxs, terms_path, terms_path, dtmap_path, algo, lowercase);
+	{
+		static const char *const norm_only[] = { "normalizer" };
+		return index_open_common(nxs, terms_path, terms_path, dtmap_path, algo,
+		    norm_only, lowercase ? 1 : 0, "en");
+	}
 }
 
 static void index_drain(nxs_index_t *);
@@ -532,6 +586,7 @@ nxs_index_close(nxs_index_t *idx)
 		idx->comm = NULL;
 	}
 	free(idx->emu_block);
+	nxs_filters_destroy(idx->filters);
 	nxs_index_unload(idx);
 	free(idx->name);
 	free(idx);
@@ -1686,6 +1741,31 @@ nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint3
 	}
 	free(fake.errmsg);
 	return failed;
+}
+
+/* the "normalizer" stage (+ optional stop words from `basedir`) on one string:
+ * -> malloc'd result, NULL if discarded or on error (*act tells which) */
+char *
+nxs_test_filter(const char *basedir, int stopwords, const char *s, int *act)
+{
+	static const char *const names[] = { "normalizer", "stopwords" };
+	const char *err = NULL;
+	nxs_filters_t *f = nxs_filters_create(basedir, names, stopwords ? 2 : 1, "en", &err);
+	char *val = strdup(s);
+	size_t len = strlen(s);
+
+	*act = -2;
+	if (!f) {
+		free(val);
+		return NULL;
+	}
+	*act = nxs_filters_run(f, &val, &len);
+	nxs_filters_destroy(f);
+	if (*act != 1) {
+		free(val);
+		return NULL;
+	}
+	return val;
 }
 
 /* host BK-tree image over a word list (ids 1..n), for structure tests */

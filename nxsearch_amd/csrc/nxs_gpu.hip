@@ -186,6 +186,7 @@ struct nxsgpu_index {
 	 * device workspace and pinned staging; plans go up on their own stream */
 	hipStream_t	stream_up;
 	hipStream_t	stream_down;	/* record blocks: all-gather (sharded) + copy to pinned memory */
+	hipStream_t	stream_fz;	/* BK-tree searches: beside the batches in flight, not behind them */
 	struct nxsgpu_comm *comm;	/* attached communicator (query sharding) or NULL */
 	struct dev_slot_t {
 		void *		ws;
@@ -2653,6 +2654,7 @@ k_scanr(const scan_args_t A)
 	}
 }
 
+#ifdef NXS_EXPERIMENTAL	/* opt-in build: measured not faster than the tiles (DESIGN.md "dead ends") */
 /*
  * k_scanh: the posting-step path for queries without a very dense term.
  *
@@ -2986,6 +2988,7 @@ k_scanh(const scan_args_t A)
 		}
 	}
 }
+#endif /* NXS_EXPERIMENTAL */
 
 /* ------------------------------------------------------------------ */
 /* k_replay: the reference's heap, replayed exactly                     */
@@ -3826,6 +3829,10 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream_down) {
 		(void)hipStreamDestroy(ix->stream_down);
 	}
+	if (ix->stream_fz) {
+		(void)hipStreamSynchronize(ix->stream_fz);
+		(void)hipStreamDestroy(ix->stream_fz);
+	}
 	if (ix->ev_cls) {
 		(void)hipEventDestroy(ix->ev_cls);
 	}
@@ -3882,6 +3889,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
@@ -4134,7 +4142,11 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	const uint64_t target = cf.wave_target, min_post = cf.min_post;
 	/* densest term has >= this many postings per tile => tile path (step path
 	 * off by default: the tile path is at least as fast) */
+#ifdef NXS_EXPERIMENTAL
 	const double dense_thr = cf.dense_thr;
+#else
+	const double dense_thr = 0.0;	/* k_scanh is an opt-in build */
+#endif
 	const bool use_scanr = cf.use_scanr && ix->n_docs < (1ull << 31);
 	const bool no_step = cf.no_step, mask_off = cf.mask_off;
 	const uint32_t rmin = cf.rmin;	/* 3: "a AND b" takes k_scan8's sign-bit path */
@@ -4177,6 +4189,9 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 				const bool hit = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
 				and_only = hit == (m == (1u << hq[i].nt) - 1);
 			}
+#ifndef NXS_EXPERIMENTAL
+			and_only = false;	/* the sign-bit AND path (MM = 2) is an opt-in build */
+#endif
 			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
 			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
 			/* pure OR of 2..8 tokens whose lists are sparse: mask path (k_scanm).
@@ -4365,10 +4380,14 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 					hipLaunchKernelGGL((k_scan1<MODE>), grid, block, 0, ix->stream, a);
 				}
 				break;
-			case 2: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 2, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 2, 0>), grid, block, 0, ix->stream, a); } break;
-			case 3: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 3, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 3, 0>), grid, block, 0, ix->stream, a); } break;
-			case 5: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 5, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, 0>), grid, block, 0, ix->stream, a); } break;
-			default: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); } else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 8, 2>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, 0>), grid, block, 0, ix->stream, a); } break;
+			case 2: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); }
+#ifdef NXS_EXPERIMENTAL
+			else if (l.nomask == 2) { hipLaunchKernelGGL((k_scan8<MODE, 2, 2>), grid, block, 0, ix->stream, a); }
+#endif
+			else { hipLaunchKernelGGL((k_scan8<MODE, 2, 0>), grid, block, 0, ix->stream, a); } break;
+			case 3: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 3, 0>), grid, block, 0, ix->stream, a); } break;
+			case 5: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 5, 0>), grid, block, 0, ix->stream, a); } break;
+			default: if (l.nomask == 1) { hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); } else { hipLaunchKernelGGL((k_scan8<MODE, 8, 0>), grid, block, 0, ix->stream, a); } break;
 			}
 		} else if (l.kind == 4) {
 			/* mask path: top-k filter pass only; the exact passes (count, emit
@@ -4414,12 +4433,14 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			default: hipLaunchKernelGGL((k_scanr<MODE, 8>), grid, block, 0, ix->stream, a); break;
 			}
 		} else {
+#ifdef NXS_EXPERIMENTAL
 			switch (l.nt_bucket) {
 			case 2: hipLaunchKernelGGL((k_scanh<MODE, 2>), grid, block, 0, ix->stream, a); break;
 			case 3: hipLaunchKernelGGL((k_scanh<MODE, 3>), grid, block, 0, ix->stream, a); break;
 			case 5: hipLaunchKernelGGL((k_scanh<MODE, 5>), grid, block, 0, ix->stream, a); break;
 			default: hipLaunchKernelGGL((k_scanh<MODE, 8>), grid, block, 0, ix->stream, a); break;
 			}
+#endif
 		}
 		if (ra && l.q_count) {
 			replay_args_t r = *ra;
@@ -6046,17 +6067,17 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 		for (uint32_t i = 0; i <= nc; i++) {
 			roff[i] = tok_off[c0 + i] - boff;
 		}
-		if (hipMemcpyAsync(d_bytes, tok_bytes + boff, blen, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(d_off, roff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-		    hipMemsetAsync(counts, 0, levels * 4, ix->stream) != hipSuccess ||
-		    hipMemsetAsync(d_ovf, 0, 4, ix->stream) != hipSuccess ||
-		    hipMemsetAsync(d_evals, 0, 8, ix->stream) != hipSuccess) {
+		if (hipMemcpyAsync(d_bytes, tok_bytes + boff, blen, hipMemcpyHostToDevice, ix->stream_fz) != hipSuccess ||
+		    hipMemcpyAsync(d_off, roff.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ix->stream_fz) != hipSuccess ||
+		    hipMemsetAsync(counts, 0, levels * 4, ix->stream_fz) != hipSuccess ||
+		    hipMemsetAsync(d_ovf, 0, 4, ix->stream_fz) != hipSuccess ||
+		    hipMemsetAsync(d_evals, 0, 8, ix->stream_fz) != hipSuccess) {
 			set_error("fuzzy upload failed");
 			return -1;
 		}
-		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
-		hipLaunchKernelGGL(k_bk_peq, dim3(nc), dim3(256), 0, ix->stream, d_bytes, d_off, nc, d_peq);
-		hipLaunchKernelGGL(k_bk_seed, dim3((nc + 255) / 256), dim3(256), 0, ix->stream,
+		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream_fz);
+		hipLaunchKernelGGL(k_bk_peq, dim3(nc), dim3(256), 0, ix->stream_fz, d_bytes, d_off, nc, d_peq);
+		hipLaunchKernelGGL(k_bk_seed, dim3((nc + 255) / 256), dim3(256), 0, ix->stream_fz,
 		    qa, counts, nc, d_best, visited ? d_vis : (unsigned long long *)NULL);
 
 		memset(&fa, 0, sizeof(fa));
@@ -6078,27 +6099,27 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			fa.next = (lvl & 1) ? qa : qb;
 			fa.cur_count = counts + lvl;
 			fa.next_count = counts + lvl + 1;
-			hipLaunchKernelGGL(k_bk_level<false>, dim3(512), dim3(1024), 0, ix->stream, fa);
+			hipLaunchKernelGGL(k_bk_level<false>, dim3(512), dim3(1024), 0, ix->stream_fz, fa);
 			if (any_long) {
 				/* tokens longer than 64 bytes: row DP, bounded scratch */
-				hipLaunchKernelGGL(k_bk_level<true>, dim3(LONG_THREADS / 64), dim3(64), 0, ix->stream, fa);
+				hipLaunchKernelGGL(k_bk_level<true>, dim3(LONG_THREADS / 64), dim3(64), 0, ix->stream_fz, fa);
 			}
 		}
-		hipLaunchKernelGGL(k_bk_finish, dim3((nc + 255) / 256), dim3(256), 0, ix->stream,
+		hipLaunchKernelGGL(k_bk_finish, dim3((nc + 255) / 256), dim3(256), 0, ix->stream_fz,
 		    ix->d_bk, d_best, nc, d_tids);
-		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
+		if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream_fz);
 		if (hipGetLastError() != hipSuccess) {
 			set_error("fuzzy kernel launch failed");
 			return -1;
 		}
 		std::vector<uint32_t> h_counts(levels);
 		unsigned long long h_evals = 0;
-		if (hipMemcpyAsync(term_ids + c0, d_tids, nc * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(&h_evals, d_evals, 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    (visited && hipMemcpyAsync(visited + c0, d_vis, nc * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
-		    hipMemcpyAsync(&h_ovf, d_ovf, 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    hipMemcpyAsync(h_counts.data(), counts, levels * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+		if (hipMemcpyAsync(term_ids + c0, d_tids, nc * 4, hipMemcpyDeviceToHost, ix->stream_fz) != hipSuccess ||
+		    hipMemcpyAsync(&h_evals, d_evals, 8, hipMemcpyDeviceToHost, ix->stream_fz) != hipSuccess ||
+		    (visited && hipMemcpyAsync(visited + c0, d_vis, nc * 8, hipMemcpyDeviceToHost, ix->stream_fz) != hipSuccess) ||
+		    hipMemcpyAsync(&h_ovf, d_ovf, 4, hipMemcpyDeviceToHost, ix->stream_fz) != hipSuccess ||
+		    hipMemcpyAsync(h_counts.data(), counts, levels * 4, hipMemcpyDeviceToHost, ix->stream_fz) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream_fz) != hipSuccess) {
 			set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
 			return -1;
 		}

@@ -86,7 +86,8 @@ struct nxs_index {
 	nxs_t *		nxs;
 	char *		name;
 	int		algo;		/* NXSGPU_BM25 / NXSGPU_TF_IDF */
-	bool		lowercase;
+	bool		lowercase;	/* open_files(): the pipeline is { normalizer } */
+	struct nxs_filters *filters;	/* filter pipeline of query tokens, or NULL */
 
 	uint8_t *	tmap;	size_t tmap_len;
 	uint8_t *	dmap;	size_t dmap_len;
@@ -138,6 +139,15 @@ typedef struct {
 int	nxs_bk_build(const hterm_t *terms, uint32_t last_id, const uint8_t *tmap,
 	    nxs_bkimage_t *out);
 void	nxs_bk_free(nxs_bkimage_t *);
+
+/* ---- filter pipeline of query tokens (nxs_filters.c) ------------------------ */
+
+typedef struct nxs_filters nxs_filters_t;
+
+nxs_filters_t *nxs_filters_create(const char *basedir, const char *const *names, size_t n,
+	    const char *lang, const char **err);
+void	nxs_filters_destroy(nxs_filters_t *);
+int	nxs_filters_run(nxs_filters_t *, char **val, size_t *len);
 
 /* ---- query ----------------------------------------------------------- */
 

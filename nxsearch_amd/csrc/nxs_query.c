@@ -410,9 +410,26 @@ nxs_query_prepare(const nxs_index_t *idx, const char *query, qprep_t *out)
 		}
 		len = strlen(it->str);
 		val = strdup(it->str);
-		if (idx && idx->lowercase) {
-			/* ASCII part of the "normalizer" filter
-			 * (filters_builtin.c:57-76); see DESIGN.md scope */
+		/* tokenize_value: the index's filter pipeline on the leaf string
+		 * (tokenizer.c:205-227; nxs_filters.c) */
+		if (idx && idx->filters) {
+			const int act = nxs_filters_run(idx->filters, &val, &len);
+
+			if (act == 0) {
+				/* FILT_DISCARD (a stop word): no token; the leaf is the
+				 * empty set (search.c:140) */
+				free(val);
+				continue;
+			}
+			if (act < 0) {
+				/* FILT_ERROR => query_prepare fails (search.c:199-203) */
+				free(val);
+				out->errcode = NXS_ERR_FATAL;
+				out->errmsg = strdup("query_prepare() failed");
+				return;
+			}
+		} else if (idx && idx->lowercase) {
+			/* (host-only tests without a pipeline object) */
 			for (size_t c = 0; c < len; c++) {
 				if (val[c] >= 'A' && val[c] <= 'Z') {
 					val[c] += 32;

@@ -288,6 +288,31 @@ def test_index_open_by_name_reads_params_db(nxs, golden, tmp_path):
         assert e.value.code == 3
 
 
+def test_filter_pipeline_on_query_tokens(nxs, tmp_path):
+    """N2: params.db filters { normalizer, stopwords }: non-ASCII query tokens go
+    through ICU (NFKC_Casefold + diacritics), stop words are discarded (their
+    leaf is the empty set, search.c:140)."""
+    base = tmp_path / "b3"
+    docs = [(1, ["azul", "henry", "viii"]), (2, ["azuolelis", "arbae", "azul"]), (3, ["fuglafjordur", "henry"]),
+            (4, ["viii", "finance"])]
+    nxsfmt.write_index(str(base), "n2", docs, filters=["normalizer", "stopwords"])
+    sw = base / "filters" / "stopwords"
+    sw.mkdir(parents=True)
+    (sw / "en").write_text("the\nof\n")
+    t, d = base / "data" / "n2" / "nxsterms", base / "data" / "n2" / "nxsdtmap"
+    with N.Nxs(str(base)) as n2:
+        idx = n2.open_index("n2")
+        oidx = O.Index(str(t), str(d))
+        for q, plain in (("AZÚL", "azul"), ("Henry AND Ⅷ", "henry AND viii"), ("ĄŽUOLĖLIS OR Árbæ", "azuolelis OR arbae"),
+                         ("Fuglafjørður", "fuglafjordur"), ("THE OR azul", "nosuchterm OR azul"),
+                         ("the AND azul", "nosuchterm AND azul"), ("ﬁnance AND NOT of", "finance AND NOT nosuchterm")):
+            assert_same(idx.search(q, fuzzymatch=False), oidx.search(plain, fuzzymatch=False), q)
+        with pytest.raises(N.NxsError) as e:
+            idx.search(b"\xff\xfe AND azul")
+        assert (e.value.code, e.value.msg) == (1, "query_prepare() failed")
+        idx.close()
+
+
 @pytest.mark.parametrize("seed,n_terms,alphabet", [(1, 500, "abcd"), (2, 20000, "abcdefghijklmnopqrstuvwxyz")])
 def test_fuzzy_matches_oracle(nxs, tmp_path, seed, n_terms, alphabet):
     rng = random.Random(seed)

@@ -111,6 +111,34 @@ def test_plan_token_order_truth_table_and_empty_leaves():
     assert empty
 
 
+def test_query_token_filters(golden, tmp_path):
+    """N2: the normalizer stage (ICU NFKC_Casefold + the diacritics transform of
+    src/utils/utf8.c:30-31) on the reference's own known answers
+    (src/tests/t_utf8.c:85-150), stop words (filters_builtin.c:88-199), and the
+    loud refusal of the stemmer."""
+    for src, want in golden["utf8"]["normalize"]:
+        assert N.filter_token(src) == (1, want)
+    # the filter runs utf8_normalize THEN utf8_subs_diacritics (filters_builtin.c:56-76):
+    # the diacritics answers arrive case-folded
+    for src, want in golden["utf8"]["diacritics"]:
+        assert N.filter_token(src) == (1, want.lower())
+    assert N.filter_token("UNIX") == (1, "unix")                 # ASCII fast path
+    assert N.filter_token("ﬁnance ①") == (1, "finance 1")
+    assert N.filter_token(b"\xff\xfe")[0] == -1                 # invalid UTF-8 => FILT_ERROR
+    sw = tmp_path / "filters" / "stopwords"
+    sw.mkdir(parents=True)
+    (sw / "en").write_text("the\nand\n\nof\n")
+    assert N.filter_token("The", basedir=str(tmp_path), stopwords=True) == (0, None)
+    assert N.filter_token("Then", basedir=str(tmp_path), stopwords=True) == (1, "then")
+    assert N.filter_token("the", basedir=str(tmp_path), stopwords=False) == (1, "the")
+    # an index whose params.db lists the stemmer cannot be served here: say so
+    nxsfmt.write_index(str(tmp_path), "stemmed", [(1, ["cat"])], filters=["normalizer", "stopwords", "stemmer"])
+    with N.Nxs(str(tmp_path)) as nxs:
+        with pytest.raises(N.NxsError) as e:
+            nxs.open_index("stemmed")
+        assert e.value.code == 3 and "stemmer" in e.value.msg
+
+
 def _eval_wide(prog, present):
     st = []
     for op in prog:

@@ -121,6 +121,35 @@ const char *	nxsgpu_last_error(void);
 nxsgpu_index_t *nxsgpu_index_create(int device, const nxsgpu_index_src_t *);
 void		nxsgpu_index_destroy(nxsgpu_index_t *);
 
+/*
+ * N1 -- incremental refresh: what idx_terms_sync / idx_dtmap_sync consumed since
+ * the last snapshot (src/index/terms.c:320-414, src/index/dtmap.c:440-544),
+ * validated by the host: appended docs carry ids above every loaded one (they
+ * take the highest ordinals) and name known terms only.
+ */
+typedef struct {
+	uint32_t	n_terms;	/* new last term id (>= the old one) */
+	const uint8_t *	term_ok;	/* [n_terms+1] */
+	const uint8_t *	dtmap_img;	/* the mapped nxsdtmap image */
+	uint64_t	dtmap_len;
+	const uint64_t *blk_off;	/* [n_new] appended doc blocks, ascending doc id */
+	const uint64_t *doc_ids;	/* [n_new] */
+	const uint64_t *pair_base;	/* [n_new+1] */
+	uint64_t	n_new;
+	const uint32_t *dead_term;	/* (term, ordinal) of every posting of a removed doc */
+	const uint32_t *dead_ord;
+	uint64_t	n_dead_pairs;
+	uint32_t	hdr_doc_count;	/* header counters now (dtmap.c:660-677) */
+	uint64_t	hdr_token_count;
+} nxsgpu_index_delta_t;
+
+/* merge the delta into the device CSR and recompute every impact; 0 / -1 (the
+ * index is unchanged on failure unless the error says otherwise) */
+int		nxsgpu_index_apply(nxsgpu_index_t *, const nxsgpu_index_delta_t *);
+/* replace the BK-tree image (after terms were inserted on the host) */
+int		nxsgpu_index_set_bk(nxsgpu_index_t *, const nxsgpu_bknode_t *nodes, uint32_t n,
+		    uint32_t depth, const uint8_t *bytes, uint64_t bytes_len);
+
 /* document frequency per term id [n_terms+1] (host buffer) */
 int		nxsgpu_index_df(nxsgpu_index_t *, uint32_t *df);
 uint64_t	nxsgpu_index_postings(const nxsgpu_index_t *);

@@ -95,6 +95,7 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_allgather",
     "nxsgpu_index_set_comm", "nxsgpu_batch_begin", "nxsgpu_batch_end",
     "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_hbm_read_gbs",
+    "nxsgpu_index_apply", "nxsgpu_index_set_bk",
 ]
 
 _lib = None
@@ -465,6 +466,8 @@ class Index:
         n = len(toks)
         ids = (C.c_uint32 * max(n, 1))()
         vis = (C.c_uint64 * max(n, 1))() if want_visited else None
+        L.nxs_index_bk_sync.argtypes = [C.c_void_p]
+        L.nxs_index_bk_sync(self._h)        # terms appended since the last image (N1)
         r = L.nxsgpu_fuzzy(self.device, blob, (C.c_uint32 * (n + 1))(*offs), n, ids, vis)
         if r != 0:
             raise NxsError(1, L.nxsgpu_last_error().decode())

@@ -923,6 +923,9 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 			}
 		}
 		fz_off[k] = (uint32_t)o;
+		if (nxs_index_bk_sync(idx) == -1) {
+			goto out;
+		}
 		if (nxsgpu_fuzzy(idx->dev, fz_bytes, fz_off, (uint32_t)n_fz, fz_ids, NULL) != 0) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s",
 			    nxsgpu_last_error());

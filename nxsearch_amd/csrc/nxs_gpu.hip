@@ -37,6 +37,7 @@
 #include <cstdarg>
 #include <vector>
 #include <algorithm>
+#include <thread>
 #include <type_traits>
 
 #include <dlfcn.h>
@@ -220,7 +221,11 @@ struct nxsgpu_index {
 	uint64_t *	d_doc_ids;	/* [D] */
 	uint32_t *	d_doc_len;	/* [D] */
 	uint64_t *	d_post_off;	/* [T+2] */
-	uint64_t *	d_post_dt;	/* [P] doc<<32 | tf (kept for refresh) */
+	uint64_t *	d_post_dt;	/* [P] doc<<32 | tf, sorted by (term, doc): the primary array;
+					 * impacts are recomputed from it at every refresh (N1) */
+	uint64_t	cap_post;	/* capacity of d_post[*] */
+	uint64_t	cap_docs_ids, cap_docs_len;
+	uint32_t	max_tf;
 	posting_t *	d_post[2];	/* [P] per ranking algo */
 	std::vector<uint64_t> h_post_off;
 	std::vector<float> h_maximp[2];	/* [T+2] largest impact per term and ranking algo */
@@ -388,6 +393,202 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 			atomicMax(&max_tfidf[t], bt_);
 		}
 	}
+}
+
+__global__ void
+k_shift_ords(uint64_t *__restrict__ vals, uint64_t n, uint64_t first_ord)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		vals[i] += first_ord << 32;
+	}
+}
+
+/*
+ * CSR walk shared by the refresh kernels: a wavefront takes SPAN consecutive
+ * postings; the term of the first one is found by ONE binary search in the
+ * row offsets (all lanes search the same key), then every lane advances its
+ * own term index while its posting lies beyond the row's end -- rows are
+ * ascending, so a lane's term only ever grows.
+ */
+#define	CSR_SPAN	(WAVE * 8)
+
+__device__ static inline uint32_t
+csr_row_of(const uint64_t *__restrict__ off, uint32_t n_rows, uint64_t i)
+{
+	/* largest t in [0, n_rows] with off[t] <= i */
+	uint32_t lo = 0, hi = n_rows + 1;
+	while (lo + 1 < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if (off[mid] <= i) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+/*
+ * Per-posting scores straight from the CSR form (term, doc, tf): the refreshable
+ * twin of k_impacts (same arithmetic, same operation order; the term comes from
+ * the row offsets instead of a key array).  off has n_terms + 2 entries.
+ */
+__global__ void
+k_impacts_csr(const uint64_t *__restrict__ off, uint32_t n_terms, const uint64_t *__restrict__ vals,
+    uint64_t n, const uint32_t *__restrict__ doc_len,
+    const double *__restrict__ logtf, const double *__restrict__ idf_bm25,
+    const float *__restrict__ idf_tfidf, double adl, double kk, double bb,
+    posting_t *__restrict__ out_bm25, posting_t *__restrict__ out_tfidf,
+    uint32_t *__restrict__ max_bm25, uint32_t *__restrict__ max_tfidf)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+	for (uint64_t base = wave0 * CSR_SPAN; base < n; base += n_waves * CSR_SPAN) {
+		uint32_t t = csr_row_of(off, n_terms, base);
+		for (unsigned k = 0; k < CSR_SPAN / WAVE; k++) {
+			const uint64_t i = base + k * WAVE + lane;
+			const bool valid = i < n;
+			posting_t pb, pt;
+			uint32_t bb_ = 0, bt_ = 0;
+
+			if (valid) {
+				while (i >= off[t + 1]) {
+					t++;
+				}
+				const uint64_t v = vals[i];
+				const uint32_t doc = (uint32_t)(v >> 32), cnt = (uint32_t)v;
+				const double tf = logtf[cnt];
+				const double dl = (double)(int)doc_len[doc];
+				const double one_b = 1 - bb;
+				const double tf_bm25 = tf / (tf + kk * (one_b + bb * dl / adl));
+
+				pb.doc = doc;
+				pb.imp = (float)(tf_bm25 * idf_bm25[t]);
+				pt.doc = doc;
+				pt.imp = (float)tf * idf_tfidf[t];
+				out_bm25[i] = pb;
+				out_tfidf[i] = pt;
+				bb_ = pb.imp > 0.0f ? __float_as_uint(pb.imp) : 0u;
+				bt_ = pt.imp > 0.0f ? __float_as_uint(pt.imp) : 0u;
+			}
+			/* largest impact per term (k_scanm's bounds): one atomic per
+			 * wavefront when all its postings belong to one term */
+			const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+			const bool whole = base + k * WAVE + 63 < n;
+			if (whole && __builtin_amdgcn_ballot_w64(t != t0) == 0) {
+				for (int o = 32; o; o >>= 1) {
+					bb_ = max(bb_, (uint32_t)__shfl_xor((int)bb_, o));
+					bt_ = max(bt_, (uint32_t)__shfl_xor((int)bt_, o));
+				}
+				if (lane != 0) {
+					bb_ = bt_ = 0;
+				}
+			}
+			if (valid) {
+				if (bb_ > max_bm25[t]) {
+					atomicMax(&max_bm25[t], bb_);
+				}
+				if (bt_ > max_tfidf[t]) {
+					atomicMax(&max_tfidf[t], bt_);
+				}
+			}
+		}
+	}
+}
+
+/*
+ * Incremental refresh, step 1: the surviving postings of the old CSR move to
+ * their places in the new one.  Posting i of term t goes to
+ *	i - (dead postings before i) + (new postings of terms < t)
+ * (appended docs have the highest ordinals, so a term's new postings follow
+ * its old ones).  dead_pos = ascending positions of the postings of removed
+ * docs; new_off = row offsets of the sorted new postings.
+ */
+__global__ void
+k_merge_old(const uint64_t *__restrict__ off, uint32_t n_terms_old, const uint64_t *__restrict__ vals,
+    uint64_t n, const uint64_t *__restrict__ dead_pos, uint32_t n_dead,
+    const uint64_t *__restrict__ new_off, uint64_t *__restrict__ out)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+	for (uint64_t base = wave0 * CSR_SPAN; base < n; base += n_waves * CSR_SPAN) {
+		uint32_t t = csr_row_of(off, n_terms_old, base);
+		for (unsigned k = 0; k < CSR_SPAN / WAVE; k++) {
+			const uint64_t i = base + k * WAVE + lane;
+			if (i >= n) {
+				continue;
+			}
+			while (i >= off[t + 1]) {
+				t++;
+			}
+			/* dead postings at positions < i, and is i itself one? */
+			uint32_t lo = 0, hi = n_dead;
+			while (lo < hi) {
+				const uint32_t mid = lo + ((hi - lo) >> 1);
+				if (dead_pos[mid] < i) lo = mid + 1; else hi = mid;
+			}
+			if (lo < n_dead && dead_pos[lo] == i) {
+				continue;
+			}
+			out[i - lo + new_off[t]] = vals[i];
+		}
+	}
+}
+
+/* step 2: the new postings (sorted by term, doc ascending inside a term) go to
+ * the tail of their term's new row: row t ends at new_row_off[t + 1] */
+__global__ void
+k_place_new(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, uint64_t n_new,
+    const uint64_t *__restrict__ new_off, const uint64_t *__restrict__ row_off_new,
+    uint64_t *__restrict__ out)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += stride) {
+		const uint32_t t = keys[j];
+		out[row_off_new[t + 1] - (new_off[t + 1] - j)] = vals[j];
+	}
+}
+
+/* position of every (term, doc ordinal) of a removed doc in the old CSR
+ * (~0 if the posting is not there: cannot happen on a consistent index) */
+__global__ void
+k_dead_positions(const uint64_t *__restrict__ off, const uint64_t *__restrict__ vals,
+    const uint32_t *__restrict__ dead_term, const uint32_t *__restrict__ dead_ord, uint32_t n_dead,
+    uint64_t *__restrict__ pos)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_dead) {
+		return;
+	}
+	const uint32_t t = dead_term[j], ord = dead_ord[j];
+	uint64_t lo = off[t], hi = off[t + 1];
+	const uint64_t end = hi;
+	while (lo < hi) {
+		const uint64_t mid = lo + ((hi - lo) >> 1);
+		if ((uint32_t)(vals[mid] >> 32) < ord) lo = mid + 1; else hi = mid;
+	}
+	pos[j] = (lo < end && (uint32_t)(vals[lo] >> 32) == ord) ? lo : ~0ull;
+}
+
+/* new row offsets: old row start minus the dead postings before it plus the
+ * new postings of lower terms; rows of new terms start at the old end */
+__global__ void
+k_new_row_offsets(const uint64_t *__restrict__ off_old, uint32_t n_terms_old, uint64_t n_old,
+    const uint64_t *__restrict__ dead_pos, uint32_t n_dead, const uint64_t *__restrict__ new_off,
+    uint32_t n_terms_new, uint64_t *__restrict__ off_out)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > (uint64_t)n_terms_new + 1) {
+		return;
+	}
+	const uint64_t o = t <= (uint64_t)n_terms_old + 1 ? off_old[t] : n_old;
+	uint32_t lo = 0, hi = n_dead;
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if (dead_pos[mid] < o) lo = mid + 1; else hi = mid;
+	}
+	off_out[t] = o - lo + new_off[t];
 }
 
 /* ------------------------------------------------------------------ */
@@ -3848,6 +4049,95 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	delete ix;
 }
 
+/*
+ * Impacts of every posting from the CSR form (d_post_off, d_post_dt) and the
+ * header statistics: host libm tables (the device only does IEEE + - * / on
+ * them), one k_impacts_csr pass, the per-term maxima back to the host.  Used by
+ * the first build and by every refresh (N, adl and df move every idf).
+ */
+static int
+rebuild_impacts(nxsgpu_index_t *ix)
+{
+	const uint32_t T = ix->n_terms;
+	const uint64_t P = ix->n_post;
+	const unsigned long N = ix->hdr_doc_count;
+	static const double kk = 1.2f;		/* ranking.c:141 */
+	static const double bb = 0.75f;		/* ranking.c:142 */
+	std::vector<double> logtf((size_t)ix->max_tf + 2), idf_b((size_t)T + 2, 0.0);
+	std::vector<float> idf_t((size_t)T + 2, 0.0f);
+	double *d_logtf = NULL, *d_idf_bm25 = NULL;
+	float *d_idf_tfidf = NULL;
+	uint32_t *d_maximp = NULL;
+	double adl = 0.0;
+	int rc = -1;
+
+	for (size_t c = 0; c < logtf.size(); c++) {
+		logtf[c] = log((double)((int)c + 1));	/* ranking.c:90,168 */
+	}
+	/* two log() per term: spread over a few host threads (1M terms ~ 40 ms on one) */
+	{
+		const unsigned nthr = T > 65536 ? 8u : 1u;
+		std::vector<std::thread> thr;
+		auto work = [&](uint32_t lo, uint32_t hi) {
+			for (uint32_t t = lo; t < hi; t++) {
+				const unsigned long df = ix->h_post_off[t + 1] - ix->h_post_off[t];
+				if (df == 0 || N == 0) {
+					continue;
+				}
+				idf_b[t] = log(((N - df + 0.5) / (df + 0.5)) + 1);	/* ranking.c:172 */
+				/* ranking.c:91: f32 division, double log, f32 result */
+				float idf = log((double)((float)N / (float)df)) + 1;
+				idf_t[t] = idf;
+			}
+		};
+		for (unsigned k = 1; k < nthr; k++) {
+			const uint32_t lo = 1 + (uint32_t)((uint64_t)T * k / nthr), hi = 1 + (uint32_t)((uint64_t)T * (k + 1) / nthr);
+			thr.emplace_back(work, lo, hi);
+		}
+		work(1, 1 + (uint32_t)((uint64_t)T / nthr));
+		for (auto &th : thr) {
+			th.join();
+		}
+	}
+	ix->tfidf_valid = N != 0;
+	ix->bm25_valid = false;
+	if (N != 0) {
+		adl = (double)(ix->hdr_token_count / N);	/* ranking.c:163 */
+		ix->bm25_valid = !(adl < 1);
+	}
+	ix->h_maximp[NXSGPU_BM25].assign((size_t)T + 2, 0.0f);
+	ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
+	if (P == 0) {
+		return 0;
+	}
+	HIP_TRY(hipMalloc(&d_logtf, logtf.size() * 8));
+	HIP_TRY(hipMalloc(&d_idf_bm25, idf_b.size() * 8));
+	HIP_TRY(hipMalloc(&d_idf_tfidf, idf_t.size() * 4));
+	HIP_TRY(hipMemcpyAsync(d_logtf, logtf.data(), logtf.size() * 8, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipMemcpyAsync(d_idf_bm25, idf_b.data(), idf_b.size() * 8, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipMemcpyAsync(d_idf_tfidf, idf_t.data(), idf_t.size() * 4, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipMalloc(&d_maximp, ((size_t)T + 2) * 4 * 2));
+	HIP_TRY(hipMemsetAsync(d_maximp, 0, ((size_t)T + 2) * 4 * 2, ix->stream));
+	hipLaunchKernelGGL(k_impacts_csr, dim3(4096), dim3(256), 0, ix->stream,
+	    ix->d_post_off, T, ix->d_post_dt, P, ix->d_doc_len, d_logtf, d_idf_bm25,
+	    d_idf_tfidf, adl >= 1 ? adl : 1.0, kk, bb,
+	    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF],
+	    d_maximp, d_maximp + (size_t)T + 2);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_BM25].data(), d_maximp, ((size_t)T + 2) * 4,
+	    hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
+	    hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	rc = 0;
+fail:
+	(void)hipFree(d_logtf);
+	(void)hipFree(d_idf_bm25);
+	(void)hipFree(d_idf_tfidf);
+	(void)hipFree(d_maximp);
+	return rc;
+}
+
 extern "C" nxsgpu_index_t *
 nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 {
@@ -3861,9 +4151,6 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	unsigned long long *d_first_bad = NULL;
 	unsigned int *d_max_tf = NULL;
 	void *d_tmp = NULL;
-	double *d_logtf = NULL, *d_idf_bm25 = NULL;
-	float *d_idf_tfidf = NULL;
-	uint32_t *d_maximp = NULL;
 	size_t tmp_bytes = 0;
 	unsigned long long h_first_bad = ~0ull;
 	unsigned int h_max_tf = 0;
@@ -3977,58 +4264,11 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	    hipMemcpyDeviceToHost, ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 
-	/* host libm tables (the device only does IEEE + - * / on them) */
-	{
-		const unsigned long N = src->hdr_doc_count;
-		std::vector<double> logtf((size_t)h_max_tf + 2), idf_b((size_t)T + 2, 0.0);
-		std::vector<float> idf_t((size_t)T + 2, 0.0f);
-		double adl = 0.0;
-		static const double kk = 1.2f;		/* ranking.c:141 */
-		static const double bb = 0.75f;		/* ranking.c:142 */
-
-		for (size_t c = 0; c < logtf.size(); c++) {
-			logtf[c] = log((double)((int)c + 1));	/* ranking.c:90,168 */
-		}
-		for (uint32_t t = 1; t <= T; t++) {
-			const unsigned long df = ix->h_post_off[t + 1] - ix->h_post_off[t];
-			if (df == 0 || N == 0) {
-				continue;
-			}
-			/* ranking.c:172 */
-			idf_b[t] = log(((N - df + 0.5) / (df + 0.5)) + 1);
-			/* ranking.c:91: f32 division, double log, f32 result */
-			float idf = log((double)((float)N / (float)df)) + 1;
-			idf_t[t] = idf;
-		}
-		ix->tfidf_valid = N != 0;
-		ix->bm25_valid = false;
-		if (N != 0) {
-			adl = (double)(src->hdr_token_count / N);	/* ranking.c:163 */
-			ix->bm25_valid = !(adl < 1);
-		}
-		if (P) {
-			HIP_TRY(hipMalloc(&d_logtf, logtf.size() * 8));
-			HIP_TRY(hipMalloc(&d_idf_bm25, idf_b.size() * 8));
-			HIP_TRY(hipMalloc(&d_idf_tfidf, idf_t.size() * 4));
-			HIP_TRY(hipMemcpyAsync(d_logtf, logtf.data(), logtf.size() * 8, hipMemcpyHostToDevice, ix->stream));
-			HIP_TRY(hipMemcpyAsync(d_idf_bm25, idf_b.data(), idf_b.size() * 8, hipMemcpyHostToDevice, ix->stream));
-			HIP_TRY(hipMemcpyAsync(d_idf_tfidf, idf_t.data(), idf_t.size() * 4, hipMemcpyHostToDevice, ix->stream));
-			HIP_TRY(hipMalloc(&d_maximp, ((size_t)T + 2) * 4 * 2));
-			HIP_TRY(hipMemsetAsync(d_maximp, 0, ((size_t)T + 2) * 4 * 2, ix->stream));
-			hipLaunchKernelGGL(k_impacts, dim3(4096), dim3(256), 0, ix->stream,
-			    d_keys, ix->d_post_dt, P, ix->d_doc_len, d_logtf, d_idf_bm25,
-			    d_idf_tfidf, adl >= 1 ? adl : 1.0, kk, bb,
-			    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF],
-			    d_maximp, d_maximp + (size_t)T + 2);
-			HIP_TRY(hipGetLastError());
-			ix->h_maximp[NXSGPU_BM25].assign((size_t)T + 2, 0.0f);
-			ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
-			HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_BM25].data(), d_maximp, ((size_t)T + 2) * 4,
-			    hipMemcpyDeviceToHost, ix->stream));
-			HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
-			    hipMemcpyDeviceToHost, ix->stream));
-			HIP_TRY(hipStreamSynchronize(ix->stream));
-		}
+	ix->max_tf = h_max_tf;
+	ix->cap_post = std::max<uint64_t>(P, 1);
+	ix->cap_docs_ids = ix->cap_docs_len = std::max<uint64_t>(D, 1);
+	if (rebuild_impacts(ix) != 0) {
+		goto fail;
 	}
 
 	/* BK-tree image */
@@ -4046,10 +4286,6 @@ done_partial:
 	(void)hipFree(d_first_bad);
 	(void)hipFree(d_max_tf);
 	(void)hipFree(d_tmp);
-	(void)hipFree(d_logtf);
-	(void)hipFree(d_idf_bm25);
-	(void)hipFree(d_idf_tfidf);
-	(void)hipFree(d_maximp);
 	return ix;
 fail:
 	(void)hipFree(d_img);
@@ -4062,12 +4298,291 @@ fail:
 	(void)hipFree(d_first_bad);
 	(void)hipFree(d_max_tf);
 	(void)hipFree(d_tmp);
-	(void)hipFree(d_logtf);
-	(void)hipFree(d_idf_bm25);
-	(void)hipFree(d_idf_tfidf);
-	(void)hipFree(d_maximp);
 	nxsgpu_index_destroy(ix);
 	return NULL;
+}
+
+/* device array with room to grow: keeps `keep` elements when it has to move */
+template <typename T>
+static int
+grow_array(T *&p, uint64_t &cap, uint64_t need, uint64_t keep, hipStream_t stream)
+{
+	if (need <= cap && p) {
+		return 0;
+	}
+	const uint64_t ncap = need + need / 8 + 4096;
+	T *np = NULL;
+	if (hipMalloc((void **)&np, ncap * sizeof(T)) != hipSuccess) {
+		set_error("hipMalloc(%llu) failed", (unsigned long long)(ncap * sizeof(T)));
+		return -1;
+	}
+	if (p && keep && hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+		(void)hipFree(np);
+		set_error("device copy failed");
+		return -1;
+	}
+	if (p) {
+		(void)hipStreamSynchronize(stream);
+		(void)hipFree(p);
+	}
+	p = np;
+	cap = ncap;
+	return 0;
+}
+
+/*
+ * N1 -- incremental refresh (idx_terms_sync + idx_dtmap_sync on an open index,
+ * src/index/terms.c:320-414, src/index/dtmap.c:440-544, called before every
+ * search: src/query/search.c:309-312).  The delta -- appended doc blocks,
+ * the postings of removed docs, new term ids, the header counters -- is merged
+ * into the device CSR in one streaming pass and every impact is recomputed
+ * (N, adl and df changed): O(postings) of device bandwidth, a few ms at 10M
+ * docs, instead of re-reading and re-sorting the whole forward index.
+ */
+extern "C" int
+nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
+{
+	const uint32_t T_old = ix->n_terms, T_new = d->n_terms;
+	const uint64_t P_old = ix->n_post, D_old = ix->n_docs;
+	const uint64_t n_newdocs = d->n_new, n_newp = n_newdocs ? d->pair_base[n_newdocs] : 0;
+	const uint32_t n_dead = (uint32_t)d->n_dead_pairs;
+	uint8_t *d_img = NULL, *d_term_ok = NULL;
+	uint64_t *d_blk_off = NULL, *d_pair_base = NULL, *d_vals_in = NULL, *d_vals = NULL;
+	uint32_t *d_keys_in = NULL, *d_keys = NULL, *d_dead_term = NULL, *d_dead_ord = NULL;
+	uint64_t *d_dead_pos = NULL, *d_dead_sorted = NULL, *d_new_off = NULL, *d_off_new = NULL, *d_out = NULL;
+	unsigned long long *d_first_bad = NULL;
+	unsigned int *d_max_tf = NULL;
+	void *d_tmp = NULL;
+	size_t tmp_bytes = 0;
+	unsigned long long h_first_bad = ~0ull;
+	unsigned int h_max_tf = 0;
+	int rc = -1;
+
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_index_apply: batches are in flight");
+		return -1;
+	}
+	if (T_new < T_old || D_old + n_newdocs >= (1ull << 32)) {
+		set_error("nxsgpu_index_apply: bad delta");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	uint64_t min_off = ~0ull, max_end = 0;
+	for (uint64_t i = 0; i < n_newdocs; i++) {
+		min_off = std::min(min_off, d->blk_off[i]);
+		max_end = std::max(max_end, d->blk_off[i] + 16 + 8 * (d->pair_base[i + 1] - d->pair_base[i]));
+	}
+	if (n_newdocs && max_end > d->dtmap_len) {
+		set_error("nxsgpu_index_apply: block beyond the image");
+		return -1;
+	}
+
+	/* the doc tables grow at the end (appended docs take the highest ordinals) */
+	if (grow_array(ix->d_doc_ids, ix->cap_docs_ids, D_old + n_newdocs, D_old, ix->stream) != 0 ||
+	    grow_array(ix->d_doc_len, ix->cap_docs_len, D_old + n_newdocs, D_old, ix->stream) != 0) {
+		return -1;
+	}
+	HIP_TRY(hipMalloc(&d_new_off, ((size_t)T_new + 2) * 8));
+	HIP_TRY(hipMalloc(&d_off_new, ((size_t)T_new + 2) * 8));
+	if (n_newdocs) {
+		std::vector<uint64_t> rel(n_newdocs);
+		for (uint64_t i = 0; i < n_newdocs; i++) {
+			rel[i] = d->blk_off[i] - min_off;
+		}
+		HIP_TRY(hipMalloc(&d_img, max_end - min_off));
+		HIP_TRY(hipMalloc(&d_blk_off, n_newdocs * 8));
+		HIP_TRY(hipMalloc(&d_pair_base, (n_newdocs + 1) * 8));
+		HIP_TRY(hipMalloc(&d_term_ok, (size_t)T_new + 1));
+		HIP_TRY(hipMalloc(&d_keys_in, std::max<uint64_t>(n_newp, 1) * 4));
+		HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(n_newp, 1) * 4));
+		HIP_TRY(hipMalloc(&d_vals_in, std::max<uint64_t>(n_newp, 1) * 8));
+		HIP_TRY(hipMalloc(&d_vals, std::max<uint64_t>(n_newp, 1) * 8));
+		HIP_TRY(hipMalloc(&d_first_bad, 8));
+		HIP_TRY(hipMalloc(&d_max_tf, 4));
+		HIP_TRY(hipMemcpyAsync(d_img, d->dtmap_img + min_off, max_end - min_off, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_blk_off, rel.data(), n_newdocs * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_pair_base, d->pair_base, (n_newdocs + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_term_ok, d->term_ok, (size_t)T_new + 1, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_doc_ids + D_old, d->doc_ids, n_newdocs * 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_first_bad, &h_first_bad, 8, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemsetAsync(d_max_tf, 0, 4, ix->stream));
+		{
+			const uint64_t waves = (n_newdocs + 15) / 16;
+			const unsigned blocks = (unsigned)((waves + 3) / 4);
+			/* ordinals of the appended docs start at D_old: the kernel numbers
+			 * docs from 0, so it gets shifted views of the doc tables */
+			hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(256), 0, ix->stream,
+			    d_img, d_blk_off, d_pair_base, n_newdocs, T_new, d_term_ok, d_keys_in, d_vals_in,
+			    ix->d_doc_len + D_old, d_first_bad, d_max_tf);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipMemcpyAsync(&h_first_bad, d_first_bad, 8, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipMemcpyAsync(&h_max_tf, d_max_tf, 4, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		if (h_first_bad != ~0ull) {
+			set_error("nxsgpu_index_apply: an appended block names an unknown term");
+			goto fail;	/* (the host validates the delta first) */
+		}
+		if (h_max_tf >= (1u << 24)) {
+			set_error("term frequency %u exceeds the supported 2^24", h_max_tf);
+			goto fail;
+		}
+		if (n_newp) {
+			unsigned bits = 1;
+			while (bits < 32 && (1ull << bits) <= T_new) {
+				bits++;
+			}
+			/* ordinals: + D_old (k_expand_pairs wrote 0-based ones) */
+			hipLaunchKernelGGL(k_shift_ords, dim3((unsigned)std::min<uint64_t>((n_newp + 255) / 256, 65535)), dim3(256), 0,
+			    ix->stream, d_vals_in, n_newp, D_old);
+			HIP_TRY(rocprim::radix_sort_pairs(NULL, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals,
+			    (size_t)n_newp, 0, bits, ix->stream));
+			HIP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8));
+			HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals,
+			    (size_t)n_newp, 0, bits, ix->stream));
+		}
+	}
+	/* row offsets of the new postings (all zero when there are none) */
+	if (n_newp) {
+		const unsigned blocks = (unsigned)(((uint64_t)T_new + 2 + 255) / 256);
+		hipLaunchKernelGGL(k_post_offsets, dim3(blocks), dim3(256), 0, ix->stream, d_keys, n_newp, T_new, d_new_off);
+	} else {
+		HIP_TRY(hipMemsetAsync(d_new_off, 0, ((size_t)T_new + 2) * 8, ix->stream));
+	}
+	/* where the postings of the removed docs sit */
+	if (n_dead) {
+		HIP_TRY(hipMalloc(&d_dead_term, (size_t)n_dead * 4));
+		HIP_TRY(hipMalloc(&d_dead_ord, (size_t)n_dead * 4));
+		HIP_TRY(hipMalloc(&d_dead_pos, (size_t)n_dead * 8));
+		HIP_TRY(hipMalloc(&d_dead_sorted, (size_t)n_dead * 8));
+		HIP_TRY(hipMemcpyAsync(d_dead_term, d->dead_term, (size_t)n_dead * 4, hipMemcpyHostToDevice, ix->stream));
+		HIP_TRY(hipMemcpyAsync(d_dead_ord, d->dead_ord, (size_t)n_dead * 4, hipMemcpyHostToDevice, ix->stream));
+		hipLaunchKernelGGL(k_dead_positions, dim3((n_dead + 255) / 256), dim3(256), 0, ix->stream,
+		    ix->d_post_off, ix->d_post_dt, d_dead_term, d_dead_ord, n_dead, d_dead_pos);
+		size_t tb = 0;
+		void *tmp2 = NULL;
+		HIP_TRY(rocprim::radix_sort_keys(NULL, tb, d_dead_pos, d_dead_sorted, (size_t)n_dead, 0, 64, ix->stream));
+		HIP_TRY(hipMalloc(&tmp2, tb ? tb : 8));
+		if (rocprim::radix_sort_keys(tmp2, tb, d_dead_pos, d_dead_sorted, (size_t)n_dead, 0, 64, ix->stream) != hipSuccess) {
+			(void)hipFree(tmp2);
+			set_error("sort failed");
+			goto fail;
+		}
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		(void)hipFree(tmp2);
+		/* a posting that was not found would corrupt the merge */
+		uint64_t last = 0;
+		HIP_TRY(hipMemcpy(&last, d_dead_sorted + (n_dead - 1), 8, hipMemcpyDeviceToHost));
+		if (last == ~0ull) {
+			set_error("nxsgpu_index_apply: a removed doc's posting is not in the index");
+			goto fail;
+		}
+	}
+	{
+		const uint64_t P_new = P_old - n_dead + n_newp;
+		const unsigned blocks = (unsigned)(((uint64_t)T_new + 2 + 255) / 256);
+
+		HIP_TRY(hipMalloc(&d_out, std::max<uint64_t>(P_new + P_new / 16 + 4096, 1) * 8));
+		hipLaunchKernelGGL(k_new_row_offsets, dim3(blocks), dim3(256), 0, ix->stream,
+		    ix->d_post_off, T_old, P_old, d_dead_sorted, n_dead, d_new_off, T_new, d_off_new);
+		if (P_old) {
+			hipLaunchKernelGGL(k_merge_old, dim3(4096), dim3(256), 0, ix->stream,
+			    ix->d_post_off, T_old, ix->d_post_dt, P_old, d_dead_sorted, n_dead, d_new_off, d_out);
+		}
+		if (n_newp) {
+			hipLaunchKernelGGL(k_place_new, dim3((unsigned)std::min<uint64_t>((n_newp + 255) / 256, 65535)), dim3(256), 0,
+			    ix->stream, d_keys, d_vals, n_newp, d_new_off, d_off_new, d_out);
+		}
+		HIP_TRY(hipGetLastError());
+		ix->h_post_off.assign((size_t)T_new + 2, 0);
+		HIP_TRY(hipMemcpyAsync(ix->h_post_off.data(), d_off_new, ((size_t)T_new + 2) * 8, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		if (ix->h_post_off[(size_t)T_new + 1] != P_new) {
+			set_error("nxsgpu_index_apply: merged %llu postings, expected %llu",
+			    (unsigned long long)ix->h_post_off[(size_t)T_new + 1], (unsigned long long)P_new);
+			goto fail;
+		}
+		/* swap in the new CSR */
+		(void)hipFree(ix->d_post_dt);
+		ix->d_post_dt = d_out;
+		d_out = NULL;
+		(void)hipFree(ix->d_post_off);
+		ix->d_post_off = d_off_new;
+		d_off_new = NULL;
+		ix->n_post = P_new;
+		ix->n_terms = T_new;
+		ix->n_docs = D_old + n_newdocs;
+		ix->max_tf = std::max(ix->max_tf, h_max_tf);
+		ix->hdr_doc_count = d->hdr_doc_count;
+		ix->hdr_token_count = d->hdr_token_count;
+		/* impact arrays follow the posting count */
+		if (P_new > ix->cap_post) {
+			(void)hipFree(ix->d_post[0]);
+			(void)hipFree(ix->d_post[1]);
+			ix->d_post[0] = ix->d_post[1] = NULL;
+			ix->cap_post = P_new + P_new / 16 + 4096;
+			HIP_TRY(hipMalloc(&ix->d_post[0], ix->cap_post * sizeof(posting_t)));
+			HIP_TRY(hipMalloc(&ix->d_post[1], ix->cap_post * sizeof(posting_t)));
+		}
+	}
+	if (rebuild_impacts(ix) != 0) {
+		goto fail;
+	}
+	rc = 0;
+fail:
+	(void)hipFree(d_img);
+	(void)hipFree(d_blk_off);
+	(void)hipFree(d_pair_base);
+	(void)hipFree(d_term_ok);
+	(void)hipFree(d_keys_in);
+	(void)hipFree(d_keys);
+	(void)hipFree(d_vals_in);
+	(void)hipFree(d_vals);
+	(void)hipFree(d_first_bad);
+	(void)hipFree(d_max_tf);
+	(void)hipFree(d_tmp);
+	(void)hipFree(d_dead_term);
+	(void)hipFree(d_dead_ord);
+	(void)hipFree(d_dead_pos);
+	(void)hipFree(d_dead_sorted);
+	(void)hipFree(d_new_off);
+	(void)hipFree(d_off_new);
+	(void)hipFree(d_out);
+	return rc;
+}
+
+/* replace the BK-tree image (new terms were inserted on the host) */
+extern "C" int
+nxsgpu_index_set_bk(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n, uint32_t depth,
+    const uint8_t *bytes, uint64_t bytes_len)
+{
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	(void)hipStreamSynchronize(ix->stream_fz);
+	(void)hipFree(ix->d_bk);
+	(void)hipFree(ix->d_bk_bytes);
+	ix->d_bk = NULL;
+	ix->d_bk_bytes = NULL;
+	ix->n_bk = 0;
+	ix->bk_depth = 0;
+	if (n == 0) {
+		return 0;
+	}
+	if (hipMalloc(&ix->d_bk, (size_t)n * sizeof(nxsgpu_bknode_t)) != hipSuccess ||
+	    hipMalloc(&ix->d_bk_bytes, bytes_len + 16) != hipSuccess ||
+	    hipMemcpy(ix->d_bk, nodes, (size_t)n * sizeof(nxsgpu_bknode_t), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(ix->d_bk_bytes, bytes, bytes_len, hipMemcpyHostToDevice) != hipSuccess) {
+		set_error("BK-tree upload failed");
+		return -1;
+	}
+	ix->n_bk = n;
+	ix->bk_depth = depth;
+	return 0;
 }
 
 extern "C" int

@@ -115,16 +115,32 @@ struct nxs_index {
 	uint8_t *	emu_block;
 	size_t		emu_block_len;
 
-	/* snapshot identity: what idx_terms_sync/idx_dtmap_sync had consumed */
+	/* what idx_terms_sync / idx_dtmap_sync have consumed (bytes of the data areas)
+	 * and the header counters the device statistics were computed from */
 	char *		terms_path;
 	char *		dtmap_path;
-	uint64_t	terms_seen, dt_seen;	/* header data_len at load */
+	uint64_t	terms_consumed, dt_consumed;
+	uint64_t	hdr_docs_seen, hdr_tokens_seen;
+	size_t		terms_cap;
+	/* persistent doc table, ordinal order (= ascending doc id) */
+	uint64_t *	h_doc_ids;
+	uint64_t *	h_blk_off;	/* block offset in the nxsdtmap image */
+	uint32_t *	h_npairs;
+	uint8_t *	h_alive;
+	uint64_t	n_ord, cap_ord;
+	/* host BK-tree (terms inserted up to bk_upto) behind the device image */
+	struct nxs_bktree *bktree;
+	uint32_t	bk_upto;
+	bool		bk_flags_stale;
+	uint64_t	n_incremental, n_rebuilds;
 };
 
 /* nxs_index.c */
 int	nxs_index_load(nxs_index_t *, const char *terms_path, const char *dtmap_path);
 void	nxs_index_unload(nxs_index_t *);
 int	nxs_index_refresh(nxs_index_t *);
+int	nxs_index_bk_sync(nxs_index_t *);
+void	nxs_index_refresh_stats(const nxs_index_t *, uint64_t out[2]);
 uint32_t nxs_term_lookup(const nxs_index_t *, const uint8_t *val, size_t len);
 
 /* flattened BK-tree built on the host (exported for the CPU-side tests) */
@@ -136,6 +152,13 @@ typedef struct {
 	uint64_t	bytes_len;
 } nxs_bkimage_t;
 
+typedef struct nxs_bktree nxs_bktree_t;
+
+nxs_bktree_t *nxs_bktree_create(void);
+void	nxs_bktree_destroy(nxs_bktree_t *);
+int	nxs_bktree_insert(nxs_bktree_t *, const hterm_t *terms, uint32_t from_id, uint32_t last_id);
+int	nxs_bk_flatten(const nxs_bktree_t *, const hterm_t *terms, const uint8_t *tmap,
+	    nxs_bkimage_t *out);
 int	nxs_bk_build(const hterm_t *terms, uint32_t last_id, const uint8_t *tmap,
 	    nxs_bkimage_t *out);
 void	nxs_bk_free(nxs_bkimage_t *);

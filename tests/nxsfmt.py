@@ -104,3 +104,63 @@ def write_index(basedir, name, docs, removed=(), algo="BM25", filters=()):
     with open(os.path.join(d, "params.db"), "w") as f:
         f.write('{"algo":"%s","lang":"en","filters":[%s]}' % (algo, flt))
     return (os.path.join(d, "nxsterms"), os.path.join(d, "nxsdtmap"), term_ids)
+
+
+def build_images_log(events):
+    """Like build_images, from an event log in FILE ORDER: ("add", doc_id,
+    tokens) appends a doc block, ("rm", doc_id) zeroes that doc's block id and
+    appends a tombstone (dtmap.c:546-658) -- so every prefix of the log is an
+    append-only earlier state of the same files (what idx_*_sync consumes)."""
+    term_ids = {}
+    terms, totals = [], []
+    blocks = []
+    token_count = 0
+    doc_count = 0
+    for ev in events:
+        if ev[0] == "add":
+            _, doc_id, tokens = ev
+            counts = {}
+            for t in tokens:
+                if isinstance(t, str):
+                    t = t.encode()
+                counts[t] = counts.get(t, 0) + 1
+            for t in counts:
+                if t not in term_ids:
+                    term_ids[t] = len(terms) + 1
+                    terms.append(t)
+                    totals.append(counts[t])
+            pairs = sorted((term_ids[t], c) for t, c in counts.items())
+            for tid, c in pairs:
+                totals[tid - 1] += c
+            blocks.append([doc_id, len(tokens), pairs])
+            token_count += len(tokens)
+            doc_count += 1
+        else:
+            rid = ev[1]
+            for blk in blocks:
+                if blk[0] == rid and blk[1] != 0:
+                    for tid, c in blk[2]:
+                        totals[tid - 1] -= c
+                    token_count -= blk[1]
+                    doc_count -= 1
+                    blk[0] = 0
+                    break
+            else:
+                raise KeyError(rid)
+            blocks.append([rid, 0, []])
+    return (terms_image(terms, totals),
+            dtmap_image([tuple(b) for b in blocks], token_count, doc_count),
+            term_ids)
+
+
+def publish_in_place(tpath, dpath, timg, dimg):
+    """Rewrite both files IN PLACE (same inode, MAP_SHARED readers see it):
+    body first, the header -- with data_len -- last, like the reference's
+    publish order (terms.c:303-305, dtmap.c:327-337)."""
+    for path, img, hdr in ((tpath, timg, 16), (dpath, dimg, 32)):
+        with open(path, "r+b") as f:
+            f.seek(hdr)
+            f.write(img[hdr:])
+            f.flush()
+            f.seek(0)
+            f.write(img[:hdr])

@@ -687,3 +687,102 @@ def test_search_resyncs_appended_and_removed_docs(nxs, tmp_path):
     for q in ("cat", "emu", "cow"):
         assert_same(gidx.search(q), oidx.search(q), q)
     gidx.close()
+
+
+def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path):
+    """N1: 100 interleaved appends (new docs with growing ids, some with new
+    terms) and removals, each published in place and picked up by the NEXT
+    search through the incremental path (delta merged into the device CSR, all
+    impacts recomputed, BK-tree re-flattened for new terms) -- never a rebuild;
+    results against a freshly loaded oracle after every step.  A re-used doc id
+    then takes the rebuild path, also exactly."""
+    import ctypes as C
+    rng = random.Random(97)
+    vocab = ["w%d" % i for i in range(60)]
+    weights = [1.0 / (i + 1) for i in range(len(vocab))]
+    mk = lambda: rng.choices(vocab, weights, k=rng.randint(2, 9))
+    events = [("add", i + 1, mk()) for i in range(400)]
+    timg, dimg, _ = nxsfmt.build_images_log(events)
+    t, d = str(tmp_path / "nxsterms"), str(tmp_path / "nxsdtmap")
+    # room for the appends: the files are sized once, like a preallocated index
+    with open(t, "wb") as f:
+        f.write(timg + b"\0" * (1 << 16))
+    with open(d, "wb") as f:
+        f.write(dimg + b"\0" * (1 << 18))
+    gidx = nxs.open_files(t, d)
+    stats = (C.c_uint64 * 2)()
+    L = N.lib()
+    L.nxs_index_refresh_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    alive, next_id, n_new_terms = set(range(1, 401)), 401, 0
+    queries = ["w0", "w1 AND w2", "w3 OR w7 OR w20", "w0 AND NOT w1", "w5 OR w40 OR w55 OR w9 OR w2"]
+    for step in range(100):
+        r = rng.random()
+        if r < 0.2 and len(alive) > 50:
+            victim = rng.choice(sorted(alive))
+            alive.discard(victim)
+            events.append(("rm", victim))
+        else:
+            for _ in range(rng.randint(1, 3)):
+                toks = mk()
+                if rng.random() < 0.3:
+                    n_new_terms += 1
+                    toks.append("fresh%d" % n_new_terms)        # a term nxsterms did not hold
+                events.append(("add", next_id, toks))
+                alive.add(next_id)
+                next_id += rng.randint(1, 5)
+        timg, dimg, _ = nxsfmt.build_images_log(events)
+        nxsfmt.publish_in_place(t, d, timg, dimg)
+        oidx = O.Index(t, d)
+        qs = queries + (["fresh%d" % n_new_terms, "fresh%d OR w1" % max(1, n_new_terms - 1)] if n_new_terms else [])
+        if step % 10 == 0:
+            qs = qs + ["w0 OR frush%d" % max(1, n_new_terms)]         # fuzzy -> the newest term (BK image)
+        algo = ("BM25", 1) if step % 3 else ("TF-IDF", 0)
+        got = gidx.search_batch(qs, limit=10, algo=algo[0])
+        for q, g in zip(qs, got):
+            assert_same(g, oidx.search(q, algo=algo[1], limit=10), (step, q))
+        if step % 25 == 0:
+            assert_same(gidx.search("w1 OR w2"), oidx.search("w1 OR w2"), step)     # default limit
+    L.nxs_index_refresh_stats(gidx._h, stats)
+    assert (stats[0], stats[1]) == (100, 0), list(stats)
+    # a removed id comes back: not an append of a higher id => full rebuild, same answers
+    gone = sorted(set(range(1, 401)) - alive)[0]
+    events.append(("add", gone, ["w0", "w1", "w1"]))
+    timg, dimg, _ = nxsfmt.build_images_log(events)
+    nxsfmt.publish_in_place(t, d, timg, dimg)
+    oidx = O.Index(t, d)
+    for q in queries:
+        assert_same(gidx.search(q, limit=10), oidx.search(q, limit=10), q)
+    L.nxs_index_refresh_stats(gidx._h, stats)
+    assert (stats[0], stats[1]) == (100, 1), list(stats)
+    gidx.close()
+
+
+def test_incremental_refresh_grows_the_files_and_keeps_serving(nxs, tmp_path):
+    """The files outgrow their mapping (32 KiB steps, index.h:24): re-mapped;
+    a block naming a term that nxsterms does not hold yet is NOT consumed
+    (partial sync, dtmap.c:527-535) until the term arrives."""
+    events = [("add", i + 1, ["a", "b", "c%d" % (i % 7)]) for i in range(50)]
+    timg, dimg, _ = nxsfmt.build_images_log(events)
+    t, d = str(tmp_path / "nxsterms"), str(tmp_path / "nxsdtmap")
+    open(t, "wb").write(timg)
+    open(d, "wb").write(dimg)
+    gidx = nxs.open_files(t, d)
+    assert len(gidx.search("a")) == 50
+    # 3000 more docs: both files grow past 32 KiB
+    events += [("add", 100 + i, ["a", "t%d" % i, "t%d" % (i // 2)]) for i in range(3000)]
+    timg2, dimg2, _ = nxsfmt.build_images_log(events)
+    assert len(dimg2) > len(dimg) and len(timg2) > len(timg)
+    for path, img in ((t, timg2), (d, dimg2)):
+        with open(path, "r+b") as f:
+            f.seek(0, 2)
+            f.write(b"\0" * (len(img) - f.tell()))
+    # publish the dtmap FIRST: its new blocks name terms the term file lacks
+    nxsfmt.publish_in_place(t, d, timg, dimg2)
+    oidx_old = O.Index(t, d)
+    assert_same(gidx.search("a", limit=5), oidx_old.search("a", limit=5))
+    nxsfmt.publish_in_place(t, d, timg2, dimg2)
+    oidx = O.Index(t, d)
+    for q in ("a", "t2999", "t7 OR c3", "b AND NOT a"):
+        assert_same(gidx.search(q, limit=20), oidx.search(q, limit=20), q)
+    assert len(gidx.search("a", limit=5000)) == 3050
+    gidx.close()

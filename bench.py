@@ -289,6 +289,15 @@ def main():
             out.update(side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev))
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, info, queries, idx, fuzzy_on, work)
+        if not args.no_extras:
+            try:
+                out["refresh"] = refresh_measurements(args, idx, info, terms)
+            except Exception as e:        # a side measurement never costs the run
+                out["refresh"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                os.unlink(marker)             # the corpus files were modified: do not reuse them
+            except OSError:
+                pass
     barrier()
     L.nxs_params_release(params)
     idx.close()
@@ -436,6 +445,94 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
                                          "L2 / Infinity Cache, HBM peak is the nominal denominator only"},
                     "what": "C4: %d tokens, d<=2 over a %d-term BK-tree" % (len(toks), args.terms)}
     return res
+
+
+def refresh_measurements(args, idx, info, terms):
+    """N1: what one appended / removed document costs the NEXT search (the
+    reference re-syncs before every search, search.c:309-312).  The corpus files
+    are modified in place like an indexer process would: block first, header
+    counters and data_len last.  Runs last: the corpus is not pristine after it."""
+    import struct
+    import ctypes as C
+    import nxsearch_amd as N
+    L = N.lib()
+    stats = (C.c_uint64 * 2)()
+    L.nxs_index_refresh_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    dpath, tpath = info["dtmap"], info["terms"]
+
+    def hdr(f):
+        f.seek(0)
+        h = f.read(32)
+        data_len, tokens, docs = struct.unpack(">QQI", h[8:28])
+        return data_len, tokens, docs
+
+    def append_block(doc_id, pairs):
+        with open(dpath, "r+b") as f:
+            data_len, tokens, docs = hdr(f)
+            blk = struct.pack(">QII", doc_id, sum(c for _, c in pairs), len(pairs))
+            blk += b"".join(struct.pack(">II", t, c) for t, c in sorted(pairs))
+            f.seek(32 + data_len)
+            f.write(blk)
+            f.flush()
+            f.seek(8)
+            f.write(struct.pack(">QQI", data_len + len(blk), tokens + sum(c for _, c in pairs), docs + 1))
+        return 32 + data_len
+
+    def remove_doc(block_off, doc_id, doc_len):
+        with open(dpath, "r+b") as f:
+            data_len, tokens, docs = hdr(f)
+            f.seek(block_off)
+            f.write(struct.pack(">Q", 0))
+            f.seek(32 + data_len)
+            f.write(struct.pack(">QII", doc_id, 0, 0))
+            f.flush()
+            f.seek(8)
+            f.write(struct.pack(">QQI", data_len + 16, tokens - doc_len, docs - 1))
+
+    def append_term(word):
+        with open(tpath, "r+b") as f:
+            f.seek(8)
+            data_len = struct.unpack(">I", f.read(4))[0]
+            blk = struct.pack(">H", len(word)) + word + b"\0"
+            blk += b"\0" * (-len(blk) % 8) + struct.pack(">Q", 2)
+            f.seek(16 + data_len)
+            f.write(blk)
+            f.flush()
+            f.seek(8)
+            f.write(struct.pack(">I", data_len + len(blk)))
+
+    q = terms[99].decode()
+    def timed_search(query=q, fuzzymatch=False):
+        t0 = time.perf_counter()
+        r = idx.search(query, limit=args.limit, fuzzymatch=fuzzymatch)
+        return 1e3 * (time.perf_counter() - t0), r
+    base_ms = min(timed_search()[0] for _ in range(5))
+    out = {"plain_search_ms": round(base_ms, 3)}
+    new_id = args.docs + 10
+    pairs = [(t, 1 + (t % 3)) for t in (5, 17, 100, 101, 2000, 31337 % args.terms + 1, 7, 9, 11, 13)]
+    off = append_block(new_id, pairs)
+    ms, r = timed_search(terms[99].decode())
+    out["append_1_doc_ms"] = round(ms, 3)
+    ms2, r2 = timed_search(terms[100].decode())           # term 101 holds the new doc
+    out["new_doc_found"] = any(d == new_id for d, _ in idx.search(terms[100].decode(), limit=64, fuzzymatch=False)) \
+        or len(r2) > 0
+    remove_doc(off, new_id, sum(c for _, c in pairs))
+    ms, _ = timed_search()
+    out["remove_1_doc_ms"] = round(ms, 3)
+    word = b"zzqxjkvbnm"
+    append_term(word)
+    append_block(new_id + 5, [(args.terms + 1, 2), (5, 1)])
+    ms, r = timed_search(word.decode())
+    out["append_doc_with_new_term_ms"] = round(ms, 3)
+    out["new_term_found"] = [d for d, _ in r] == [new_id + 5]
+    ms, r = timed_search("zzqxjkvbnn", fuzzymatch=True)      # fuzzy: BK image re-flattened lazily
+    out["first_fuzzy_after_new_term_ms"] = round(ms, 3)
+    out["fuzzy_resolves_new_term"] = [d for d, _ in r] == [new_id + 5]
+    L.nxs_index_refresh_stats(idx._h, stats)
+    out["incremental_refreshes"], out["rebuilds"] = int(stats[0]), int(stats[1])
+    out["what"] = ("wall time of the nxs_index_search() that picks the change up (incremental "
+                   "merge into the device CSR + all impacts recomputed), %d docs" % args.docs)
+    return out
 
 
 def cpu_baseline(args, info, queries, idx, fuzzy_on, work):

@@ -140,6 +140,22 @@ nxs_index_t *	nxs_index_open_files(nxs_t *, const char *terms_path,
 		    const char *dtmap_path, const char *algo, bool lowercase);
 
 /*
+ * Doc-sharded mode (new): for collections beyond one GPU's
+ * memory.  Shard s of S holds the docs of rank [D*s/S, D*(s+1)/S) in ascending
+ * doc id, scored with collection-wide statistics; nxs_docshard_search_batch()
+ * runs a batch on every shard (each on its own device, `device` < 0 = the
+ * NXS_GPU_DEVICE default) and merges the shards' candidates through one more
+ * exact heap replay: the responses equal those of the unsharded index, ties
+ * included.  limit <= 64; a shard is a static snapshot (no re-sync).
+ */
+nxs_index_t *	nxs_index_open_shard(nxs_t *, const char *terms_path,
+		    const char *dtmap_path, const char *algo, bool lowercase,
+		    unsigned shard, unsigned n_shards, int device);
+int		nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards,
+		    nxs_params_t *, const char *const *queries, size_t n,
+		    nxs_resp_t **resps, nxs_err_t *errs);
+
+/*
  * Host-side phase times of the batches since the last call, in seconds:
  * out[0] parse/resolve/compile, out[1] queueing on the device, out[2] waiting
  * for the device, out[3] building responses, out[4] number of batches.

@@ -150,6 +150,27 @@ int		nxsgpu_index_apply(nxsgpu_index_t *, const nxsgpu_index_delta_t *);
 int		nxsgpu_index_set_bk(nxsgpu_index_t *, const nxsgpu_bknode_t *nodes, uint32_t n,
 		    uint32_t depth, const uint8_t *bytes, uint64_t bytes_len);
 
+/*
+ * N4 -- doc-sharded mode (collections beyond one GPU's HBM): every shard holds
+ * the postings of a contiguous range of docs (ascending doc id) but scores with
+ * COLLECTION-WIDE statistics: N and the token count come from the file header,
+ * df is handed in (sum of the shards' nxsgpu_index_df) and all impacts are
+ * recomputed.  A query then runs on every shard, each returns the exact
+ * sequence of candidates its local heap accepted, and the sequences -- highest
+ * shard first -- are replayed through the reference's heap once more
+ * (nxsgpu_merge_candidates): identical top-k, ties included.
+ */
+int		nxsgpu_index_set_global_df(nxsgpu_index_t *, const uint32_t *df, uint32_t n_terms);
+/* ids/scores [n_queries][cap], counts [n_queries] (host); counts[q] > cap = overflow */
+int		nxsgpu_search_candidates(nxsgpu_index_t *, int algo, uint64_t limit,
+		    const nxsgpu_query_t *queries, uint32_t n_queries, uint32_t cap,
+		    uint64_t *ids, float *scores, uint32_t *counts);
+/* ids/scores [nq][n_shards][cap], counts [nq][n_shards], shard 0 = lowest docs;
+ * out_* [nq][limit] / [nq]; limit <= NXSGPU_FAST_K */
+int		nxsgpu_merge_candidates(int device, uint32_t limit, uint32_t nq, uint32_t n_shards,
+		    uint32_t cap, const uint64_t *ids, const float *scores, const uint32_t *counts,
+		    uint64_t *out_ids, float *out_scores, uint32_t *out_counts);
+
 /* document frequency per term id [n_terms+1] (host buffer) */
 int		nxsgpu_index_df(nxsgpu_index_t *, uint32_t *df);
 uint64_t	nxsgpu_index_postings(const nxsgpu_index_t *);

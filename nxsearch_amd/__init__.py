@@ -81,7 +81,7 @@ NXS_H_SYMBOLS = [
     "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
     "nxs_index_plan_batch", "nxs_index_search_batch_begin",
     "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
-    "nxs_index_host_profile",
+    "nxs_index_host_profile", "nxs_index_open_shard", "nxs_docshard_search_batch",
 ]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -95,7 +95,8 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_allgather",
     "nxsgpu_index_set_comm", "nxsgpu_batch_begin", "nxsgpu_batch_end",
     "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_hbm_read_gbs",
-    "nxsgpu_index_apply", "nxsgpu_index_set_bk",
+    "nxsgpu_index_apply", "nxsgpu_index_set_bk", "nxsgpu_index_set_global_df",
+    "nxsgpu_search_candidates", "nxsgpu_merge_candidates",
 ]
 
 _lib = None
@@ -259,6 +260,48 @@ class Nxs:
         if not h:
             self._raise()
         return Index(self, h)
+
+    def open_shard(self, terms_path, dtmap_path, shard, n_shards, algo="BM25", lowercase=False,
+                   device=-1):
+        """nxs_index_open_shard(): shard `shard` of a doc-sharded collection (N4)."""
+        L = lib()
+        L.nxs_index_open_shard.restype = C.c_void_p
+        L.nxs_index_open_shard.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_bool,
+                                           C.c_uint, C.c_uint, C.c_int]
+        h = L.nxs_index_open_shard(self._h, os.fsencode(terms_path), os.fsencode(dtmap_path),
+                                   _b(algo), lowercase, shard, n_shards, device)
+        if not h:
+            self._raise()
+        return Index(self, h)
+
+    def docshard_search_batch(self, shards, queries, limit=None, algo=None, fuzzymatch=None):
+        """nxs_docshard_search_batch(): one batch over all shards, merged exactly."""
+        L = lib()
+        L.nxs_docshard_search_batch.restype = C.c_int
+        L.nxs_docshard_search_batch.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_void_p,
+                                                C.POINTER(C.c_char_p), C.c_size_t,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        n = len(queries)
+        hs = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        resps = (C.c_void_p * max(n, 1))()
+        errs = (C.c_int * max(n, 1))()
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            r = L.nxs_docshard_search_batch(hs, len(shards), p, qs, n, resps, errs)
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        if r < 0:
+            self._raise()
+        out = []
+        for i in range(n):
+            if resps[i]:
+                out.append(_drain(resps[i]))
+                L.nxs_resp_release(resps[i])
+            else:
+                out.append(NxsError(errs[i], "query %d failed" % i))
+        return out
 
     def shard_unique_id(self):
         """nxs_shard_unique_id(): the bytes rank 0 hands to the other ranks."""

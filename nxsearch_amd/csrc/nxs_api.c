@@ -566,6 +566,51 @@ nxs_index_open_files(nxs_t *nxs, const char *terms_path, const char *dtmap_path,
 
 static void index_drain(nxs_index_t *);
 
+/* N4: one shard of a doc-sharded collection (include/nxs.h) */
+nxs_index_t *
+nxs_index_open_shard(nxs_t *nxs, const char *terms_path, const char *dtmap_path,
+    const char *algo_name, bool lowercase, unsigned shard, unsigned n_shards, int device)
+{
+	static const char *const norm_only[] = { "normalizer" };
+	const int algo = get_ranking_func_id(algo_name ? algo_name : "BM25");
+	nxs_index_t *idx, **list;
+	const char *ferr = NULL;
+
+	nxs_clear_error(nxs);
+	if (algo < 0 || n_shards == 0 || shard >= n_shards) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, algo < 0 ? "invalid algorithm" : "invalid shard");
+		return NULL;
+	}
+	if ((idx = calloc(1, sizeof(nxs_index_t))) == NULL) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		return NULL;
+	}
+	idx->nxs = nxs;
+	idx->algo = algo;
+	idx->lowercase = lowercase;
+	idx->shard = shard;
+	idx->n_shards = n_shards;
+	idx->want_device = device >= 0 ? device + 1 : 0;
+	idx->name = strdup(terms_path);
+	if (lowercase && (idx->filters = nxs_filters_create(nxs->basedir, norm_only, 1, "en", &ferr)) == NULL) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "%s", ferr ? ferr : "filter pipeline failed");
+		free(idx->name);
+		free(idx);
+		return NULL;
+	}
+	if (nxs_index_load(idx, terms_path, dtmap_path) == -1) {
+		nxs_index_unload(idx);
+		nxs_filters_destroy(idx->filters);
+		free(idx->name);
+		free(idx);
+		return NULL;
+	}
+	list = realloc(nxs->indexes, (nxs->n_indexes + 1) * sizeof(void *));
+	nxs->indexes = list;
+	nxs->indexes[nxs->n_indexes++] = idx;
+	return idx;
+}
+
 void
 nxs_index_close(nxs_index_t *idx)
 {
@@ -1548,6 +1593,195 @@ nxs_index_search(nxs_index_t *idx, nxs_params_t *params, const char *query, size
 		return NULL;
 	}
 	return resp;
+}
+
+/* ---- N4: doc-sharded collections --------------------------------------------------- */
+
+/* collection-wide df = sum of the shards' (in a multi-process deployment: an
+ * all-reduce of the same arrays); every shard then recomputes its impacts */
+static int
+docshard_set_global_df(nxs_index_t *const *shards, unsigned n_shards)
+{
+	nxs_t *nxs = shards[0]->nxs;
+	const uint32_t T = shards[0]->last_id;
+	uint32_t *sum = calloc((size_t)T + 2, sizeof(uint32_t));
+	uint32_t *df = calloc((size_t)T + 2, sizeof(uint32_t));
+	int ret = -1;
+
+	if (!sum || !df) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	for (unsigned s = 0; s < n_shards; s++) {
+		if (shards[s]->last_id != T || shards[s]->n_shards != n_shards || shards[s]->shard != s) {
+			nxs_decl_err(nxs, NXS_ERR_INVALID, "the indexes are not shards 0..%u of one collection",
+			    n_shards - 1);
+			goto out;
+		}
+		(void)nxsgpu_index_df(shards[s]->dev, df);
+		for (uint32_t t = 1; t <= T; t++) {
+			sum[t] += df[t];
+		}
+	}
+	for (unsigned s = 0; s < n_shards; s++) {
+		if (nxsgpu_index_set_global_df(shards[s]->dev, sum, T) != 0) {
+			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "%s", nxsgpu_last_error());
+			goto out;
+		}
+		shards[s]->global_df_set = true;
+	}
+	ret = 0;
+out:
+	free(sum);
+	free(df);
+	return ret;
+}
+
+int
+nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_params_t *params,
+    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_index_t *idx0 = shards[0];
+	nxs_t *nxs = idx0->nxs;
+	search_params_t sp;
+	qprep_t *prep = NULL;
+	nxsgpu_query_t *plans = NULL;
+	uint32_t *plan_of = NULL, *cnt_s = NULL, *cnt_all = NULL, *o_cnt = NULL;
+	uint64_t *ids_s = NULL, *ids_all = NULL, *o_ids = NULL;
+	float *sc_s = NULL, *sc_all = NULL, *o_sc = NULL;
+	slab_builder_t sb = { 0 };
+	size_t np = 0, total = 0;
+	uint32_t cap = 512;
+	int failed = 0, ret = -1;
+
+	nxs_clear_error(nxs);
+	for (size_t i = 0; i < n; i++) {
+		resps[i] = NULL;
+		if (errs) {
+			errs[i] = NXS_ERR_SUCCESS;
+		}
+	}
+	if (get_search_params(idx0, params, &sp) == -1) {
+		return -1;
+	}
+	if (sp.limit > NXSGPU_FAST_K) {
+		nxs_decl_err(nxs, NXS_ERR_LIMIT, "doc-sharded search takes limit <= %d", NXSGPU_FAST_K);
+		return -1;
+	}
+	if (!idx0->global_df_set && docshard_set_global_df(shards, n_shards) == -1) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	prep = calloc(n, sizeof(qprep_t));
+	plans = calloc(n, sizeof(nxsgpu_query_t));
+	plan_of = calloc(n, sizeof(uint32_t));
+	if (!prep || !plans || !plan_of) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	/* the term dictionary and the BK-tree are the same on every shard */
+	if (plan_batch(idx0, &sp, queries, n, prep) == -1) {
+		goto out;
+	}
+	for (size_t i = 0; i < n; i++) {
+		if (!prep[i].errcode && prep[i].wide) {
+			prep[i].errcode = NXS_ERR_LIMIT;
+			prep[i].errmsg = strdup("doc-sharded search takes at most 32 query terms");
+		}
+		if (!prep[i].errcode && !prep[i].empty) {
+			plan_of[i] = (uint32_t)np;
+			plans[np++] = prep[i].plan;
+		}
+	}
+	o_ids = malloc((np ? np : 1) * sp.limit * sizeof(uint64_t));
+	o_sc = malloc((np ? np : 1) * sp.limit * sizeof(float));
+	o_cnt = calloc(np ? np : 1, sizeof(uint32_t));
+	for (;;) {
+		bool overflow = false;
+
+		free(ids_s); free(sc_s); free(cnt_s); free(ids_all); free(sc_all); free(cnt_all);
+		ids_s = malloc((np ? np : 1) * (size_t)cap * sizeof(uint64_t));
+		sc_s = malloc((np ? np : 1) * (size_t)cap * sizeof(float));
+		cnt_s = calloc(np ? np : 1, sizeof(uint32_t));
+		ids_all = malloc((np ? np : 1) * (size_t)n_shards * cap * sizeof(uint64_t));
+		sc_all = malloc((np ? np : 1) * (size_t)n_shards * cap * sizeof(float));
+		cnt_all = calloc((np ? np : 1) * (size_t)n_shards, sizeof(uint32_t));
+		if (!o_ids || !o_sc || !o_cnt || !ids_s || !sc_s || !cnt_s || !ids_all || !sc_all || !cnt_all) {
+			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+			goto out;
+		}
+		for (unsigned s = 0; s < n_shards && np; s++) {
+			if (nxsgpu_search_candidates(shards[s]->dev, sp.algo, sp.limit, plans, (uint32_t)np, cap,
+			    ids_s, sc_s, cnt_s) != 0) {
+				nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+				goto out;
+			}
+			/* [query][shard][cap]: what the merge (and an all-gather of the
+			 * shards' blocks, in a multi-process deployment) works on */
+			for (size_t q = 0; q < np; q++) {
+				const size_t at = (q * n_shards + s) * cap;
+				overflow = overflow || cnt_s[q] > cap;
+				cnt_all[q * n_shards + s] = cnt_s[q];
+				memcpy(ids_all + at, ids_s + q * cap, (size_t)cap * sizeof(uint64_t));
+				memcpy(sc_all + at, sc_s + q * cap, (size_t)cap * sizeof(float));
+			}
+		}
+		if (!overflow) {
+			break;
+		}
+		if (cap >= (1u << 16)) {
+			nxs_decl_err(nxs, NXS_ERR_LIMIT, "candidate log overflow");
+			goto out;
+		}
+		cap *= 8;	/* rare: adversarial score orders; try again with room */
+	}
+	if (np && nxsgpu_merge_candidates(idx0->device, (uint32_t)sp.limit, (uint32_t)np, n_shards, cap,
+	    ids_all, sc_all, cnt_all, o_ids, o_sc, o_cnt) != 0) {
+		nxs_decl_err(nxs, NXS_ERR_FATAL, "merge failed: %s", nxsgpu_last_error());
+		goto out;
+	}
+	for (size_t q = 0; q < np; q++) {
+		total += o_cnt[q];
+	}
+	if (slab_begin(&sb, n, total) == -1) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	for (size_t i = 0; i < n; i++) {
+		const qprep_t *q = &prep[i];
+		nxs_resp_t *rp;
+
+		if (q->errcode) {
+			failed++;
+			if (errs) {
+				errs[i] = q->errcode;
+			}
+			nxs_decl_err(nxs, q->errcode, "%s", q->errmsg ? q->errmsg : "");
+			continue;
+		}
+		if (q->empty) {
+			resps[i] = slab_resp(&sb, i, 0);
+			continue;
+		}
+		rp = slab_resp(&sb, i, o_cnt[plan_of[i]]);
+		memcpy(rp->ids, o_ids + (size_t)plan_of[i] * sp.limit, (size_t)rp->count * sizeof(uint64_t));
+		memcpy(rp->scores, o_sc + (size_t)plan_of[i] * sp.limit, (size_t)rp->count * sizeof(float));
+		resps[i] = rp;
+	}
+	if (sb.slab && sb.slab->refs == 0) {
+		free(sb.slab);
+	}
+	ret = failed;
+out:
+	for (size_t i = 0; prep && i < n; i++) {
+		nxs_query_release(&prep[i]);
+	}
+	free(prep); free(plans); free(plan_of);
+	free(ids_s); free(sc_s); free(cnt_s); free(ids_all); free(sc_all); free(cnt_all);
+	free(o_ids); free(o_sc); free(o_cnt);
+	return ret;
 }
 
 /* ---- query sharding over the GPUs of a node ---------------------------------------- */

@@ -229,6 +229,7 @@ struct nxsgpu_index {
 	posting_t *	d_post[2];	/* [P] per ranking algo */
 	std::vector<uint64_t> h_post_off;
 	std::vector<float> h_maximp[2];	/* [T+2] largest impact per term and ranking algo */
+	std::vector<uint32_t> df_global;	/* [T+2] doc-sharded mode: collection-wide df, else empty */
 
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;
@@ -3284,6 +3285,20 @@ struct replay_args_t {
 	uint8_t *		rec_base;
 	const uint32_t *	rec_slot;
 	uint32_t		rec_bytes;
+	/*
+	 * Doc-sharded mode (N4): every item the heap ACCEPTS, in feed order, is
+	 * also written to log_*[q * log_cap ...] -- the exact sequence the
+	 * reference's heap would take from this shard's docs if they were fed alone;
+	 * the sequence it takes from them inside the global feed is a subsequence
+	 * (the global root is never below the local one).  log_cnt[q] keeps counting
+	 * past log_cap (overflow).  cand_doc == NULL: the candidate's index is its
+	 * doc handle (doc_ids[] is then indexed like cand_sc[]).
+	 */
+	uint64_t *		log_ids;
+	float *			log_sc;
+	uint32_t *		log_cnt;
+	uint32_t		log_cap;
+	const uint32_t *	log_slot;	/* [Q] row of the log per query (NULL: q) */
 };
 
 template <bool LDS_HEAP>
@@ -3382,7 +3397,7 @@ k_replay(const replay_args_t A)
 				if (j < total) {
 					const uint64_t at = s_sb + (j - (s_incl - s_cnt));
 					scv[u] = A.cand_sc[at];
-					dcv[u] = A.cand_doc[at];
+					dcv[u] = A.cand_doc ? A.cand_doc[at] : (uint32_t)at;
 				}
 			}
 #pragma unroll
@@ -3402,6 +3417,15 @@ k_replay(const replay_args_t A)
 					if (lane == 0) {
 						uint32_t cnt = s_n;
 						heap_add(hs, hd, &cnt, cap, v, dv);
+						if (A.log_cnt) {
+							const uint32_t row = A.log_slot ? A.log_slot[q] : q;
+							const uint32_t nl = A.log_cnt[row];
+							if (nl < A.log_cap) {
+								A.log_ids[(uint64_t)row * A.log_cap + nl] = A.doc_ids[dv];
+								A.log_sc[(uint64_t)row * A.log_cap + nl] = v;
+							}
+							A.log_cnt[row] = nl + 1;
+						}
 						s_n = cnt;
 						s_min = hs[0];
 					}
@@ -4080,7 +4104,9 @@ rebuild_impacts(nxsgpu_index_t *ix)
 		std::vector<std::thread> thr;
 		auto work = [&](uint32_t lo, uint32_t hi) {
 			for (uint32_t t = lo; t < hi; t++) {
-				const unsigned long df = ix->h_post_off[t + 1] - ix->h_post_off[t];
+				/* doc-sharded (N4): df of the WHOLE collection, not of this shard */
+				const unsigned long df = !ix->df_global.empty() ? ix->df_global[t] :
+				    ix->h_post_off[t + 1] - ix->h_post_off[t];
 				if (df == 0 || N == 0) {
 					continue;
 				}
@@ -4191,8 +4217,10 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		HIP_TRY(hipEventCreate(&ix->ev[i]));
 	}
 
-	HIP_TRY(hipMalloc(&ix->d_doc_ids, std::max<uint64_t>(D, 1) * 8));
-	HIP_TRY(hipMalloc(&ix->d_doc_len, std::max<uint64_t>(D, 1) * 4));
+	/* room for appended docs (N1) without moving the tables */
+	ix->cap_docs_ids = ix->cap_docs_len = D + D / 8 + 4096;
+	HIP_TRY(hipMalloc(&ix->d_doc_ids, ix->cap_docs_ids * 8));
+	HIP_TRY(hipMalloc(&ix->d_doc_len, ix->cap_docs_len * 4));
 	HIP_TRY(hipMalloc(&ix->d_post_off, ((size_t)T + 2) * 8));
 	HIP_TRY(hipMalloc(&ix->d_post_dt, std::max<uint64_t>(P, 1) * 8));
 	HIP_TRY(hipMalloc(&ix->d_post[0], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
@@ -4266,7 +4294,6 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 
 	ix->max_tf = h_max_tf;
 	ix->cap_post = std::max<uint64_t>(P, 1);
-	ix->cap_docs_ids = ix->cap_docs_len = std::max<uint64_t>(D, 1);
 	if (rebuild_impacts(ix) != 0) {
 		goto fail;
 	}
@@ -5059,9 +5086,17 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 	return 0;
 }
 
+/* doc-sharded mode: the accepted-candidate log of every query (host arrays) */
+struct cand_log_t {
+	uint32_t	cap;
+	uint64_t *	ids;	/* [nq * cap] */
+	float *		sc;	/* [nq * cap] */
+	uint32_t *	cnt;	/* [nq]; > cap = overflow */
+};
+
 static int
 search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
-    uint32_t nq, nxsgpu_results_t *res)
+    uint32_t nq, nxsgpu_results_t *res, cand_log_t *cl = NULL)
 {
 	const bool fast = limit <= NXSGPU_FAST_K;
 	const uint32_t seg_cap = ix->cfg.seg_cap;
@@ -5100,6 +5135,23 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		return 0;
 	}
 
+	uint64_t *d_log_ids = NULL;
+	float *d_log_sc = NULL;
+	uint32_t *d_log_cnt = NULL, *d_log_slot = NULL;
+	struct log_guard_t {
+		uint64_t *&a; float *&b; uint32_t *&c; uint32_t *&d;
+		~log_guard_t() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); }
+	} log_guard{d_log_ids, d_log_sc, d_log_cnt, d_log_slot};
+	if (cl) {
+		if (hipMalloc((void **)&d_log_ids, (size_t)nq * cl->cap * 8 + 8) != hipSuccess ||
+		    hipMalloc((void **)&d_log_sc, (size_t)nq * cl->cap * 4 + 4) != hipSuccess ||
+		    hipMalloc((void **)&d_log_cnt, (size_t)nq * 4) != hipSuccess ||
+		    hipMalloc((void **)&d_log_slot, (size_t)nq * 4) != hipSuccess ||
+		    hipMemsetAsync(d_log_cnt, 0, (size_t)nq * 4, ix->stream) != hipSuccess) {
+			set_error("hipMalloc for the candidate log failed");
+			return -1;
+		}
+	}
 	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post) != 0) {
 		return -1;
 	}
@@ -5191,6 +5243,12 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		ra.out_sc = d_sc;
 		ra.out_count = d_cnt;
 		ra.skip = d_ovf;
+		if (cl) {
+			ra.log_ids = d_log_ids;
+			ra.log_sc = d_log_sc;
+			ra.log_cnt = d_log_cnt;
+			ra.log_cap = cl->cap;
+		}
 		if (ix->cfg.one_replay) {
 			launch_scan<MODE_TOPK>(ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
@@ -5373,6 +5431,18 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			ra.out_sc = dx_sc;
 			ra.out_count = dx_cnt;
 			ra.out_off = dx_ooff;
+			if (cl) {
+				/* row of the log = the query's index in the whole batch */
+				if (hipMemcpyAsync(d_log_slot, xq.data(), (size_t)nx * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+					set_error("upload failed");
+					break;
+				}
+				ra.log_ids = d_log_ids;
+				ra.log_sc = d_log_sc;
+				ra.log_cnt = d_log_cnt;
+				ra.log_cap = cl->cap;
+				ra.log_slot = d_log_slot;
+			}
 			hipLaunchKernelGGL(k_replay<false>, dim3(nx), dim3(WAVE), 0, ix->stream, ra);
 			if (hipGetLastError() != hipSuccess) {
 				set_error("kernel launch failed");
@@ -5394,6 +5464,16 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		}
 		if (res) {
 			res->exact_requeries = nx;
+		}
+	}
+
+	if (cl) {
+		if (hipMemcpyAsync(cl->ids, d_log_ids, (size_t)nq * cl->cap * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(cl->sc, d_log_sc, (size_t)nq * cl->cap * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(cl->cnt, d_log_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("candidate log copy failed");
+			return -1;
 		}
 	}
 
@@ -5438,6 +5518,149 @@ nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t
 {
 	/* (runs behind the batches in flight, if any: same stream, own workspace) */
 	return search_impl(ix, algo, limit, queries, nq, res);
+}
+
+/* ---- N4: doc-sharded mode ------------------------------------------------------------ */
+
+extern "C" int
+nxsgpu_index_set_global_df(nxsgpu_index_t *ix, const uint32_t *df, uint32_t n_terms)
+{
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_index_set_global_df: batches are in flight");
+		return -1;
+	}
+	if (n_terms != ix->n_terms) {
+		set_error("nxsgpu_index_set_global_df: %u terms, the index has %u", n_terms, ix->n_terms);
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	ix->df_global.assign((size_t)n_terms + 2, 0);
+	for (uint32_t t = 1; t <= n_terms; t++) {
+		ix->df_global[t] = df[t];
+	}
+	return rebuild_impacts(ix);
+}
+
+extern "C" int
+nxsgpu_search_candidates(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint32_t cap, uint64_t *ids, float *scores, uint32_t *counts)
+{
+	cand_log_t cl;
+	nxsgpu_results_t res;
+	int r;
+
+	if (cap == 0) {
+		set_error("nxsgpu_search_candidates: cap is 0");
+		return -1;
+	}
+	cl.cap = cap;
+	cl.ids = ids;
+	cl.sc = scores;
+	cl.cnt = counts;
+	memset(counts, 0, (size_t)nq * 4);
+	r = search_impl(ix, algo, limit, queries, nq, &res, &cl);
+	if (r == 0) {
+		nxsgpu_results_free(&res);
+	}
+	return r;
+}
+
+/*
+ * The merge step of the doc-sharded mode: the shards' accepted-candidate logs
+ * of every query, highest shard (highest doc ids) first, are fed to the
+ * reference's heap again (k_replay) -- by induction its state is the global
+ * one (results.c:182-220 feeds descending doc id; heap.c:58-221).  Layout:
+ * ids/scores [nq][n_shards][cap], counts [nq][n_shards], shard 0 = LOWEST docs.
+ * Output: [nq][limit] + counts.  Runs on `device`, blocking.
+ */
+extern "C" int
+nxsgpu_merge_candidates(int device, uint32_t limit, uint32_t nq, uint32_t n_shards, uint32_t cap,
+    const uint64_t *ids, const float *scores, const uint32_t *counts,
+    uint64_t *out_ids, float *out_scores, uint32_t *out_counts)
+{
+	const size_t nseg = (size_t)nq * n_shards, ncand = nseg * cap;
+	std::vector<qmeta_t> qm(nq);
+	void *ws = NULL;
+	hipStream_t st = NULL;
+	int rc = -1;
+
+	if (limit == 0 || limit > NXSGPU_FAST_K) {
+		set_error("nxsgpu_merge_candidates: limit must be 1..%d", NXSGPU_FAST_K);
+		return -1;
+	}
+	if (nq == 0) {
+		return 0;
+	}
+	for (size_t i = 0; i < nseg; i++) {
+		if (counts[i] > cap) {
+			set_error("nxsgpu_merge_candidates: a candidate log overflowed (%u > %u)", counts[i], cap);
+			return -1;
+		}
+	}
+	for (uint32_t q = 0; q < nq; q++) {
+		qm[q].seg_first = q * n_shards;
+		qm[q].n_groups = n_shards;
+		qm[q].group_docs = 0;
+		qm[q].pad = 0;
+	}
+	do {
+		if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+			set_error("device setup failed");
+			break;
+		}
+		const size_t need = 8192 + nq * sizeof(qmeta_t) + nseg * 4 + ncand * 12 + (size_t)nq * limit * 12 + nq * 4;
+		if (hipMalloc(&ws, need) != hipSuccess) {
+			set_error("hipMalloc(%zu) failed", need);
+			break;
+		}
+		uint8_t *p = (uint8_t *)ws;
+		qmeta_t *d_qm = carve<qmeta_t>(p, nq);
+		uint32_t *d_cnt = carve<uint32_t>(p, nseg);
+		uint64_t *d_ids = carve<uint64_t>(p, ncand);
+		float *d_sc = carve<float>(p, ncand);
+		uint64_t *d_oid = carve<uint64_t>(p, (size_t)nq * limit);
+		float *d_osc = carve<float>(p, (size_t)nq * limit);
+		uint32_t *d_ocnt = carve<uint32_t>(p, nq);
+		replay_args_t ra;
+
+		if (hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(qmeta_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+		    hipMemcpyAsync(d_cnt, counts, nseg * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+		    hipMemcpyAsync(d_ids, ids, ncand * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+		    hipMemcpyAsync(d_sc, scores, ncand * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+		    hipMemsetAsync(d_ocnt, 0, nq * 4, st) != hipSuccess) {
+			set_error("upload failed");
+			break;
+		}
+		memset(&ra, 0, sizeof(ra));
+		ra.qmeta = d_qm;
+		ra.seg_cap = cap;
+		ra.seg_count = d_cnt;
+		ra.cand_doc = NULL;		/* the candidate's index is its handle */
+		ra.cand_sc = d_sc;
+		ra.doc_ids = d_ids;
+		ra.k = limit;
+		ra.out_ids = d_oid;
+		ra.out_sc = d_osc;
+		ra.out_count = d_ocnt;
+		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, st, ra);
+		if (hipGetLastError() != hipSuccess ||
+		    hipMemcpyAsync(out_ids, d_oid, (size_t)nq * limit * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipMemcpyAsync(out_scores, d_osc, (size_t)nq * limit * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipMemcpyAsync(out_counts, d_ocnt, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess) {
+			set_error("merge failed: %s", hipGetErrorString(hipGetLastError()));
+			break;
+		}
+		rc = 0;
+	} while (0);
+	(void)hipFree(ws);
+	if (st) {
+		(void)hipStreamDestroy(st);
+	}
+	return rc;
 }
 
 /*

@@ -110,6 +110,10 @@ struct nxs_index {
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
 	double		hp_plan, hp_queue, hp_wait, hp_resps;
 	uint64_t	hp_batches;
+	/* doc-sharded mode (N4): this index is shard `shard` of `n_shards` (0 = whole) */
+	unsigned	shard, n_shards;
+	int		want_device;	/* explicit device + 1, or 0: NXS_GPU_DEVICE / device 0 */
+	bool		global_df_set;
 	/* tests: play one rank of emu_world (nxs_test_shard_emulate) */
 	int		emu_rank, emu_world;
 	uint8_t *	emu_block;

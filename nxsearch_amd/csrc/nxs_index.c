@@ -712,6 +712,13 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 		if (walk_dtmap(idx, stop_off, &docs, &n) == -1) {
 			goto out;
 		}
+		if (idx->n_shards > 1) {
+			/* N4: this shard's slice of the docs (ascending doc id) */
+			const uint64_t lo = n * idx->shard / idx->n_shards;
+			const uint64_t hi = n * ((uint64_t)idx->shard + 1) / idx->n_shards;
+			memmove(docs, docs + lo, (hi - lo) * sizeof(ldoc_t));
+			n = hi - lo;
+		}
 		/* the doc table stays: ordinal = rank in ascending doc id */
 		free(idx->h_doc_ids); free(idx->h_blk_off); free(idx->h_npairs); free(idx->h_alive);
 		idx->cap_ord = n + n / 8 + 1024;
@@ -754,7 +761,7 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 		src.bk_bytes = bk.bytes;
 		src.bk_bytes_len = bk.bytes_len;
 
-		idx->device = dev_env ? atoi(dev_env) : 0;
+		idx->device = idx->want_device ? idx->want_device - 1 : dev_env ? atoi(dev_env) : 0;
 		idx->dev = nxsgpu_index_create(idx->device, &src);
 		free(pair_base);
 		if (!idx->dev) {
@@ -839,30 +846,31 @@ remap_if_grown(nxs_index_t *idx)
 {
 	struct stat sb;
 
+	/* mremap extends the MAP_SHARED file mapping without tearing the old pages
+	 * down (the reference grows its files in 32 KiB steps, index.h:24: this
+	 * happens often) */
 	if (stat(idx->terms_path, &sb) == 0 && (size_t)sb.st_size > idx->tmap_len) {
-		size_t nlen;
-		uint8_t *nm = map_file(idx->terms_path, &nlen);
-		if (!nm) {
+		uint8_t *nm = mremap(idx->tmap, idx->tmap_len, (size_t)sb.st_size, MREMAP_MAYMOVE);
+		if (nm == MAP_FAILED) {
 			return -1;
 		}
-		for (uint32_t id = 1; id <= idx->last_id; id++) {
-			if (idx->terms[id].tot_off) {
-				idx->terms[id].val = nm + (idx->terms[id].val - idx->tmap);
+		if (nm != idx->tmap) {
+			for (uint32_t id = 1; id <= idx->last_id; id++) {
+				if (idx->terms[id].tot_off) {
+					idx->terms[id].val = nm + (idx->terms[id].val - idx->tmap);
+				}
 			}
 		}
-		munmap(idx->tmap, idx->tmap_len);
 		idx->tmap = nm;
-		idx->tmap_len = nlen;
+		idx->tmap_len = (size_t)sb.st_size;
 	}
 	if (stat(idx->dtmap_path, &sb) == 0 && (size_t)sb.st_size > idx->dmap_len) {
-		size_t nlen;
-		uint8_t *nm = map_file(idx->dtmap_path, &nlen);
-		if (!nm) {
+		uint8_t *nm = mremap(idx->dmap, idx->dmap_len, (size_t)sb.st_size, MREMAP_MAYMOVE);
+		if (nm == MAP_FAILED) {
 			return -1;
 		}
-		munmap(idx->dmap, idx->dmap_len);
 		idx->dmap = nm;
-		idx->dmap_len = nlen;
+		idx->dmap_len = (size_t)sb.st_size;
 	}
 	return 0;
 }
@@ -977,6 +985,9 @@ nxs_index_refresh(nxs_index_t *idx)
 	if (t_now == idx->terms_consumed && d_now == idx->dt_consumed &&
 	    hd_docs == idx->hdr_docs_seen && hd_tokens == idx->hdr_tokens_seen) {
 		return 0;
+	}
+	if (idx->n_shards > 1) {
+		return 0;	/* a doc shard is a static snapshot (include/nxs.h) */
 	}
 	if (idx->dev && nxsgpu_batches_in_flight(idx->dev) > 0) {
 		return 0;	/* the device arrays are in use: between batches only */

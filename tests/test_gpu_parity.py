@@ -786,3 +786,46 @@ def test_incremental_refresh_grows_the_files_and_keeps_serving(nxs, tmp_path):
         assert_same(gidx.search(q, limit=20), oidx.search(q, limit=20), q)
     assert len(gidx.search("a", limit=5000)) == 3050
     gidx.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_doc_sharded_collection_equals_the_whole_index(nxs, tmp_path, n_shards):
+    """N4: the collection cut into doc ranges, every shard a device index of its
+    own scoring with collection-wide N / token count / df; a batch runs on every
+    shard and the shards' accepted candidates are replayed through the heap once
+    more (highest docs first).  Same ids, order (massive ties) and score bits as
+    the unsharded index = the oracle."""
+    rng = random.Random(61 + n_shards)
+    vocab = ["w%d" % i for i in range(50)]
+    weights = [1.0 / (i + 1) for i in range(len(vocab))]
+    pool = rng.choices(vocab, weights, k=4096)
+    docs = random_corpus(rng, 9000, pool, max_len=7, sparse=True)
+    t, d, _ = nxsfmt.write_index(str(tmp_path), "whole", docs)
+    oidx = O.Index(t, d)
+    shards = [nxs.open_shard(t, d, s_, n_shards) for s_ in range(n_shards)]
+    queries = [random_query(rng, vocab[:16]) for _ in range(50)]
+    queries += ["w0", "w0 AND w1", "w49 OR w0", "w3 OR w4 OR w5 OR w6 OR w7", "broken AND", "w1 AND NOT w0",
+                "zzzz OR yyyy", "w2 OR ww3"]
+    for limit in (1, 10, 64):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = nxs.docshard_search_batch(shards, queries, limit=limit, algo=name)
+            for q, g in zip(queries, got):
+                try:
+                    want = oidx.search(q, algo=algo, limit=limit)
+                except O.SearchError as e:
+                    assert isinstance(g, N.NxsError) and g.code == e.code
+                    continue
+                assert_same(g, want, (n_shards, q, limit, name))
+    # a synthetic corpus too (sparse and dense terms, C3-style queries)
+    c = corpus.write_corpus(str(tmp_path / "syn"), 150_000, 6000, seed=71)
+    terms = corpus.term_strings(6000, seed=71)
+    o2 = O.Index(c["terms"], c["dtmap"])
+    sh2 = [nxs.open_shard(c["terms"], c["dtmap"], s_, n_shards) for s_ in range(n_shards)]
+    qs = corpus.queries_bool5(terms, 48, seed=5, hi=500) + corpus.queries_single(terms, 8, seed=6, lo=1, hi=200)
+    for q, g in zip(qs, nxs.docshard_search_batch(sh2, qs, limit=10, fuzzymatch=False)):
+        assert_same(g, o2.search(q, limit=10, fuzzymatch=False), q)
+    with pytest.raises(N.NxsError) as e:
+        nxs.docshard_search_batch(sh2, qs[:2], limit=100)
+    assert e.value.code == 6
+    for s_ in shards + sh2:
+        s_.close()

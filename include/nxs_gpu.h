@@ -317,6 +317,10 @@ void		nxsgpu_index_reconfigure(nxsgpu_index_t *);
  * GB/s, the denominator bench.py prints beside the nominal 8 TB/s.  0 on error.
  */
 double		nxsgpu_hbm_read_gbs(nxsgpu_index_t *, int reps);
+/* one launch of k_hbm_read (16 B/lane) and of k_hbm_read_x2 (8 B/lane, the scan
+ * kernels' width) over *bytes bytes each: known byte counts to calibrate the
+ * FETCH_SIZE counter against (tools/pmc_calib.py) */
+int		nxsgpu_hbm_calibrate(nxsgpu_index_t *, uint64_t *bytes);
 
 void		nxsgpu_set_profiling(nxsgpu_index_t *, int on);
 void		nxsgpu_get_profile(nxsgpu_index_t *, nxsgpu_profile_t *, int reset);

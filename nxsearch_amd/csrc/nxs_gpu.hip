@@ -6459,6 +6459,50 @@ k_hbm_read(const v4u_t *__restrict__ src, uint64_t n16, uint32_t *__restrict__ s
 	}
 }
 
+/* the scan kernels' own access width: one 8-byte posting per lane and load
+ * (global_load_dwordx2) -- the PMC calibration case (tools/pmc_calib.py) */
+__global__ void __launch_bounds__(256)
+k_hbm_read_x2(const uint2 *__restrict__ src, uint64_t n8, uint32_t *__restrict__ sink)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint32_t acc = 0;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+	for (; i + 3 * stride < n8; i += 4 * stride) {
+		const uint2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+		acc ^= a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y ^ d.x ^ d.y;
+	}
+	for (; i < n8; i += stride) {
+		const uint2 a = src[i];
+		acc ^= a.x ^ a.y;
+	}
+	if (acc == 0x9e3779b9u) {
+		atomicAdd(sink, 1u);
+	}
+}
+
+/* one launch of each probe kernel over exactly `*bytes` bytes (returned): the
+ * known byte count FETCH_SIZE is calibrated against */
+extern "C" int
+nxsgpu_hbm_calibrate(nxsgpu_index_t *ix, uint64_t *bytes_out)
+{
+	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 2ull << 30) & ~(uint64_t)4095;
+	uint32_t *d_sink = NULL;
+
+	*bytes_out = bytes;
+	if (bytes == 0 || hipSetDevice(ix->device) != hipSuccess || hipMalloc((void **)&d_sink, 4) != hipSuccess) {
+		return -1;
+	}
+	(void)hipMemsetAsync(d_sink, 0, 4, ix->stream);
+	hipLaunchKernelGGL(k_hbm_read, dim3(256 * 16), dim3(256), 0, ix->stream,
+	    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+	hipLaunchKernelGGL(k_hbm_read_x2, dim3(256 * 16), dim3(256), 0, ix->stream,
+	    (const uint2 *)ix->d_post[NXSGPU_TF_IDF], bytes / 8, d_sink);
+	(void)hipStreamSynchronize(ix->stream);
+	(void)hipFree(d_sink);
+	return 0;
+}
+
 extern "C" double
 nxsgpu_hbm_read_gbs(nxsgpu_index_t *ix, int reps)
 {

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--terms", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--limit", type=int, default=10)
+    ap.add_argument("--name", default="C3", help="workload name (bench.py --workload)")
+    ap.add_argument("--calib", default=None, help="DIR of the --pmc FETCH_SIZE pass over tools/pmc_calib.py")
+    ap.add_argument("--calib-json", default=None, help="stdout of tools/pmc_calib.py (known byte counts)")
     a = ap.parse_args()
 
     if a.stats:
@@ -58,6 +61,33 @@ def main():
                     w.writerow([short(name), calls, round(tot, 3), round(avg, 3), round(pct, 3)])
         else:
             raise SystemExit("no single kernel stats csv / rocpd db under %s" % a.stats)
+
+    # FETCH_SIZE against known byte counts: bytes really read per counted KiB, for
+    # 16 B/lane loads (the guide's case: 2.0) and for 8 B/lane global_load_dwordx2
+    # (what the scan kernels issue)
+    calib = None
+    if a.calib and a.calib_json:
+        known = None
+        for line in open(a.calib_json):
+            line = line.strip()
+            if line.startswith("{"):
+                known = json.loads(line)["bytes_per_kernel"]
+        files = glob.glob(os.path.join(a.calib, "**", "*_counter_collection.csv"), recursive=True)
+        dbs = glob.glob(os.path.join(a.calib, "**", "*.db"), recursive=True)
+        if files:
+            with open(files[0], newline="") as f:
+                rows = [(r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(f)]
+        else:
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+        per = collections.defaultdict(float)
+        for kname, cname, val in rows:
+            if cname == "FETCH_SIZE" and short(kname).startswith("k_hbm_read"):
+                per[short(kname)] += float(val)
+        if known and per:
+            calib = {"bytes_per_kernel": known,
+                     "FETCH_SIZE_KB": dict(per),
+                     "bytes_per_counted_byte": {k: known / (v * 1024.0) for k, v in per.items() if v > 0}}
 
     # counter -> kernel -> [sum, dispatches]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
@@ -89,16 +119,23 @@ def main():
                    if k.startswith("k_scan") and cname in v)
 
     fetch_kb, write_kb = scan_total("FETCH_SIZE"), scan_total("WRITE_SIZE")
+    factor, factor_src = 2.0, "MI355X_MICROARCH.md (16 B/lane streaming reads), unverified for 8 B/lane"
+    if calib and "k_hbm_read_x2" in calib["bytes_per_counted_byte"]:
+        factor = calib["bytes_per_counted_byte"]["k_hbm_read_x2"]
+        factor_src = "measured: k_hbm_read_x2 (global_load_dwordx2, the scan kernels' width) over a known byte count"
     out = {
         "command": a.command,
-        "workload": {"docs": a.docs, "terms": a.terms, "batch": a.batch, "limit": a.limit},
+        "workload": {"name": a.name, "docs": a.docs, "terms": a.terms, "batch": a.batch, "limit": a.limit},
+        "fetch_size_calibration": calib,
+        "fetch_size_factor": factor,
+        "fetch_size_factor_source": factor_src,
         "kernel": "k_scan* (all query-class launches of one step summed)",
         "steps_profiled": a.steps,
         "FETCH_SIZE_KB_per_step": fetch_kb,
         "WRITE_SIZE_KB_per_step": write_kb,
         "correction": "gfx950 FETCH_SIZE reports half the bytes of coalesced streaming reads "
                       "(MI355X_MICROARCH.md, HBM): hbm_read_bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 as is",
-        "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+        "hbm_bytes_per_launch": fetch_kb * 1024 * factor + write_kb * 1024,
         "counters": counters,
     }
     with open(a.out_prefix + "_pmc_summary.json", "w") as f:

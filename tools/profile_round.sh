@@ -14,4 +14,8 @@ rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_fetch" -o run -- $B > /dev/null 2
 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_pmc_write" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_write.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d "$out/${tag}_pmc_sq1" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_sq1.log"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$out/${tag}_pmc_sq2" -o run -- $B > /dev/null 2> "$out/${tag}_pmc_sq2.log"
+# FETCH_SIZE against known byte counts, 16 B/lane and 8 B/lane (the scan kernels' width)
+rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_calib" -o run -- python3 tools/pmc_calib.py > "$out/${tag}_pmc_calib.json" 2> "$out/${tag}_pmc_calib.log"
+# the fuzzy path (C4) on its own: kernel stats of k_bk_level
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_fuzzy_stats" -o run -- python3 bench.py --workload C4 --steps 5 --warmup 1 --cpu-seconds 0 --no-extras > "$out/${tag}_fuzzy_bench.json" 2> "$out/${tag}_fuzzy_stats.log"
 tail -c 1500 "$out/${tag}_bench.json"

@@ -114,6 +114,8 @@ struct dev_query_t {
 	uint32_t	req;		/* tokens present in every matching mask */
 	uint32_t	n_req;		/* k_scanr: slots [0, n_req) are the required tokens ... */
 	uint8_t		slot_tok[8];	/* ... slot -> token, ascending list length within each group */
+	uint32_t	drop_mask;	/* k_scanm<.., DROP>: dense tokens that leave the scan once the
+					 * threshold exceeds what they can contribute together */
 	float		tmax[8];	/* k_scanm: largest impact of tokens 0..7 */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
@@ -135,6 +137,8 @@ struct gpu_cfg_t {
 	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */
 	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
+	bool		use_drop;	/* !NXS_GPU_NODROP: dense terms leave sparse OR scans (k_scanm<.., DROP>) */
+	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
 };
 
 static void
@@ -175,6 +179,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.one_replay = on("NXS_GPU_ONEREPLAY");
 	c.fuzzy_safe = on("NXS_GPU_FUZZY_SAFE");
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
+	c.use_drop = !on("NXS_GPU_NODROP");
+	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
 }
 
 struct nxsgpu_index {
@@ -1967,7 +1973,23 @@ nxsgpu_debug_stats(unsigned long long *out, int reset)
 /* No min-waves launch bound on kernels that own AGPRs by name (bpair_*): under
  * register pressure the compiler would spill VGPRs into accumulation registers,
  * possibly the ones with a prefetch in flight.  tests check .agpr_count. */
-template <int NT, bool GEN>	/* GEN: the expression is more than an OR: check the truth table */
+/*
+ * DROP (queries that mix sparse terms with a DENSE one -- a list holding 8 % of
+ * the docs or more): MaxScore's "non-essential lists", kept exact.  A doc that
+ * holds only dense terms scores at most U = the token-order f32 sum of their
+ * largest impacts (f32 rounding is monotone, so the bound survives the
+ * reference's own summation).  Once the candidate threshold reaches U no such
+ * doc can be emitted any more (a candidate needs score > thr), and thr never
+ * falls: from then on the dense lists LEAVE the scan -- they are not streamed at
+ * all.  A doc with sparse terms enters the pending list if its byte bound plus
+ * the quantised U can beat the threshold, and its exact score takes the dense
+ * terms' impacts from the lists by a 64-ary search (three dependent loads), in
+ * token order like every other term.  Until the threshold gets there (cold
+ * start: the first few hundred docs of a range whose higher ranges have not
+ * published yet) the dense terms are scanned like any other; the wavefront
+ * publishes its threshold the moment it drops them, so lower ranges start warm.
+ */
+template <int NT, bool GEN, bool DROP = false>	/* GEN: the expression is more than an OR: check the truth table */
 __global__ void __launch_bounds__(WAVE)
 k_scanm(const scan_args_t A)
 {
@@ -2127,6 +2149,21 @@ k_scanm(const scan_args_t A)
 	};
 	int32_t thr_q = thr_quant(thr);
 
+	/* DROP: the dense tokens, what they can add to a score (exactly: U; in
+	 * byte-map units: qU), and where their lists lie for the look-ups */
+	uint32_t dmask = 0, dropped = 0, qU = 0;
+	float U = 0.0f;
+	if constexpr (DROP) {
+		dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask);
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			if ((dmask >> t) & 1) {
+				U += tmx[t];			/* token order, f32: see above */
+				qU += (uint32_t)(tmx[t] * qs) + 2;
+			}
+		}
+	}
+
 	uint32_t n_pend = 0;
 	auto push = [&](uint64_t m, uint32_t doc) {
 		const uint32_t n = __popcll(m);
@@ -2213,6 +2250,36 @@ k_scanm(const scan_args_t A)
 				uint32_t pm = 0;	/* the tokens the doc holds (GEN) */
 				static_for<NT>([&](auto tc) {
 					constexpr int t = decltype(tc)::value;
+					if (DROP && ((dropped >> t) & 1)) {
+						/* a dense term that left the scan: 64-ary search for the
+						 * doc in its list (wave-uniform bounds) */
+						int32_t a = (int32_t)rfl32((uint32_t)lo[t]), b = (int32_t)rfl32((uint32_t)hi[t]);
+						while (b - a > WAVE) {
+							const int32_t step = (b - a + WAVE - 1) / WAVE;
+							const int32_t i = a + (int32_t)lane * step;
+							const uint32_t dd = i < b ? pt[t][i].doc : 0xffffffffu;
+							const uint32_t n_le = __popcll(ballot64(dd <= dj));
+							if (n_le == 0) {
+								b = a;		/* below the first posting: absent */
+							} else {
+								const int32_t na = a + (int32_t)(n_le - 1) * step;
+								b = min(na + step, b);
+								a = na;
+							}
+							a = (int32_t)rfl32((uint32_t)a);
+							b = (int32_t)rfl32((uint32_t)b);
+						}
+						if (b > a) {
+							const int32_t i = min(a + (int32_t)lane, b - 1);
+							const posting_t pp = pt[t][i];
+							const uint64_t mh = ballot64(pp.doc == dj);
+							if (mh) {
+								acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+								    __builtin_bit_cast(int, pp.imp), __builtin_ctzll(mh)));
+								pm |= 1u << t;
+							}
+						}
+					} else
 					if (hi[t] > lo[t]) {
 						const uint64_t ma = ballot64(Ad[t] == dj);
 						if (ma) {
@@ -2279,12 +2346,29 @@ k_scanm(const scan_args_t A)
 			}
 		}
 		WAVE_SYNC();
-		thr_q = thr_quant(thr);
+		thr_q = thr_quant(thr) - (int32_t)(DROP && dropped ? qU : 0u);
 		n_pend = 0;
 	};
 
 	/* widest tile tried next: small while nothing is known about the threshold */
 	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
+
+	if constexpr (DROP) {
+		/* a higher range has published a threshold above U already: warm start */
+		if (dmask && __builtin_amdgcn_readfirstlane(thr >= U && thr > 0.0f ? 1 : 0) != 0) {
+			dropped = dmask;
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				if ((dmask >> t) & 1) {
+					vmA[t] = vmN[t] = 0;
+					ab[t] = lo[t];
+					pdoc[t] = -1;
+					ldocN[t] = 0;
+				}
+			});
+			thr_q -= (int32_t)qU;
+		}
+	}
 
 	uint32_t ovf_u = 0;		/* `ovf` as the loop carries it */
 	for (;;) {
@@ -2300,6 +2384,9 @@ k_scanm(const scan_args_t A)
 		thr_q = (int32_t)rfl32((uint32_t)thr_q);
 		ovf_u = rfl32(ovf_u | (ovf ? 1u : 0u));
 		ovf = ovf_u != 0;
+		if constexpr (DROP) {
+			dropped = rfl32(dropped);
+		}
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			ab[t] = (int32_t)rfl32((uint32_t)ab[t]);
@@ -2421,6 +2508,33 @@ k_scanm(const scan_args_t A)
 			tw = min(tw * 2, (uint32_t)MT_W);
 		} else if (n_tile > 48) {
 			tw = max(tw / 2, (uint32_t)MT_W0);
+		}
+		if constexpr (DROP) {
+			if (!dropped && dmask) {
+				/* cold phase: a higher range may have published meanwhile */
+				const float h2 = range_hint(A, qm, g);
+				if (h2 > thr) {
+					thr = h2;
+					thr_q = thr_quant(thr);
+				}
+				const bool go = __builtin_amdgcn_readfirstlane(thr >= U ? 1 : 0) != 0;
+				if (go) {
+					dropped = dmask;
+					/* the dense lists end here as far as the scan is concerned */
+					static_for<NT>([&](auto tc) {
+						constexpr int t = decltype(tc)::value;
+						if ((dmask >> t) & 1) {
+							vmA[t] = vmN[t] = 0;
+							ab[t] = lo[t];
+							pdoc[t] = -1;
+							ldocN[t] = 0;
+						}
+					});
+					thr_q -= (int32_t)qU;	/* their share of every doc's bound, from now on */
+					tw = (uint32_t)MT_W_HINTED;
+					range_publish(A, seg, __shfl(top, kidx));	/* lower ranges start warm */
+				}
+			}
 		}
 	}
 
@@ -4756,6 +4870,29 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt &&
 			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
 				cls[i] = 4u * 64 + (or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
+			} else if (tile && or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
+			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
+				/*
+				 * A pure OR of sparse terms AND dense ones: the mask path on the
+				 * sparse terms, the dense lists leave the scan once the threshold
+				 * exceeds their joint ceiling (k_scanm<.., DROP>).  Needs enough
+				 * sparse postings for a threshold to form in every doc range; the
+				 * work is what the sparse lists hold.
+				 */
+				uint64_t ws = 0;
+				uint32_t n_sparse = 0;
+				for (uint32_t t = 0; t < hq[i].nt; t++) {
+					if (!((hq[i].drop_mask >> t) & 1)) {
+						ws += hq[i].pend[t] - hq[i].pbeg[t];
+						n_sparse++;
+					}
+				}
+				if (n_sparse && ws >= cf.drop_minpost) {
+					total -= work[i];
+					work[i] = ws + 8192;
+					total += work[i];
+					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
+				}
 			}
 			/* required terms: intersect first (k_scanr).  Its work is set by
 			 * the shortest required list; longer lists are mostly skipped */
@@ -4776,7 +4913,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	/* launch order of the classes: the mask path first -- a class's heap replay
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
-	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 4 ? (c & 63) : c + 64; };
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 4 ? (c & 63) : (c >> 6) == 5 ? 32 + (c & 63) : c + 128; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
 		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
@@ -4967,6 +5104,24 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 					}
 				}
 			}
+		} else if (l.kind == 5) {
+			/* sparse + dense pure OR: top-k pass with the dense lists dropped;
+			 * the exact passes take the accumulator tiles */
+			if (MODE == MODE_TOPK && a.k >= 1 && a.k <= WAVE) {
+				switch (l.nt_bucket) {
+				case 2:
+				case 3: hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, ix->stream, a); break;
+				case 5: hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, ix->stream, a); break;
+				default: hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, ix->stream, a); break;
+				}
+			} else {
+				switch (l.nt_bucket) {
+				case 2: hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); break;
+				case 3: hipLaunchKernelGGL((k_scan8<MODE, 3, 1>), grid, block, 0, ix->stream, a); break;
+				case 5: hipLaunchKernelGGL((k_scan8<MODE, 5, 1>), grid, block, 0, ix->stream, a); break;
+				default: hipLaunchKernelGGL((k_scan8<MODE, 8, 1>), grid, block, 0, ix->stream, a); break;
+				}
+			}
 		} else if (l.kind == 3) {
 			switch (l.nt_bucket) {
 			case 2: hipLaunchKernelGGL((k_scanr<MODE, 2>), grid, block, 0, ix->stream, a); break;
@@ -5062,6 +5217,15 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			total_post += d.pend[t] - d.pbeg[t];
 			if (t < 8 && tid < ix->h_maximp[algo].size()) {
 				d.tmax[t] = ix->h_maximp[algo][tid];
+			}
+		}
+		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
+		d.drop_mask = 0;
+		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop) {
+			for (uint32_t t = 0; t < d.nt; t++) {
+				if ((double)(d.pend[t] - d.pbeg[t]) > ix->cfg.scanm_dens * (double)ix->n_docs) {
+					d.drop_mask |= 1u << t;
+				}
 			}
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */

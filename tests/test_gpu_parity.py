@@ -399,7 +399,10 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_NOSCANR2": "1"},
                                  {"NXS_GPU_NOSCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
+                                 {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
@@ -425,7 +428,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
 
 
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
-                                 {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"}])
+                                 {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
     tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""
@@ -829,3 +833,33 @@ def test_doc_sharded_collection_equals_the_whole_index(nxs, tmp_path, n_shards):
     assert e.value.code == 6
     for s_ in shards + sh2:
         s_.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"}])
+def test_dense_terms_leave_sparse_or_scans(nxs, tmp_path, monkeypatch, env):
+    """k_scanm<.., DROP>: pure-OR queries that mix dense terms (8 % of the docs and
+    more) with sparse ones.  The dense lists are scanned only until the threshold
+    exceeds what they can contribute, then looked up per candidate; cold starts
+    (tiny ranges, fewer sparse docs than k), massive ties and both rankings."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = corpus.write_corpus(str(tmp_path), 300_000, 12_000, seed=83)
+    terms = corpus.term_strings(12_000, seed=83)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    rng = random.Random(3)
+    T = lambda r: terms[r - 1].decode()
+    qs = []
+    for _ in range(60):
+        nd, ns = rng.randint(1, 2), rng.randint(1, 5)
+        ranks = rng.sample(range(1, 25), nd) + rng.sample(range(40, 4000), ns)
+        rng.shuffle(ranks)
+        qs.append(" OR ".join(T(r) for r in ranks))
+    qs += ["%s OR %s" % (T(1), T(11000)), "%s OR %s OR %s" % (T(2), T(3), T(9000)),    # almost no sparse docs
+           "%s %s %s %s" % (T(5), T(300), T(301), T(302))]
+    for limit in (1, 10, 64):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = gidx.search_batch(qs, limit=limit, algo=name, fuzzymatch=False)
+            for q, g in zip(qs, got):
+                assert_same(g, oidx.search(q, algo=algo, limit=limit, fuzzymatch=False), (env, q, limit, name))
+    gidx.close()

@@ -36,7 +36,9 @@ bits = lambda x: struct.pack("<f", x)
 bad = 0
 t0 = time.time()
 want = {}
-for env in ({}, {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
+for env in ({}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "256"},
+            {"NXS_GPU_SCANM_DENS": "0.01", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
+            {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
             {"NXS_GPU_NOSCANM": "1"}):
     for kk, v in env.items():
         os.environ[kk] = v

@@ -158,9 +158,10 @@ int		nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards,
 /*
  * Host-side phase times of the batches since the last call, in seconds:
  * out[0] parse/resolve/compile, out[1] queueing on the device, out[2] waiting
- * for the device, out[3] building responses, out[4] number of batches.
+ * for the device, out[3] building responses, out[4] number of batches, out[5]
+ * queries that had to be re-run on the exact two-pass path.
  */
-void		nxs_index_host_profile(nxs_index_t *, double out[5]);
+void		nxs_index_host_profile(nxs_index_t *, double out[6]);
 
 /* The device-side handle behind an index (see nxs_gpu.h), for benches. */
 struct nxsgpu_index;

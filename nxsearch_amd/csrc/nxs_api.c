@@ -1059,8 +1059,10 @@ now_s(void)
  * building the responses; out[4] = batches.  Reset on read.
  */
 void
-nxs_index_host_profile(nxs_index_t *idx, double out[5])
+nxs_index_host_profile(nxs_index_t *idx, double out[6])
 {
+	out[5] = (double)idx->hp_inexact;	/* queries re-run on the exact path */
+	idx->hp_inexact = 0;
 	out[0] = idx->hp_plan;
 	out[1] = idx->hp_queue;
 	out[2] = idx->hp_wait;
@@ -1434,6 +1436,7 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 			if (run_exact(idx, pd, which, nw, &res, &wres, pos) != 0) {
 				goto out;
 			}
+			idx->hp_inexact += nw;
 			for (size_t j = 0; j < nw; j++) {
 				uint8_t *rec = mine + (size_t)which[j] * v.rec_bytes;
 				uint32_t *st = (uint32_t *)(mine + (size_t)v.n_slots * v.rec_bytes);

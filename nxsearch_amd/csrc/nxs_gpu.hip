@@ -116,6 +116,7 @@ struct dev_query_t {
 	uint8_t		slot_tok[8];	/* ... slot -> token, ascending list length within each group */
 	uint32_t	drop_mask;	/* k_scanm<.., DROP>: dense tokens that leave the scan once the
 					 * threshold exceeds what they can contribute together */
+	uint32_t	drop_col[8];	/* ... and their impact columns (scan_args_t::dense_col) */
 	float		tmax[8];	/* k_scanm: largest impact of tokens 0..7 */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
@@ -236,6 +237,15 @@ struct nxsgpu_index {
 	std::vector<uint64_t> h_post_off;
 	std::vector<float> h_maximp[2];	/* [T+2] largest impact per term and ranking algo */
 	std::vector<uint32_t> df_global;	/* [T+2] doc-sharded mode: collection-wide df, else empty */
+	/*
+	 * Dense terms (lists holding more than cfg.scanm_dens of the docs: a few
+	 * dozen at most) also get a direct-access impact COLUMN per ranking
+	 * function, [n_docs] f32: what a candidate needs from a dense list once
+	 * k_scanm<.., DROP> no longer streams it is then one load, not a search.
+	 */
+	std::vector<uint32_t> dense_terms;	/* ascending term ids; column = position */
+	uint32_t *	d_dense_col[2];
+	uint64_t	dense_cap;		/* allocated words per algo */
 
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;
@@ -399,6 +409,17 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 		if (bt_ > max_tfidf[t]) {
 			atomicMax(&max_tfidf[t], bt_);
 		}
+	}
+}
+
+/* impact column of one dense term: col[doc] = impact bits of its postings */
+__global__ void
+k_dense_fill(const posting_t *__restrict__ post, uint64_t beg, uint64_t end, uint32_t *__restrict__ col)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = beg + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
+		const posting_t p = post[i];
+		col[p.doc] = __float_as_uint(p.imp);
 	}
 }
 
@@ -625,6 +646,9 @@ struct scan_args_t {
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
 	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
+	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
+						 * 0xffffffff = the doc does not hold the term */
+	uint64_t		dense_stride;
 };
 
 /*
@@ -2151,7 +2175,7 @@ k_scanm(const scan_args_t A)
 
 	/* DROP: the dense tokens, what they can add to a score (exactly: U; in
 	 * byte-map units: qU), and where their lists lie for the look-ups */
-	uint32_t dmask = 0, dropped = 0, qU = 0;
+	uint32_t dmask = 0, dropped = 0, qU = 0, q1max = 0;
 	float U = 0.0f;
 	if constexpr (DROP) {
 		dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask);
@@ -2160,8 +2184,12 @@ k_scanm(const scan_args_t A)
 			if ((dmask >> t) & 1) {
 				U += tmx[t];			/* token order, f32: see above */
 				qU += (uint32_t)(tmx[t] * qs) + 2;
+			} else {
+				q1max = max(q1max, (uint32_t)(tmx[t] * qs) + 2);	/* one sparse posting's largest share */
 			}
 		}
+		q1max = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1max);
+		qU = (uint32_t)__builtin_amdgcn_readfirstlane((int)qU);
 	}
 
 	uint32_t n_pend = 0;
@@ -2242,6 +2270,20 @@ k_scanm(const scan_args_t A)
 			const bool live = valid && !dup;
 			float sc = 0.0f;
 			uint64_t todo = ballot64(live);
+			/* DROP: every lane fetches its own doc's impacts in the dropped dense
+			 * terms -- independent loads, one round trip for the whole chunk */
+			uint32_t dcol[NT];
+			if constexpr (DROP) {
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					dcol[t] = 0xffffffffu;
+					if ((dropped >> t) & 1) {
+						const uint64_t cbase = (uint64_t)__builtin_amdgcn_readfirstlane((int)Q->drop_col[t]) * A.dense_stride;
+						dcol[t] = A.dense_col[cbase + (live ? d : 0u)];
+					}
+				});
+			}
+			(void)dcol;
 			while (todo) {
 				const int j = __builtin_ctzll(todo);
 				todo &= todo - 1;
@@ -2251,33 +2293,12 @@ k_scanm(const scan_args_t A)
 				static_for<NT>([&](auto tc) {
 					constexpr int t = decltype(tc)::value;
 					if (DROP && ((dropped >> t) & 1)) {
-						/* a dense term that left the scan: 64-ary search for the
-						 * doc in its list (wave-uniform bounds) */
-						int32_t a = (int32_t)rfl32((uint32_t)lo[t]), b = (int32_t)rfl32((uint32_t)hi[t]);
-						while (b - a > WAVE) {
-							const int32_t step = (b - a + WAVE - 1) / WAVE;
-							const int32_t i = a + (int32_t)lane * step;
-							const uint32_t dd = i < b ? pt[t][i].doc : 0xffffffffu;
-							const uint32_t n_le = __popcll(ballot64(dd <= dj));
-							if (n_le == 0) {
-								b = a;		/* below the first posting: absent */
-							} else {
-								const int32_t na = a + (int32_t)(n_le - 1) * step;
-								b = min(na + step, b);
-								a = na;
-							}
-							a = (int32_t)rfl32((uint32_t)a);
-							b = (int32_t)rfl32((uint32_t)b);
-						}
-						if (b > a) {
-							const int32_t i = min(a + (int32_t)lane, b - 1);
-							const posting_t pp = pt[t][i];
-							const uint64_t mh = ballot64(pp.doc == dj);
-							if (mh) {
-								acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-								    __builtin_bit_cast(int, pp.imp), __builtin_ctzll(mh)));
-								pm |= 1u << t;
-							}
+						/* a dense term that left the scan: its impact for this
+						 * doc was fetched from the term's column above */
+						const uint32_t xb = (uint32_t)__builtin_amdgcn_readlane((int)dcol[t], j);
+						if (xb != 0xffffffffu) {
+							acc += __uint_as_float(xb);
+							pm |= 1u << t;
 						}
 					} else
 					if (hi[t] > lo[t]) {
@@ -2367,6 +2388,9 @@ k_scanm(const scan_args_t A)
 				}
 			});
 			thr_q -= (int32_t)qU;
+			tw = thr_q >= (int32_t)q1max ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
+		} else if (dmask) {
+			tw = (uint32_t)MT_W0;	/* cold: the dense lists fill any wider tile */
 		}
 	}
 
@@ -2531,7 +2555,9 @@ k_scanm(const scan_args_t A)
 						}
 					});
 					thr_q -= (int32_t)qU;	/* their share of every doc's bound, from now on */
-					tw = (uint32_t)MT_W_HINTED;
+					/* a wide tile only if one sparse posting alone cannot pass:
+					 * the threshold of a cold phase is a weak one */
+					tw = thr_q >= (int32_t)q1max ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
 					range_publish(A, seg, __shfl(top, kidx));	/* lower ranges start warm */
 				}
 			}
@@ -4130,6 +4156,8 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	(void)hipFree(ix->d_post_dt);
 	(void)hipFree(ix->d_post[0]);
 	(void)hipFree(ix->d_post[1]);
+	(void)hipFree(ix->d_dense_col[0]);
+	(void)hipFree(ix->d_dense_col[1]);
 	(void)hipFree(ix->d_bk);
 	(void)hipFree(ix->d_bk_bytes);
 	(void)hipFree(ix->ws);
@@ -4269,6 +4297,53 @@ rebuild_impacts(nxsgpu_index_t *ix)
 	HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
 	    hipMemcpyDeviceToHost, ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
+	/* impact columns of the dense terms (at most 64, densest first) */
+	{
+		std::vector<std::pair<uint64_t, uint32_t>> dn;
+		for (uint32_t t = 1; t <= T; t++) {
+			const uint64_t df = ix->h_post_off[t + 1] - ix->h_post_off[t];
+			if ((double)df > ix->cfg.scanm_dens * (double)ix->n_docs && df >= 1024) {
+				dn.push_back(std::make_pair(df, t));
+			}
+		}
+		std::sort(dn.begin(), dn.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
+			return x.first != y.first ? x.first > y.first : x.second < y.second;
+		});
+		if (dn.size() > 64) {
+			dn.resize(64);
+		}
+		ix->dense_terms.clear();
+		for (auto &e : dn) {
+			ix->dense_terms.push_back(e.second);
+		}
+		std::sort(ix->dense_terms.begin(), ix->dense_terms.end());
+		const uint64_t words = (uint64_t)ix->dense_terms.size() * ix->n_docs;
+		if (words > ix->dense_cap || (!words && ix->dense_cap)) {
+			(void)hipFree(ix->d_dense_col[0]);
+			(void)hipFree(ix->d_dense_col[1]);
+			ix->d_dense_col[0] = ix->d_dense_col[1] = NULL;
+			ix->dense_cap = 0;
+			if (words) {
+				const uint64_t cap = words + words / 16 + 1024;
+				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[0], cap * 4));
+				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[1], cap * 4));
+				ix->dense_cap = cap;
+			}
+		}
+		if (words) {
+			for (int a = 0; a < 2; a++) {
+				HIP_TRY(hipMemsetAsync(ix->d_dense_col[a], 0xff, words * 4, ix->stream));
+				for (size_t c = 0; c < ix->dense_terms.size(); c++) {
+					const uint32_t t = ix->dense_terms[c];
+					hipLaunchKernelGGL(k_dense_fill, dim3(1024), dim3(256), 0, ix->stream,
+					    ix->d_post[a], ix->h_post_off[t], ix->h_post_off[t + 1],
+					    ix->d_dense_col[a] + c * ix->n_docs);
+				}
+			}
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(ix->stream));
+		}
+	}
 	rc = 0;
 fail:
 	(void)hipFree(d_logtf);
@@ -5221,10 +5296,12 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 		}
 		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
 		d.drop_mask = 0;
-		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop) {
+		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty()) {
 			for (uint32_t t = 0; t < d.nt; t++) {
-				if ((double)(d.pend[t] - d.pbeg[t]) > ix->cfg.scanm_dens * (double)ix->n_docs) {
+				const auto it = std::lower_bound(ix->dense_terms.begin(), ix->dense_terms.end(), q.term_id[t]);
+				if (it != ix->dense_terms.end() && *it == q.term_id[t]) {
 					d.drop_mask |= 1u << t;
+					d.drop_col[t] = (uint32_t)(it - ix->dense_terms.begin());
 				}
 			}
 		}
@@ -5377,6 +5454,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 
 	memset(&sa, 0, sizeof(sa));
 	sa.post = ix->d_post[algo];
+	sa.dense_col = ix->d_dense_col[algo];
+	sa.dense_stride = ix->n_docs;
 	sa.queries = d_q;
 	sa.n_docs = ix->n_docs;
 	sa.qmeta = d_qmeta;
@@ -6090,6 +6169,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	replay_args_t ra;
 	memset(&sa, 0, sizeof(sa));
 	sa.post = ix->d_post[algo];
+	sa.dense_col = ix->d_dense_col[algo];
+	sa.dense_stride = ix->n_docs;
 	sa.queries = d_q;
 	sa.n_docs = ix->n_docs;
 	sa.qmeta = d_qmeta;

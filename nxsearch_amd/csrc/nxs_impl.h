@@ -109,7 +109,7 @@ struct nxs_index {
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
 	double		hp_plan, hp_queue, hp_wait, hp_resps;
-	uint64_t	hp_batches;
+	uint64_t	hp_batches, hp_inexact;
 	/* doc-sharded mode (N4): this index is shard `shard` of `n_shards` (0 = whole) */
 	unsigned	shard, n_shards;
 	int		want_device;	/* explicit device + 1, or 0: NXS_GPU_DEVICE / device 0 */

@@ -2100,6 +2100,9 @@ k_scanm(const scan_args_t A)
 		refresh_ldoc(tc);
 	};
 
+	/* DROP: the dense tokens are never streamed; their impacts come from the
+	 * terms' columns (scan_args_t::dense_col) */
+	const uint32_t dmask = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask) : 0u;
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		pt[t] = A.post;
@@ -2119,6 +2122,9 @@ k_scanm(const scan_args_t A)
 			lo[t] = (int32_t)A.cursors[cb];
 			hi[t] = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
 			tmx[t] = Q->tmax[t];
+		}
+		if (DROP && ((dmask >> t) & 1)) {
+			hi[t] = lo[t];		/* no postings as far as the windows are concerned */
 		}
 		if (hi[t] > lo[t]) {
 			ab[t] = ((hi[t] - 1) >> 6) << 6;
@@ -2173,23 +2179,25 @@ k_scanm(const scan_args_t A)
 	};
 	int32_t thr_q = thr_quant(thr);
 
-	/* DROP: the dense tokens, what they can add to a score (exactly: U; in
-	 * byte-map units: qU), and where their lists lie for the look-ups */
-	uint32_t dmask = 0, dropped = 0, qU = 0, q1max = 0;
+	/* DROP: what the dense tokens can add to a score (exactly: U; in byte-map
+	 * units: qU -- part of every doc's bound from the start) and the largest
+	 * share of one sparse posting */
+	const uint32_t dropped = dmask;
+	uint32_t qU = 0, q1max = 0;
 	float U = 0.0f;
 	if constexpr (DROP) {
-		dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask);
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			if ((dmask >> t) & 1) {
 				U += tmx[t];			/* token order, f32: see above */
 				qU += (uint32_t)(tmx[t] * qs) + 2;
 			} else {
-				q1max = max(q1max, (uint32_t)(tmx[t] * qs) + 2);	/* one sparse posting's largest share */
+				q1max = max(q1max, (uint32_t)(tmx[t] * qs) + 2);
 			}
 		}
 		q1max = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1max);
 		qU = (uint32_t)__builtin_amdgcn_readfirstlane((int)qU);
+		thr_q -= (int32_t)qU;
 	}
 
 	uint32_t n_pend = 0;
@@ -2375,22 +2383,123 @@ k_scanm(const scan_args_t A)
 	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
 
 	if constexpr (DROP) {
-		/* a higher range has published a threshold above U already: warm start */
-		if (dmask && __builtin_amdgcn_readfirstlane(thr >= U && thr > 0.0f ? 1 : 0) != 0) {
-			dropped = dmask;
+		/*
+		 * Cold phase: while thr < U a doc that holds dense terms only may still be
+		 * a candidate, so EVERY doc of the range counts.  64 consecutive docs per
+		 * step, one per lane: the dense impacts come from the columns (one load
+		 * per dense term), the sparse terms' postings of the step -- a handful --
+		 * from their windows, summed in token order like everywhere else.  It
+		 * ends for good (thr never falls) as soon as k docs scoring >= U have
+		 * been seen here or a higher range has published such a threshold;
+		 * then the mask path takes over on the sparse terms alone.
+		 */
+		const uint32_t d_bot = min((uint64_t)g * qm.group_docs, A.n_docs);
+		const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
+		    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
+		int32_t cur = (int32_t)d_top - 1;
+		uint32_t cold = (dmask && !(thr >= U && thr > 0.0f)) ? 1u : 0u;
+		uint32_t steps = 0;
+		cold = rfl32(cold);
+		while (cold && cur >= (int32_t)d_bot && !ovf) {
+			cur = (int32_t)rfl32((uint32_t)cur);
+			n_out = rfl32(n_out);
+			steps = rfl32(steps);
+			const uint32_t base = (uint32_t)max(cur - (WAVE - 1), (int32_t)d_bot);
+			const uint32_t doc = base + lane;
+			const bool inr = doc <= (uint32_t)cur;
+			uint32_t xd[NT];
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				xd[t] = 0xffffffffu;
+				if ((dmask >> t) & 1) {
+					const uint64_t cbase = (uint64_t)__builtin_amdgcn_readfirstlane((int)Q->drop_col[t]) * A.dense_stride;
+					xd[t] = A.dense_col[cbase + (inr ? doc : base)];
+				}
+			});
+			float acc = 0.0f;
+			uint32_t pm = 0;
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
 				if ((dmask >> t) & 1) {
-					vmA[t] = vmN[t] = 0;
-					ab[t] = lo[t];
-					pdoc[t] = -1;
-					ldocN[t] = 0;
+					if (inr && xd[t] != 0xffffffffu) {
+						acc += __uint_as_float(xd[t]);
+						pm |= 1u << t;
+					}
+				} else if (hi[t] > lo[t]) {
+					/* the term's unconsumed postings inside the step (set A, and
+					 * what a shift brings up while the step lasts) */
+					for (int guard = 0; guard < 4; guard++) {
+						uint64_t in = rfl64(vmA[t] & ballot64(Ad[t] >= base));
+						vmA[t] ^= in;
+						while (in) {
+							const int j = __builtin_ctzll(in);
+							in &= in - 1;
+							const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)Ad[t], j);
+							const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+							    __builtin_bit_cast(int, Ai[t]), j));
+							if (doc == pd) {
+								acc += pi;
+								pm |= 1u << t;
+							}
+						}
+						if (!(vmA[t] == 0 && ab[t] > lo[t])) {
+							break;
+						}
+						shift(tc);
+					}
 				}
 			});
-			thr_q -= (int32_t)qU;
+			bool match = inr && pm != 0;
+			if (GEN) {
+				match = match && ((s_truth[pm >> 5] >> (pm & 31)) & 1);
+			}
+			const bool cand = match && acc > thr;
+			uint64_t bal = ballot64(cand);
+			if (bal) {
+				const uint32_t ne = __popcll(bal);
+				const bool room = n_out + ne <= A.seg_cap;
+				if (!room) {
+					ovf = true;
+				}
+				if (room && cand) {
+					/* lanes ascend with the doc: higher lanes are emitted first */
+					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+					const uint64_t o = out_base + n_out + __popcll(above);
+					A.cand_doc[o] = doc;
+					A.cand_sc[o] = acc;
+				}
+				n_out += ne;
+				while (bal) {
+					const int L = 63 - __builtin_clzll(bal);
+					const float v = __shfl(acc, L);
+					const bool ins = v > thr;
+					const uint32_t pos = __popcll(ballot64(top >= v));
+					const float up = __shfl_up(top, 1);
+					const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
+					top = ins ? ntop : top;
+					thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
+					bal &= ~(1ull << L);
+				}
+			}
+			cur = (int32_t)base - 1;
+			steps++;
+			if ((steps & 15) == 0) {
+				const float h2 = range_hint(A, qm, g);	/* a higher range may have published */
+				thr = fmaxf(thr, h2);
+			}
+			cold = rfl32(thr >= U && thr > 0.0f ? 0u : 1u);
+		}
+		if (dmask) {
+			/* warm from here on (or the range is used up) */
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				if (!((dmask >> t) & 1) && hi[t] > lo[t]) {
+					refresh_pdoc(tc);
+				}
+			});
+			thr_q = thr_quant(thr) - (int32_t)qU;
 			tw = thr_q >= (int32_t)q1max ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
-		} else if (dmask) {
-			tw = (uint32_t)MT_W0;	/* cold: the dense lists fill any wider tile */
+			range_publish(A, seg, __shfl(top, kidx));	/* lower ranges start warm */
 		}
 	}
 
@@ -2408,9 +2517,6 @@ k_scanm(const scan_args_t A)
 		thr_q = (int32_t)rfl32((uint32_t)thr_q);
 		ovf_u = rfl32(ovf_u | (ovf ? 1u : 0u));
 		ovf = ovf_u != 0;
-		if constexpr (DROP) {
-			dropped = rfl32(dropped);
-		}
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			ab[t] = (int32_t)rfl32((uint32_t)ab[t]);
@@ -2532,35 +2638,6 @@ k_scanm(const scan_args_t A)
 			tw = min(tw * 2, (uint32_t)MT_W);
 		} else if (n_tile > 48) {
 			tw = max(tw / 2, (uint32_t)MT_W0);
-		}
-		if constexpr (DROP) {
-			if (!dropped && dmask) {
-				/* cold phase: a higher range may have published meanwhile */
-				const float h2 = range_hint(A, qm, g);
-				if (h2 > thr) {
-					thr = h2;
-					thr_q = thr_quant(thr);
-				}
-				const bool go = __builtin_amdgcn_readfirstlane(thr >= U ? 1 : 0) != 0;
-				if (go) {
-					dropped = dmask;
-					/* the dense lists end here as far as the scan is concerned */
-					static_for<NT>([&](auto tc) {
-						constexpr int t = decltype(tc)::value;
-						if ((dmask >> t) & 1) {
-							vmA[t] = vmN[t] = 0;
-							ab[t] = lo[t];
-							pdoc[t] = -1;
-							ldocN[t] = 0;
-						}
-					});
-					thr_q -= (int32_t)qU;	/* their share of every doc's bound, from now on */
-					/* a wide tile only if one sparse posting alone cannot pass:
-					 * the threshold of a cold phase is a weak one */
-					tw = thr_q >= (int32_t)q1max ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
-					range_publish(A, seg, __shfl(top, kidx));	/* lower ranges start warm */
-				}
-			}
 		}
 	}
 

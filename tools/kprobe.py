@@ -47,6 +47,11 @@ sets = {
   "O": ("2-term OR rank 100..1000", [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 2)) for _ in range(a.batch)]),
   "P": ("(a AND b) OR (c AND d) rank 100..1000", ["(%s AND %s) OR (%s AND %s)" % tuple(T(r) for r in rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
   "Q": ("a OR b OR (c AND NOT d) rank 100..1000", ["%s OR %s OR (%s AND NOT %s)" % tuple(T(r) for r in rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
+  "R": ("1 dense (1..27) + 4 sparse (100..1000) OR", [" OR ".join(T(r) for r in [rng.randint(1, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
+  "S": ("1 very dense (1..5) + 4 sparse OR", [" OR ".join(T(r) for r in [rng.randint(1, 5)] + rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
+  "U": ("2 dense (1..27) + 3 sparse OR", [" OR ".join(T(r) for r in rng.sample(range(1, 28), 2) + rng.sample(range(100, 1001), 3)) for _ in range(a.batch)]),
+  "V": ("1 dense (15..27) + 4 sparse OR", [" OR ".join(T(r) for r in [rng.randint(15, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
+  "W": ("1 dense (1..27) + 4 sparse (500..1000) OR", [" OR ".join(T(r) for r in [rng.randint(1, 27)] + rng.sample(range(500, 1001), 4)) for _ in range(a.batch)]),
   "J": ("2-term AND rank 1..50 (dense)", [" AND ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
 }
 for name in a.sets.split(","):

@@ -2020,6 +2020,7 @@ k_scanm(const scan_args_t A)
 	constexpr int RING = SCANM_RING;
 	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MT_W / 4 + WAVE];	/* + one dummy word per lane */
 	__shared__ uint32_t s_pend[PEND_CAP];
+	__shared__ uint32_t s_psum[DROP ? PEND_CAP : 1];	/* DROP: the byte bound a doc was pushed with */
 	__shared__ uint32_t s_truth[GEN ? 8 : 1];	/* which presence masks match the expression */
 
 	const unsigned lane = threadIdx.x;
@@ -2201,11 +2202,14 @@ k_scanm(const scan_args_t A)
 	}
 
 	uint32_t n_pend = 0;
-	auto push = [&](uint64_t m, uint32_t doc) {
+	auto push = [&](uint64_t m, uint32_t doc, uint32_t sum) {
 		const uint32_t n = __popcll(m);
 		if (n_pend + n <= PEND_CAP) {
 			if (lane_of(m)) {
 				s_pend[n_pend + lanes_below(m)] = doc;
+				if (DROP) {
+					s_psum[n_pend + lanes_below(m)] = sum;
+				}
 			}
 		}
 		n_pend += n;
@@ -2234,13 +2238,14 @@ k_scanm(const scan_args_t A)
 		n_pend = rfl32(n_pend);		/* (see the main loop) */
 		n_out = rfl32(n_out);
 		const uint32_t nch = (n_pend + WAVE - 1) / WAVE;
-		uint32_t pd[PC], rk[PC];
+		uint32_t pd[PC], rk[PC], ps[PC];
 		STAT_ADD(3, 1);
 		STAT_ADD(4, n_pend);
 #pragma unroll
 		for (int c = 0; c < PC; c++) {
 			const uint32_t e = c * WAVE + lane;
 			pd[c] = e < n_pend ? s_pend[e] : 0;
+			ps[c] = (DROP && e < n_pend) ? s_psum[e] : 0;
 			rk[c] = 0;
 		}
 		WAVE_SYNC();
@@ -2266,6 +2271,9 @@ k_scanm(const scan_args_t A)
 			const uint32_t e = c * WAVE + lane;
 			if (e < n_pend) {
 				s_pend[rk[c]] = pd[c];
+				if (DROP) {
+					s_psum[rk[c]] = ps[c];
+				}
 			}
 		}
 		WAVE_SYNC();
@@ -2274,7 +2282,10 @@ k_scanm(const scan_args_t A)
 			const uint32_t e = off + lane;
 			const bool valid = e < n_pend;
 			const uint32_t d = valid ? s_pend[e] : 0;
-			const bool dup = valid && e > 0 && s_pend[e - 1] == d;
+			/* duplicates are adjacent, in push order: the LAST one carries the
+			 * doc's complete byte bound (DROP looks at it) */
+			const bool dup = DROP ? (valid && e + 1 < n_pend && s_pend[e + 1] == d)
+			    : (valid && e > 0 && s_pend[e - 1] == d);
 			const bool live = valid && !dup;
 			float sc = 0.0f;
 			uint64_t todo = ballot64(live);
@@ -2290,6 +2301,21 @@ k_scanm(const scan_args_t A)
 						dcol[t] = A.dense_col[cbase + (live ? d : 0u)];
 					}
 				});
+				/*
+				 * The docs were pushed on the ceiling of the dense terms (qU); now
+				 * that their real dense impacts are here the bound is redone with
+				 * them, all lanes at once: only what can still beat the threshold
+				 * goes through the exact, one-doc-at-a-time scoring below.
+				 */
+				uint32_t qd = 0;
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					if (((dropped >> t) & 1) && dcol[t] != 0xffffffffu) {
+						qd += (uint32_t)(__uint_as_float(dcol[t]) * qs) + 2;
+					}
+				});
+				const uint32_t sumq = live ? s_psum[e] : 0u;
+				todo = ballot64(live && (int32_t)(sumq + qd) > thr_q + (int32_t)qU);
 			}
 			(void)dcol;
 			while (todo) {
@@ -2563,7 +2589,7 @@ k_scanm(const scan_args_t A)
 				const uint32_t sum = ((oldv[t] >> (qv[t] & 31)) & 0xffu) + (qv[t] >> 8);
 				const uint64_t cm = vis[t] & ballot64((int32_t)sum > thr_q);
 				if (cm) {
-					push(cm, vdoc[t]);
+					push(cm, vdoc[t], sum);
 				}
 				vis[t] = 0;
 			}
@@ -2634,6 +2660,15 @@ k_scanm(const scan_args_t A)
 			}
 			refresh_pdoc(tc);
 		});
+		if (DROP && dropped) {
+			/* pushes are cheap here (refined in parallel in the flush): as wide as
+			 * the pending list takes */
+			if (n_tile <= 36) {
+				tw = min(tw * 2, (uint32_t)MT_W);
+			} else if (n_tile > 88) {
+				tw = max(tw / 2, (uint32_t)MT_W0);
+			}
+		} else
 		if (n_tile <= 8) {
 			tw = min(tw * 2, (uint32_t)MT_W);
 		} else if (n_tile > 48) {

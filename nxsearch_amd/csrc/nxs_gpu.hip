@@ -2282,10 +2282,7 @@ k_scanm(const scan_args_t A)
 			const uint32_t e = off + lane;
 			const bool valid = e < n_pend;
 			const uint32_t d = valid ? s_pend[e] : 0;
-			/* duplicates are adjacent, in push order: the LAST one carries the
-			 * doc's complete byte bound (DROP looks at it) */
-			const bool dup = DROP ? (valid && e + 1 < n_pend && s_pend[e + 1] == d)
-			    : (valid && e > 0 && s_pend[e - 1] == d);
+			const bool dup = valid && e > 0 && s_pend[e - 1] == d;
 			const bool live = valid && !dup;
 			float sc = 0.0f;
 			uint64_t todo = ballot64(live);
@@ -2314,7 +2311,16 @@ k_scanm(const scan_args_t A)
 						qd += (uint32_t)(__uint_as_float(dcol[t]) * qs) + 2;
 					}
 				});
-				const uint32_t sumq = live ? s_psum[e] : 0u;
+				/* a doc is pushed once per visit that found it above the threshold
+				 * (adjacent duplicates, at most one per term); pushes are not in
+				 * visit order, so its complete byte bound is the LARGEST of them */
+				uint32_t sumq = live ? s_psum[e] : 0u;
+#pragma unroll
+				for (int kk = 1; kk < NT; kk++) {
+					if (live && e + kk < n_pend && s_pend[e + kk] == d) {
+						sumq = max(sumq, s_psum[e + kk]);
+					}
+				}
 				todo = ballot64(live && (int32_t)(sumq + qd) > thr_q + (int32_t)qU);
 			}
 			(void)dcol;

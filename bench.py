@@ -241,7 +241,9 @@ def main():
     my_share = 1.0 / world if world > 1 else 1.0            # records of all ranks are read back
     matched = res.results / max(args.steps, 1) * my_share
     alg_bytes = prof["postings"] * POSTING_BYTES / launches + matched * RESULT_BYTES
-    scan_ms = prof["scan_ms"] / launches
+    # first scan launch -> every class scanned and replayed (classes overlap: the
+    # sparse + dense OR class runs on a stream of its own beside the others)
+    scan_ms = (prof["scan_ms"] + prof["replay_ms"]) / launches
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic(args, world)
     # one scan launch per query class and step; on C3: k_scanm<5,false> (pure OR of
@@ -256,7 +258,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(alg_bytes),
                 "kernel_ms": round(scan_ms, 4),
-                "replay_ms": round(prof["replay_ms"] / launches, 4)}
+                "of_which_after_last_scan_ms": round(prof["replay_ms"] / launches, 4)}
 
     what = WORKLOADS[args.workload][3] % args.limit
     out = {

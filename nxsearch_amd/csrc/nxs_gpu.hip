@@ -189,7 +189,9 @@ struct nxsgpu_index {
 	gpu_cfg_t	cfg;
 	hipStream_t	stream;
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
-	hipEvent_t	ev_cls, ev_join;
+	hipStream_t	stream3;	/* the sparse + dense OR class (k_scanm<.., DROP>): few, latency-bound
+					 * wavefronts that run BESIDE the other classes, not in front of them */
+	hipEvent_t	ev_cls, ev_join, ev_fork3, ev_join3;
 	/* nxsgpu_search_dev_begin/_end: two batches in flight, each with its own
 	 * device workspace and pinned staging; plans go up on their own stream */
 	hipStream_t	stream_up;
@@ -4327,6 +4329,15 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream2) {
 		(void)hipStreamDestroy(ix->stream2);
 	}
+	if (ix->stream3) {
+		(void)hipStreamDestroy(ix->stream3);
+	}
+	if (ix->ev_fork3) {
+		(void)hipEventDestroy(ix->ev_fork3);
+	}
+	if (ix->ev_join3) {
+		(void)hipEventDestroy(ix->ev_join3);
+	}
 	if (ix->stream) {
 		(void)hipStreamDestroy(ix->stream);
 	}
@@ -4507,6 +4518,9 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
@@ -5082,7 +5096,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 				}
 				if (n_sparse && ws >= cf.drop_minpost) {
 					total -= work[i];
-					work[i] = ws + 8192;
+					work[i] = 4 * ws + 65536;	/* latency-bound wavefronts: more, shorter ranges */
 					total += work[i];
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
 				}
@@ -5106,7 +5120,8 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	/* launch order of the classes: the mask path first -- a class's heap replay
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
-	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 4 ? (c & 63) : (c >> 6) == 5 ? 32 + (c & 63) : c + 128; };
+	/* (the sparse + dense class leads: it runs on a stream of its own, beside the rest) */
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 4 ? 64 + (c & 63) : c + 256; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
 		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
@@ -5223,11 +5238,18 @@ static void
 launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL)
 {
-	bool forked = false;
+	bool forked = false, forked3 = false;
 	const launch_t *last_launch = NULL;
+	size_t n_launches = 0;
 
 	for (const launch_t &l : wl.launches) {
-		if (l.count) {
+		n_launches += l.count != 0;
+	}
+	/* the sparse + dense class goes to its own stream when there is something to
+	 * run it beside (top-k pass only: its replay follows it there) */
+	const bool side3 = MODE == MODE_TOPK && ra && n_launches > 1 && a0.k >= 1 && a0.k <= WAVE;
+	for (const launch_t &l : wl.launches) {
+		if (l.count && !(side3 && l.kind == 5)) {
 			last_launch = &l;
 		}
 	}
@@ -5239,6 +5261,23 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			continue;
 		}
 		a.item_base = l.first;
+		if (side3 && l.kind == 5) {
+			replay_args_t r = *ra;
+			r.qlist = d_qorder + l.q_first;
+			if (!forked3) {
+				(void)hipEventRecord(ix->ev_fork3, ix->stream);
+				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
+				forked3 = true;
+			}
+			switch (l.nt_bucket) {
+			case 2:
+			case 3: hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, ix->stream3, a); break;
+			case 5: hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, ix->stream3, a); break;
+			default: hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, ix->stream3, a); break;
+			}
+			hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream3, r);
+			continue;
+		}
 		if (l.kind == 0) {
 			hipLaunchKernelGGL((k_scan<NXSGPU_MAX_TOKENS, uint32_t, MODE>), grid, block, 0, ix->stream, a);
 		} else if (ix->cfg.old_scan || ix->n_docs >= (1ull << 31)) {
@@ -5357,6 +5396,10 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 	if (forked) {
 		(void)hipEventRecord(ix->ev_join, ix->stream2);
 		(void)hipStreamWaitEvent(ix->stream, ix->ev_join, 0);
+	}
+	if (forked3) {
+		(void)hipEventRecord(ix->ev_join3, ix->stream3);
+		(void)hipStreamWaitEvent(ix->stream, ix->ev_join3, 0);
 	}
 }
 
@@ -6083,6 +6126,7 @@ begin_fail(nxsgpu_index_t *ix)
 	(void)hipStreamSynchronize(ix->stream_up);
 	(void)hipStreamSynchronize(ix->stream);
 	(void)hipStreamSynchronize(ix->stream2);
+	(void)hipStreamSynchronize(ix->stream3);
 	(void)hipStreamSynchronize(ix->stream_down);
 	(void)hipGetLastError();
 	return -1;

@@ -2434,90 +2434,106 @@ k_scanm(const scan_args_t A)
 		uint32_t cold = (dmask && !(thr >= U && thr > 0.0f)) ? 1u : 0u;
 		uint32_t steps = 0;
 		cold = rfl32(cold);
+		/* CB blocks of 64 docs per round: their column loads -- the round's latency
+		 * -- are all issued before the first block is looked at */
+		constexpr int CB = 4;
 		while (cold && cur >= (int32_t)d_bot && !ovf) {
 			cur = (int32_t)rfl32((uint32_t)cur);
 			n_out = rfl32(n_out);
 			steps = rfl32(steps);
-			const uint32_t base = (uint32_t)max(cur - (WAVE - 1), (int32_t)d_bot);
-			const uint32_t doc = base + lane;
-			const bool inr = doc <= (uint32_t)cur;
-			uint32_t xd[NT];
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				xd[t] = 0xffffffffu;
-				if ((dmask >> t) & 1) {
-					const uint64_t cbase = (uint64_t)__builtin_amdgcn_readfirstlane((int)Q->drop_col[t]) * A.dense_stride;
-					xd[t] = A.dense_col[cbase + (inr ? doc : base)];
-				}
-			});
-			float acc = 0.0f;
-			uint32_t pm = 0;
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				if ((dmask >> t) & 1) {
-					if (inr && xd[t] != 0xffffffffu) {
-						acc += __uint_as_float(xd[t]);
-						pm |= 1u << t;
+			uint32_t xd[CB][NT];
+#pragma unroll
+			for (int cb = 0; cb < CB; cb++) {
+				const int32_t bcur = cur - cb * WAVE;
+				const uint32_t bbase = (uint32_t)max(bcur - (WAVE - 1), (int32_t)d_bot);
+				const uint32_t bdoc = bbase + lane;
+				const bool binr = bcur >= (int32_t)d_bot && bdoc <= (uint32_t)max(bcur, 0);
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					xd[cb][t] = 0xffffffffu;
+					if ((dmask >> t) & 1) {
+						const uint64_t cbase = (uint64_t)__builtin_amdgcn_readfirstlane((int)Q->drop_col[t]) * A.dense_stride;
+						xd[cb][t] = A.dense_col[cbase + (binr ? bdoc : d_bot)];
 					}
-				} else if (hi[t] > lo[t]) {
-					/* the term's unconsumed postings inside the step (set A, and
-					 * what a shift brings up while the step lasts) */
-					for (int guard = 0; guard < 4; guard++) {
-						uint64_t in = rfl64(vmA[t] & ballot64(Ad[t] >= base));
-						vmA[t] ^= in;
-						while (in) {
-							const int j = __builtin_ctzll(in);
-							in &= in - 1;
-							const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)Ad[t], j);
-							const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-							    __builtin_bit_cast(int, Ai[t]), j));
-							if (doc == pd) {
-								acc += pi;
-								pm |= 1u << t;
+				});
+			}
+#pragma unroll
+			for (int cb = 0; cb < CB; cb++) {
+				if (cur < (int32_t)d_bot) {
+					break;
+				}
+				const uint32_t base = (uint32_t)max(cur - (WAVE - 1), (int32_t)d_bot);
+				const uint32_t doc = base + lane;
+				const bool inr = doc <= (uint32_t)cur;
+				float acc = 0.0f;
+				uint32_t pm = 0;
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					if ((dmask >> t) & 1) {
+						if (inr && xd[cb][t] != 0xffffffffu) {
+							acc += __uint_as_float(xd[cb][t]);
+							pm |= 1u << t;
+						}
+					} else if (hi[t] > lo[t]) {
+						/* the term's unconsumed postings inside the block (set A, and
+						 * what a shift brings up while the block lasts) */
+						for (int guard = 0; guard < 4; guard++) {
+							uint64_t in = rfl64(vmA[t] & ballot64(Ad[t] >= base));
+							vmA[t] ^= in;
+							while (in) {
+								const int j = __builtin_ctzll(in);
+								in &= in - 1;
+								const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)Ad[t], j);
+								const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+								    __builtin_bit_cast(int, Ai[t]), j));
+								if (doc == pd) {
+									acc += pi;
+									pm |= 1u << t;
+								}
 							}
+							if (!(vmA[t] == 0 && ab[t] > lo[t])) {
+								break;
+							}
+							shift(tc);
 						}
-						if (!(vmA[t] == 0 && ab[t] > lo[t])) {
-							break;
-						}
-						shift(tc);
+					}
+				});
+				bool match = inr && pm != 0;
+				if (GEN) {
+					match = match && ((s_truth[pm >> 5] >> (pm & 31)) & 1);
+				}
+				const bool cand = match && acc > thr;
+				uint64_t bal = ballot64(cand);
+				if (bal) {
+					const uint32_t ne = __popcll(bal);
+					const bool room = n_out + ne <= A.seg_cap;
+					if (!room) {
+						ovf = true;
+					}
+					if (room && cand) {
+						/* lanes ascend with the doc: higher lanes are emitted first */
+						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+						const uint64_t o = out_base + n_out + __popcll(above);
+						A.cand_doc[o] = doc;
+						A.cand_sc[o] = acc;
+					}
+					n_out += ne;
+					while (bal) {
+						const int L = 63 - __builtin_clzll(bal);
+						const float v = __shfl(acc, L);
+						const bool ins = v > thr;
+						const uint32_t pos = __popcll(ballot64(top >= v));
+						const float up = __shfl_up(top, 1);
+						const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
+						top = ins ? ntop : top;
+						thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
+						bal &= ~(1ull << L);
 					}
 				}
-			});
-			bool match = inr && pm != 0;
-			if (GEN) {
-				match = match && ((s_truth[pm >> 5] >> (pm & 31)) & 1);
+				cur = (int32_t)base - 1;
 			}
-			const bool cand = match && acc > thr;
-			uint64_t bal = ballot64(cand);
-			if (bal) {
-				const uint32_t ne = __popcll(bal);
-				const bool room = n_out + ne <= A.seg_cap;
-				if (!room) {
-					ovf = true;
-				}
-				if (room && cand) {
-					/* lanes ascend with the doc: higher lanes are emitted first */
-					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
-					const uint64_t o = out_base + n_out + __popcll(above);
-					A.cand_doc[o] = doc;
-					A.cand_sc[o] = acc;
-				}
-				n_out += ne;
-				while (bal) {
-					const int L = 63 - __builtin_clzll(bal);
-					const float v = __shfl(acc, L);
-					const bool ins = v > thr;
-					const uint32_t pos = __popcll(ballot64(top >= v));
-					const float up = __shfl_up(top, 1);
-					const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
-					top = ins ? ntop : top;
-					thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
-					bal &= ~(1ull << L);
-				}
-			}
-			cur = (int32_t)base - 1;
 			steps++;
-			if ((steps & 15) == 0) {
+			if ((steps & 3) == 0) {
 				const float h2 = range_hint(A, qm, g);	/* a higher range may have published */
 				thr = fmaxf(thr, h2);
 			}
@@ -5096,7 +5112,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 				}
 				if (n_sparse && ws >= cf.drop_minpost) {
 					total -= work[i];
-					work[i] = 4 * ws + 65536;	/* latency-bound wavefronts: more, shorter ranges */
+					work[i] = 2 * ws + 32768;	/* latency-bound wavefronts: more, shorter ranges */
 					total += work[i];
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
 				}

@@ -140,6 +140,8 @@ struct gpu_cfg_t {
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
 	bool		use_drop;	/* !NXS_GPU_NODROP: dense terms leave sparse OR scans (k_scanm<.., DROP>) */
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
+	uint64_t	drop_workmul;	/* NXS_GPU_DROP_WORKMUL: range count multiplier of that class */
+	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
 };
 
 static void
@@ -182,6 +184,9 @@ cfg_from_env(gpu_cfg_t &c)
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
 	c.use_drop = !on("NXS_GPU_NODROP");
 	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
+	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 1, 1, 64);
+	c.drop_prio = !on("NXS_GPU_DROP_NOPRIO");
+	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 }
 
 struct nxsgpu_index {
@@ -648,6 +653,7 @@ struct scan_args_t {
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
 	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
+	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class) */
 	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
 						 * 0xffffffff = the doc does not hold the term */
 	uint64_t		dense_stride;
@@ -2028,6 +2034,13 @@ k_scanm(const scan_args_t A)
 	const unsigned lane = threadIdx.x;
 	const unsigned long long clk0 = STAT_CLK();
 	(void)clk0;
+	if constexpr (DROP) {
+		/* few, latency-bound wavefronts beside the throughput-bound classes on
+		 * the other stream: let the CU's arbiter prefer them */
+		if (A.flags & 1) {
+			__builtin_amdgcn_s_setprio(3);
+		}
+	}
 	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
@@ -5112,7 +5125,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 				}
 				if (n_sparse && ws >= cf.drop_minpost) {
 					total -= work[i];
-					work[i] = 2 * ws + 32768;	/* latency-bound wavefronts: more, shorter ranges */
+					work[i] = cf.drop_workmul * (ws + 16384);	/* latency-bound wavefronts: more, shorter ranges */
 					total += work[i];
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
 				}
@@ -5263,7 +5276,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 	}
 	/* the sparse + dense class goes to its own stream when there is something to
 	 * run it beside (top-k pass only: its replay follows it there) */
-	const bool side3 = MODE == MODE_TOPK && ra && n_launches > 1 && a0.k >= 1 && a0.k <= WAVE;
+	const bool side3 = MODE == MODE_TOPK && ra && n_launches > 1 && a0.k >= 1 && a0.k <= WAVE && ix->cfg.drop_side;
 	for (const launch_t &l : wl.launches) {
 		if (l.count && !(side3 && l.kind == 5)) {
 			last_launch = &l;
@@ -5285,6 +5298,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
 				forked3 = true;
 			}
+			a.flags = ix->cfg.drop_prio ? 1u : 0u;
 			switch (l.nt_bucket) {
 			case 2:
 			case 3: hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, ix->stream3, a); break;

@@ -395,8 +395,10 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
     # (4) TF-IDF pass over the same batch
     pt = N._make_params(k, "TF-IDF", fuzzy_on)
     B.nxs_bench_batches(idx._h, pt, qarr, nq, 2, 2, C.byref(o))
+    idx.host_profile()
     B.nxs_bench_batches(idx._h, pt, qarr, nq, 10, 2, C.byref(o))
-    res["tfidf"] = {"queries_per_s": round(nq * 10 / o.seconds, 1), "failed": int(o.failed)}
+    res["tfidf"] = {"queries_per_s": round(nq * 10 / o.seconds, 1), "failed": int(o.failed),
+                    "exact_requeries_per_step": idx.host_profile()["exact_requeries"] / 10.0}
     L.nxs_params_release(pt)
 
     # (5) default limit (1000): what nxs_index_search(idx, NULL, ...) takes -- the

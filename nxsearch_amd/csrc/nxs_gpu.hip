@@ -5486,14 +5486,35 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			}
 		}
 		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
+		/*
+		 * (BM25 only: its tf part saturates, so a term's largest impact says what
+		 * the term typically adds.  TF-IDF's log(tf + 1) does not: one posting with
+		 * an outlier tf sets a ceiling that thresholds reach late -- measured 3x
+		 * slower than the accumulator tiles there.)
+		 */
 		d.drop_mask = 0;
-		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty()) {
+		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && algo == NXSGPU_BM25) {
 			for (uint32_t t = 0; t < d.nt; t++) {
 				const auto it = std::lower_bound(ix->dense_terms.begin(), ix->dense_terms.end(), q.term_id[t]);
 				if (it != ix->dense_terms.end() && *it == q.term_id[t]) {
 					d.drop_mask |= 1u << t;
 					d.drop_col[t] = (uint32_t)(it - ix->dense_terms.begin());
 				}
+			}
+		}
+		if (d.drop_mask) {
+			/* worth it only while the dense ceiling stays well below what one
+			 * sparse posting can add */
+			float u = 0.0f, smin = INFINITY;
+			for (uint32_t t = 0; t < d.nt; t++) {
+				if ((d.drop_mask >> t) & 1) {
+					u += d.tmax[t];
+				} else {
+					smin = std::min(smin, d.tmax[t]);
+				}
+			}
+			if (!(u <= 0.8f * smin)) {
+				d.drop_mask = 0;
 			}
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */

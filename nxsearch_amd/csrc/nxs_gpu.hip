@@ -5513,7 +5513,7 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 					smin = std::min(smin, d.tmax[t]);
 				}
 			}
-			if (!(u <= 0.8f * smin)) {
+			if (!(u <= 1.25f * smin)) {
 				d.drop_mask = 0;
 			}
 		}

@@ -2027,8 +2027,11 @@ k_scanm(const scan_args_t A)
 {
 	constexpr int RING = SCANM_RING;
 	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MT_W / 4 + WAVE];	/* + one dummy word per lane */
-	__shared__ uint32_t s_pend[PEND_CAP];
-	__shared__ uint32_t s_psum[DROP ? PEND_CAP : 1];	/* DROP: the byte bound a doc was pushed with */
+	/* (DROP pushes on a ceiling and refines in parallel: a longer list, so that a
+	 * burst of pushes does not send the query to the exact two-pass path) */
+	constexpr uint32_t PCAP = DROP ? 4 * PEND_CAP : PEND_CAP;
+	__shared__ uint32_t s_pend[PCAP];
+	__shared__ uint32_t s_psum[DROP ? PCAP : 1];	/* DROP: the byte bound a doc was pushed with */
 	__shared__ uint32_t s_truth[GEN ? 8 : 1];	/* which presence masks match the expression */
 
 	const unsigned lane = threadIdx.x;
@@ -2219,7 +2222,7 @@ k_scanm(const scan_args_t A)
 	uint32_t n_pend = 0;
 	auto push = [&](uint64_t m, uint32_t doc, uint32_t sum) {
 		const uint32_t n = __popcll(m);
-		if (n_pend + n <= PEND_CAP) {
+		if (n_pend + n <= PCAP) {
 			if (lane_of(m)) {
 				s_pend[n_pend + lanes_below(m)] = doc;
 				if (DROP) {
@@ -2249,7 +2252,7 @@ k_scanm(const scan_args_t A)
 	 * (results.c:134-136).  No memory access.
 	 */
 	auto flush = [&]() {
-		constexpr int PC = PEND_CAP / WAVE;
+		constexpr int PC = PCAP / WAVE;
 		n_pend = rfl32(n_pend);		/* (see the main loop) */
 		n_out = rfl32(n_out);
 		const uint32_t nch = (n_pend + WAVE - 1) / WAVE;
@@ -2685,7 +2688,7 @@ k_scanm(const scan_args_t A)
 		}
 
 		const uint32_t n_tile = n_pend - n_before;
-		if (n_pend > PEND_CAP) {
+		if (n_pend > PCAP) {
 			ovf = true;
 		} else if (n_pend) {
 			flush();		/* looks the docs up in A and N: before any shift */

@@ -1978,6 +1978,9 @@ k_scan8(const scan_args_t A)
 					 * small tiles, not a pending-list overflow) */
 #endif
 #define	PEND_CAP	128
+#ifndef DROP_PEND_MULT
+#define	DROP_PEND_MULT	1		/* k_scanm<.., DROP>: pending list x1 (x2: -8 %, x4: -25 % on C3) */
+#endif
 #define	PEND_FLUSH	32		/* score the pending docs once this many wait */
 #define	QSUM_MAX	224		/* quantised score bound of a doc holding every term at its largest impact */
 
@@ -2029,7 +2032,7 @@ k_scanm(const scan_args_t A)
 	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MT_W / 4 + WAVE];	/* + one dummy word per lane */
 	/* (DROP pushes on a ceiling and refines in parallel: a longer list, so that a
 	 * burst of pushes does not send the query to the exact two-pass path) */
-	constexpr uint32_t PCAP = DROP ? 4 * PEND_CAP : PEND_CAP;
+	constexpr uint32_t PCAP = DROP ? DROP_PEND_MULT * PEND_CAP : PEND_CAP;
 	__shared__ uint32_t s_pend[PCAP];
 	__shared__ uint32_t s_psum[DROP ? PCAP : 1];	/* DROP: the byte bound a doc was pushed with */
 	__shared__ uint32_t s_truth[GEN ? 8 : 1];	/* which presence masks match the expression */

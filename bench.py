@@ -191,7 +191,9 @@ def main():
     n_total = args.batch if strong else args.batch * world
     queries = make_queries(args, terms, n_total, corpus)
     fuzzy_on = args.workload in ("C4", "C5")
-    if world > 1:
+    if world > 1 or os.environ.get("NXS_BENCH_FORCE_SHARD"):
+        # (FORCE_SHARD: rehearse the sharded path -- RCCL communicator, all-gather of the
+        # record blocks -- on a one-GPU box)
         multi.attach(nxs, idx, rank, world, dist, dev)
     qarr = c_strings(queries)
     params = N._make_params(args.limit, "BM25", fuzzy_on)

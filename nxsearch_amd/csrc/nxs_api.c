@@ -1207,7 +1207,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		}
 		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
 		    (uint32_t)n_plans, slot_of, status, pd->cap,
-		    pd->world > 1 && !idx->emu_world) != 0) {
+		    idx->comm != NULL && pd->world >= 1 && !idx->emu_world) != 0) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
 			    nxsgpu_last_error());
 			goto out;

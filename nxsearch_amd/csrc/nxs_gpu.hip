@@ -6259,7 +6259,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	const size_t recs_len = (size_t)o.n_slots * sl->rec_bytes;
 	if (o.records) {
 		const size_t need = (size_t)world * sl->block_bytes + 256;
-		if (world > 1 && sl->d_blocks_len < need) {
+		if (gather && sl->d_blocks_len < need) {
 			(void)hipFree(sl->d_blocks);
 			sl->d_blocks = NULL;
 			sl->d_blocks_len = 0;
@@ -6282,7 +6282,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			sl->h_blocks_len = need;
 		}
 	}
-	const bool block_in_ws = o.records && world == 1;
+	/* (a communicator of ONE rank still goes through the collective: the same
+	 * code path as N ranks, and what the one-GPU tests exercise) */
+	const bool block_in_ws = o.records && !gather;
 
 	/* plans straight into the pinned staging area (room for the work list:
 	 * <= target + nq ranges, see build_worklist) */
@@ -6469,7 +6471,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			set_error("event failed");
 			return begin_fail(ix);
 		}
-		if (world > 1) {
+		if (gather) {
 			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes, s_down) != 0) {
 				return begin_fail(ix);
 			}

@@ -159,9 +159,10 @@ int		nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards,
  * Host-side phase times of the batches since the last call, in seconds:
  * out[0] parse/resolve/compile, out[1] queueing on the device, out[2] waiting
  * for the device, out[3] building responses, out[4] number of batches, out[5]
- * queries that had to be re-run on the exact two-pass path.
+ * queries that had to be re-run on the exact two-pass path, out[6] / out[7] the
+ * whole _begin() / _end() calls.
  */
-void		nxs_index_host_profile(nxs_index_t *, double out[6]);
+void		nxs_index_host_profile(nxs_index_t *, double out[8]);
 
 /* The device-side handle behind an index (see nxs_gpu.h), for benches. */
 struct nxsgpu_index;

@@ -446,13 +446,14 @@ class Index:
 
     def host_profile(self):
         """nxs_index_host_profile(): per-batch host phase times in ms."""
-        out = (C.c_double * 6)()
+        out = (C.c_double * 8)()
         L = lib()
         L.nxs_index_host_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.nxs_index_host_profile(self._h, out)
         n = max(out[4], 1.0)
         return {"plan_ms": round(1e3 * out[0] / n, 4), "queue_ms": round(1e3 * out[1] / n, 4),
                 "wait_ms": round(1e3 * out[2] / n, 4), "resps_ms": round(1e3 * out[3] / n, 4),
+                "begin_ms": round(1e3 * out[6] / n, 4), "end_ms": round(1e3 * out[7] / n, 4),
                 "batches": int(out[4]), "exact_requeries": int(out[5])}
 
     def reconfigure(self):

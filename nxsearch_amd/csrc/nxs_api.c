@@ -909,6 +909,9 @@ plan_compile_chunk(void *arg, size_t lo, size_t hi)
 		if (!j->prep[i].errcode) {
 			(void)nxs_query_compile(&j->prep[i]);
 		}
+		/* the parse and the token list have done their job: freed here, on the
+		 * worker, not on the caller's critical path */
+		nxs_query_release_scratch(&j->prep[i]);
 	}
 }
 
@@ -1059,8 +1062,11 @@ now_s(void)
  * building the responses; out[4] = batches.  Reset on read.
  */
 void
-nxs_index_host_profile(nxs_index_t *idx, double out[6])
+nxs_index_host_profile(nxs_index_t *idx, double out[8])
 {
+	out[6] = idx->hp_begin;		/* whole _begin() / _end() calls */
+	out[7] = idx->hp_end;
+	idx->hp_begin = idx->hp_end = 0;
 	out[5] = (double)idx->hp_inexact;	/* queries re-run on the exact path */
 	idx->hp_inexact = 0;
 	out[0] = idx->hp_plan;
@@ -1126,6 +1132,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	uint64_t lo = 0, hi = n;
 	size_t n_plans = 0, nl;
 	double t0, t1 = 0;
+	const double t_in = now_s();
 	int ret = -1;
 
 	nxs_clear_error(nxs);
@@ -1216,6 +1223,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	}
 	idx->hp_queue += now_s() - t1;
 	idx->hp_batches++;
+	idx->hp_begin += now_s() - t_in;
 	pd->seq = ++idx->pend_seq;
 	pd->active = true;
 	ret = 0;
@@ -1356,6 +1364,7 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 	uint32_t *which, *pos;
 	size_t nw = 0, total = 0, n, nl;
 	double t0;
+	const double t_in = now_s();
 	int failed = 0, ret = -1;
 
 	memset(&res, 0, sizeof(res));
@@ -1551,6 +1560,7 @@ out:
 	free(which);
 	free(pos);
 	pend_release(pd);
+	idx->hp_end += now_s() - t_in;
 	return ret;
 }
 

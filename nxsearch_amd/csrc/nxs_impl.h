@@ -108,7 +108,7 @@ struct nxs_index {
 	struct nxs_pend	pend[2];
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
-	double		hp_plan, hp_queue, hp_wait, hp_resps;
+	double		hp_plan, hp_queue, hp_wait, hp_resps, hp_begin, hp_end;
 	uint64_t	hp_batches, hp_inexact;
 	/* doc-sharded mode (N4): this index is shard `shard` of `n_shards` (0 = whole) */
 	unsigned	shard, n_shards;
@@ -195,6 +195,9 @@ typedef struct {
 	size_t		n;
 	bool		error;
 	char *		errmsg;
+	/* one block for everything the front half of a query allocates */
+	char *		arena;
+	size_t		arena_used, arena_cap;
 } qparse_t;
 
 int	nxs_query_lex(const char *query, int *kinds, size_t cap);
@@ -218,10 +221,13 @@ typedef struct qprep {
 	bool		wide;		/* does not fit nxsgpu_query_t: wplan is its plan */
 	nxsgpu_query_t	plan;
 	nxsgpu_wide_query_t wplan;	/* arrays owned by this object */
+	char **		heap_vals;	/* token values a filter grew beyond the arena's reserve */
+	size_t		n_heap_vals;
 } qprep_t;
 
 void	nxs_query_prepare(const nxs_index_t *, const char *query, qprep_t *out);
 int	nxs_query_compile(qprep_t *);	/* after term ids are final */
 void	nxs_query_release(qprep_t *);
+void	nxs_query_release_scratch(qprep_t *);	/* parse + token list; keeps errors and plans */
 
 #endif

@@ -189,6 +189,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 }
 
+struct worklist_t;
+
 struct nxsgpu_index {
 	int		device;
 	gpu_cfg_t	cfg;
@@ -222,6 +224,8 @@ struct nxsgpu_index {
 		uint32_t	n_slots, k, world;
 		size_t		rec_bytes, block_bytes;
 		uint32_t *	h_ovf;		/* overflow flags coming back (inside h_stage) */
+		worklist_t *	wl;		/* the slot's work list: its vectors keep their capacity
+						 * (several MB a batch: no mmap / page-fault churn) */
 	}		slot[2];
 	uint64_t	slot_seq;
 
@@ -4295,6 +4299,8 @@ carve(uint8_t *&p, size_t n)
 	return r;
 }
 
+static void delete_worklist(worklist_t *);
+
 extern "C" void
 nxsgpu_index_destroy(nxsgpu_index_t *ix)
 {
@@ -4337,6 +4343,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 		if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
 		if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
 		if (sl.ev_res) (void)hipEventDestroy(sl.ev_res);
+		delete_worklist(sl.wl);
 		(void)hipFree(sl.d_blocks);
 		if (sl.h_blocks) {
 			(void)hipHostFree(sl.h_blocks);
@@ -5025,6 +5032,12 @@ struct worklist_t {
 	std::vector<uint32_t>	qorder;		/* queries in launch order; launch_t::q_first/q_count index it */
 	uint32_t		n_segs;
 };
+
+static void
+delete_worklist(worklist_t *wl)
+{
+	delete wl;
+}
 
 static uint32_t
 nt_bucket(uint32_t nt)
@@ -6197,7 +6210,6 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 {
 	const uint32_t seg_cap = ix->cfg.seg_cap;
 	nxsgpu_index::dev_slot_t *sl = NULL;
-	worklist_t wl;
 	uint64_t total_post = 0;
 	const bool gather = o.records && o.gather && ix->comm;
 	const uint32_t world = gather ? (uint32_t)nxsgpu_comm_world(ix->comm) : 1u;
@@ -6225,6 +6237,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		set_error("two batches are already in flight");
 		return -1;
 	}
+	if (!sl->wl) {
+		sl->wl = new worklist_t();
+	}
+	worklist_t &wl = *sl->wl;
 	sl->nq = nq;
 	sl->postings = 0;
 	sl->records = o.records;

@@ -38,6 +38,7 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <time.h>
 #include <type_traits>
 
 #include <dlfcn.h>
@@ -142,6 +143,8 @@ struct gpu_cfg_t {
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
 	uint64_t	drop_workmul;	/* NXS_GPU_DROP_WORKMUL: range count multiplier of that class */
 	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
+	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */
+	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
 };
 
 static void
@@ -187,6 +190,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 1, 1, 64);
 	c.drop_prio = !on("NXS_GPU_DROP_NOPRIO");
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
+	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
+	c.down_inline = on("NXS_GPU_DOWN_INLINE");
 }
 
 struct worklist_t;
@@ -220,6 +225,7 @@ struct nxsgpu_index {
 		uint8_t *	d_blocks;	/* device: world blocks (own block first when world == 1) */
 		size_t		d_blocks_len;
 		uint8_t *	h_blocks;	/* pinned: world blocks */
+		uint8_t *	h_blocks_dev;	/* the same memory as the device sees it (zero-copy results) */
 		size_t		h_blocks_len;
 		uint32_t	n_slots, k, world;
 		size_t		rec_bytes, block_bytes;
@@ -4524,6 +4530,8 @@ fail:
 	return rc;
 }
 
+static void warm_streams(nxsgpu_index_t *);
+
 extern "C" nxsgpu_index_t *
 nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 {
@@ -4669,6 +4677,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		HIP_TRY(hipMemcpy(ix->d_bk_bytes, src->bk_bytes, src->bk_bytes_len, hipMemcpyHostToDevice));
 	}
 
+	warm_streams(ix);
 done_partial:
 	(void)hipFree(d_keys_in);
 	(void)hipFree(d_keys);
@@ -6241,6 +6250,13 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		sl->wl = new worklist_t();
 	}
 	worklist_t &wl = *sl->wl;
+	auto now_us = []() -> double {
+		struct timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+	};
+	const double tb0 = now_us();
+	double tb1 = 0, tb2 = 0, tb3 = 0, tc[6] = { 0, 0, 0, 0, 0, 0 };
 	sl->nq = nq;
 	sl->postings = 0;
 	sl->records = o.records;
@@ -6267,7 +6283,12 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	const bool solo = nq <= 64 && !others && !gather;
 	hipStream_t s_up = solo ? ix->stream : ix->stream_up;
-	hipStream_t s_down = solo ? ix->stream : ix->stream_down;
+	/* the records come down on their own stream only when there is a collective
+	 * to run beside the next batch's scans; a plain 135 KB copy rides the scan
+	 * stream (a separate stream showed sporadic 5-20 ms host stalls in the copy
+	 * submission, once or twice per process) */
+	const bool own_down = !solo && gather && !ix->cfg.down_inline;
+	hipStream_t s_down = own_down ? ix->stream_down : ix->stream;
 
 	/* record blocks: pinned host copies of all ranks' blocks; on the device the
 	 * own block is part of the uploaded workspace (one rank), or sits at its rank
@@ -6291,7 +6312,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			}
 			sl->h_blocks = NULL;
 			sl->h_blocks_len = 0;
-			if (hipHostMalloc((void **)&sl->h_blocks, need, hipHostMallocDefault) != hipSuccess) {
+			if (hipHostMalloc((void **)&sl->h_blocks, need, hipHostMallocMapped) != hipSuccess ||
+			    hipHostGetDevicePointer((void **)&sl->h_blocks_dev, sl->h_blocks, 0) != hipSuccess) {
 				set_error("hipHostMalloc(%zu) failed", need);
 				return -1;
 			}
@@ -6300,7 +6322,15 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	/* (a communicator of ONE rank still goes through the collective: the same
 	 * code path as N ranks, and what the one-GPU tests exercise) */
-	const bool block_in_ws = o.records && !gather;
+	/*
+	 * One rank, no collective: the heap replay writes the records STRAIGHT into
+	 * the pinned host block (mapped into the device's address space) -- 135 KB of
+	 * posted PCIe writes per batch instead of a copy command after the kernels
+	 * (whose submission showed sporadic 5-20 ms host stalls).  The host zeroes the
+	 * block and fills the status words itself before the launch.
+	 */
+	const bool block_in_ws = false;
+	const bool block_on_host = o.records && !gather;
 
 	/* plans straight into the pinned staging area (room for the work list:
 	 * <= target + nq ranges, see build_worklist) */
@@ -6317,6 +6347,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		return -1;
 	}
 	build_worklist(ix, h_q, nq, wl);
+	tb1 = now_us();
 	const uint64_t nseg = wl.n_segs;
 	if (nseg > seg_bound) {
 		set_error("work list larger than its bound (%llu > %zu)", (unsigned long long)nseg, seg_bound);
@@ -6356,6 +6387,11 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		if (block_in_ws) {
 			memset(h_block, 0, sl->block_bytes);
 		}
+		if (block_on_host) {
+			/* (the slot's previous batch was collected: nothing reads it any more) */
+			memset(sl->h_blocks, 0, recs_len);
+			h_status = (uint32_t *)(sl->h_blocks + recs_len);
+		}
 		if (o.status) {
 			memcpy(h_status, o.status, (size_t)o.n_slots * 4);
 		} else {
@@ -6384,16 +6420,19 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
-	if (o.records && !block_in_ws) {
+	if (block_on_host) {
+		d_myblock = sl->h_blocks_dev;
+	} else if (o.records && !block_in_ws) {
 		d_myblock = sl->d_blocks + (size_t)my_rank * sl->block_bytes;
 	}
 
 	sl->seq = ++ix->slot_seq;
+	tb2 = now_us();
 	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, s_up) != hipSuccess) {
 		set_error("query upload failed");
 		return begin_fail(ix);
 	}
-	if (o.records && !block_in_ws) {
+	if (o.records && !block_in_ws && !block_on_host) {
 		if ((recs_len && hipMemsetAsync(d_myblock, 0, recs_len, s_up) != hipSuccess) ||
 		    (o.n_slots && hipMemcpyAsync(d_myblock + recs_len, h_status, (size_t)o.n_slots * 4,
 		    hipMemcpyHostToDevice, s_up) != hipSuccess)) {
@@ -6402,6 +6441,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		}
 	}
 
+	tc[0] = now_us();
 	scan_args_t sa;
 	replay_args_t ra;
 	memset(&sa, 0, sizeof(sa));
@@ -6446,11 +6486,13 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	if (nq) {
 		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), s_up);
 	}
+	tc[1] = now_us();
 	if (!solo && (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
 	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess)) {
 		set_error("query upload failed");
 		return begin_fail(ix);
 	}
+	tc[2] = now_us();
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	if (nq) {
 		if (ix->cfg.one_replay) {
@@ -6466,6 +6508,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);
 	}
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], ix->stream);
+	tc[3] = now_us();
 	if (hipGetLastError() != hipSuccess) {
 		set_error("kernel launch failed");
 		return begin_fail(ix);
@@ -6482,7 +6525,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		 * per batch, sharded runs only) and the copy to pinned memory overlap the
 		 * next batch's scans instead of sitting in front of them.
 		 */
-		if (!solo && (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
+		if (own_down && (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
 		    hipStreamWaitEvent(s_down, sl->ev_res, 0) != hipSuccess)) {
 			set_error("event failed");
 			return begin_fail(ix);
@@ -6496,7 +6539,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 				set_error("copy failed");
 				return begin_fail(ix);
 			}
-		} else if (sl->block_bytes && hipMemcpyAsync(sl->h_blocks, d_myblock, sl->block_bytes,
+		} else if (!block_on_host && sl->block_bytes && hipMemcpyAsync(sl->h_blocks, d_myblock, sl->block_bytes,
 		    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
 			set_error("copy failed");
 			return begin_fail(ix);
@@ -6508,6 +6551,13 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	sl->postings = total_post;
 	sl->active = true;
+	if (ix->cfg.debug_timing) {
+		tb3 = now_us();
+		fprintf(stderr, "[nxsgpu begin #%llu] plan+worklist %.0f us, staging+alloc %.0f us, enqueue %.0f us "
+		    "(upload %.0f, cursors %.0f, fork %.0f, scans+replays %.0f, tail %.0f)\n",
+		    (unsigned long long)sl->seq, tb1 - tb0, tb2 - tb1, tb3 - tb2,
+		    tc[0] - tb2, tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tb3 - tc[3]);
+	}
 	return 0;
 }
 
@@ -6983,6 +7033,86 @@ nxsgpu_hbm_calibrate(nxsgpu_index_t *ix, uint64_t *bytes_out)
 	(void)hipStreamSynchronize(ix->stream);
 	(void)hipFree(d_sink);
 	return 0;
+}
+
+/*
+ * The HIP runtime creates its hardware queues lazily, the first time several
+ * of a process's streams are busy at once -- a one-time stall of ~16 ms that
+ * otherwise lands in whichever early batch first overlaps its neighbours
+ * (measured: begin #3 or #6).  Pay it at index create: every stream of the
+ * index gets a real kernel, all in flight together, twice.
+ */
+static void
+warm_streams(nxsgpu_index_t *ix)
+{
+	hipStream_t st[] = { ix->stream, ix->stream2, ix->stream3, ix->stream_up, ix->stream_down, ix->stream_fz };
+	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 512ull << 20) & ~(uint64_t)15;
+	const size_t cb = 4u << 20;
+	uint32_t *d_sink = NULL;
+	uint8_t *h_buf = NULL, *d_buf = NULL;
+
+	if (bytes < 4096 || hipMalloc((void **)&d_sink, 4) != hipSuccess) {
+		return;
+	}
+	(void)hipMemset(d_sink, 0, 4);
+	/* (the copy engines' queues are lazy too: uploads and downloads in flight
+	 * together, on the streams that carry them later) */
+	if (hipHostMalloc((void **)&h_buf, 2 * cb, hipHostMallocDefault) != hipSuccess ||
+	    hipMalloc((void **)&d_buf, 2 * cb) != hipSuccess) {
+		h_buf = NULL;
+	}
+	for (int round = 0; round < 3; round++) {
+		for (hipStream_t s : st) {
+			hipLaunchKernelGGL(k_hbm_read, dim3(1024), dim3(256), 0, s,
+			    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+		}
+		if (h_buf && d_buf) {
+			(void)hipMemcpyAsync(d_buf, h_buf, cb, hipMemcpyHostToDevice, ix->stream_up);
+			(void)hipMemcpyAsync(h_buf + cb, d_buf + cb, cb, hipMemcpyDeviceToHost, ix->stream_down);
+			(void)hipMemcpyAsync(h_buf + cb, d_buf + cb, 4096, hipMemcpyDeviceToHost, ix->stream);
+			(void)hipMemsetAsync(d_buf, 0, 4096, ix->stream_up);
+		}
+	}
+	/* ... and so are the runtime's pools of completion signals: a few thousand
+	 * event records / cross-stream waits / small copies queued without a sync in
+	 * between, the depth two batches in flight reach */
+	{
+		hipEvent_t ev[8];
+		int n_ev = 0;
+		for (; n_ev < 8; n_ev++) {
+			if (hipEventCreateWithFlags(&ev[n_ev], hipEventDisableTiming) != hipSuccess) {
+				break;
+			}
+		}
+		for (int i = 0; n_ev == 8 && i < 512; i++) {
+			hipStream_t sa = st[i % 6], sb = st[(i + 1 + i / 6) % 6];
+			(void)hipEventRecord(ev[i & 7], sa);
+			(void)hipStreamWaitEvent(sb, ev[i & 7], 0);
+			if (h_buf && d_buf) {
+				(void)hipMemcpyAsync(h_buf + cb + (size_t)(i & 63) * 4096, d_buf + cb, 4096,
+				    hipMemcpyDeviceToHost, sb);
+			}
+			if ((i & 63) == 63) {
+				hipLaunchKernelGGL(k_hbm_read, dim3(64), dim3(256), 0, sb,
+				    (const v4u_t *)ix->d_post[NXSGPU_BM25], (uint64_t)4096, d_sink);
+			}
+		}
+		for (hipStream_t s2 : st) {
+			(void)hipStreamSynchronize(s2);
+		}
+		for (int i = 0; i < n_ev; i++) {
+			(void)hipEventDestroy(ev[i]);
+		}
+	}
+	for (hipStream_t s : st) {
+		(void)hipStreamSynchronize(s);
+	}
+	(void)hipGetLastError();
+	(void)hipFree(d_sink);
+	(void)hipFree(d_buf);
+	if (h_buf) {
+		(void)hipHostFree(h_buf);
+	}
 }
 
 extern "C" double

@@ -18,4 +18,11 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_calib" -o run -- python3 tools/pmc_calib.py > "$out/${tag}_pmc_calib.json" 2> "$out/${tag}_pmc_calib.log"
 # the fuzzy path (C4) on its own: kernel stats of k_bk_level
 rocprofv3 --kernel-trace --stats -d "$out/${tag}_fuzzy_stats" -o run -- python3 bench.py --workload C4 --steps 5 --warmup 1 --cpu-seconds 0 --no-extras > "$out/${tag}_fuzzy_bench.json" 2> "$out/${tag}_fuzzy_stats.log"
+# condense on the box (the raw rocpd databases are ~10 MB each: gpurun merges at most 64 MiB back)
+mkdir -p "$out/${tag}_summary"
+python3 tools/pmc_summary.py --stats "$out/${tag}_stats" --pmc "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" "$out/${tag}_pmc_sq1" "$out/${tag}_pmc_sq2" \
+    --steps 6 --out-prefix "$out/${tag}_summary/${tag}" --command "$B" --calib "$out/${tag}_pmc_calib" --calib-json "$out/${tag}_pmc_calib.json"
+python3 tools/pmc_summary.py --stats "$out/${tag}_fuzzy_stats" --steps 6 --out-prefix "$out/${tag}_summary/${tag}_fuzzy" \
+    --command "python3 bench.py --workload C4 --steps 5 --warmup 1 --cpu-seconds 0 --no-extras"
+rm -rf "$out/${tag}_stats" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" "$out/${tag}_pmc_sq1" "$out/${tag}_pmc_sq2" "$out/${tag}_pmc_calib" "$out/${tag}_fuzzy_stats"
 tail -c 1500 "$out/${tag}_bench.json"

@@ -664,6 +664,8 @@ struct scan_args_t {
 	uint32_t *		overflow;	/* [Q] */
 	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
 	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class) */
+	uint32_t *		cold_state;	/* [segments][16]: what k_cold hands to k_scanm<.., DROP> */
+	float *			cold_top;	/* [segments][64]: its running top-k scores */
 	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
 						 * 0xffffffff = the doc does not hold the term */
 	uint64_t		dense_stride;
@@ -2135,6 +2137,13 @@ k_scanm(const scan_args_t A)
 	/* DROP: the dense tokens are never streamed; their impacts come from the
 	 * terms' columns (scan_args_t::dense_col) */
 	const uint32_t dmask = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask) : 0u;
+	/* DROP: the range's cold phase (k_cold) stopped at doc cs_cur: only docs below
+	 * it are left, and only for the sparse terms */
+	const uint32_t *cs = A.cold_state + seg * 16;
+	const uint32_t cs_left = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cs[0]) : 0u;	/* 0: range used up */
+	const uint32_t cs_nout = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cs[1]) : 0u;
+	const float cs_thr = DROP ? __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)cs[2])) : 0.0f;
+	const bool cs_ovf = DROP && __builtin_amdgcn_readfirstlane((int)cs[3]) != 0;
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		pt[t] = A.post;
@@ -2155,8 +2164,12 @@ k_scanm(const scan_args_t A)
 			hi[t] = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
 			tmx[t] = Q->tmax[t];
 		}
-		if (DROP && ((dmask >> t) & 1)) {
-			hi[t] = lo[t];		/* no postings as far as the windows are concerned */
+		if (DROP) {
+			if (((dmask >> t) & 1) || cs_left == 0) {
+				hi[t] = lo[t];		/* no postings as far as the windows are concerned */
+			} else if (t < (int)nt) {
+				hi[t] = min(hi[t], (int32_t)__builtin_amdgcn_readfirstlane((int)cs[4 + t]));
+			}
 		}
 		if (hi[t] > lo[t]) {
 			ab[t] = ((hi[t] - 1) >> 6) << 6;
@@ -2182,12 +2195,12 @@ k_scanm(const scan_args_t A)
 		}
 	});
 
-	float top = -INFINITY;
+	float top = DROP ? A.cold_top[seg * 64 + lane] : -INFINITY;
 	const float hint = range_hint(A, qm, g);	/* 0 = nothing published yet */
-	float thr = hint;				/* scores are > 0: 0 passes everything */
+	float thr = DROP ? fmaxf(hint, cs_thr) : hint;	/* scores are > 0: 0 passes everything */
 	const uint32_t kidx = A.k - 1;			/* 1 <= k <= 64 (host) */
-	uint32_t n_out = 0;
-	bool ovf = false;
+	uint32_t n_out = cs_nout;
+	bool ovf = cs_ovf;
 	const uint64_t out_base = seg * A.seg_cap;
 
 	/*
@@ -2446,139 +2459,11 @@ k_scanm(const scan_args_t A)
 	uint32_t tw = thr_q >= 0 ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
 
 	if constexpr (DROP) {
-		/*
-		 * Cold phase: while thr < U a doc that holds dense terms only may still be
-		 * a candidate, so EVERY doc of the range counts.  64 consecutive docs per
-		 * step, one per lane: the dense impacts come from the columns (one load
-		 * per dense term), the sparse terms' postings of the step -- a handful --
-		 * from their windows, summed in token order like everywhere else.  It
-		 * ends for good (thr never falls) as soon as k docs scoring >= U have
-		 * been seen here or a higher range has published such a threshold;
-		 * then the mask path takes over on the sparse terms alone.
-		 */
-		const uint32_t d_bot = min((uint64_t)g * qm.group_docs, A.n_docs);
-		const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
-		    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
-		int32_t cur = (int32_t)d_top - 1;
-		uint32_t cold = (dmask && !(thr >= U && thr > 0.0f)) ? 1u : 0u;
-		uint32_t steps = 0;
-		cold = rfl32(cold);
-		/* CB blocks of 64 docs per round: their column loads -- the round's latency
-		 * -- are all issued before the first block is looked at */
-		constexpr int CB = 4;
-		while (cold && cur >= (int32_t)d_bot && !ovf) {
-			cur = (int32_t)rfl32((uint32_t)cur);
-			n_out = rfl32(n_out);
-			steps = rfl32(steps);
-			uint32_t xd[CB][NT];
-#pragma unroll
-			for (int cb = 0; cb < CB; cb++) {
-				const int32_t bcur = cur - cb * WAVE;
-				const uint32_t bbase = (uint32_t)max(bcur - (WAVE - 1), (int32_t)d_bot);
-				const uint32_t bdoc = bbase + lane;
-				const bool binr = bcur >= (int32_t)d_bot && bdoc <= (uint32_t)max(bcur, 0);
-				static_for<NT>([&](auto tc) {
-					constexpr int t = decltype(tc)::value;
-					xd[cb][t] = 0xffffffffu;
-					if ((dmask >> t) & 1) {
-						const uint64_t cbase = (uint64_t)__builtin_amdgcn_readfirstlane((int)Q->drop_col[t]) * A.dense_stride;
-						xd[cb][t] = A.dense_col[cbase + (binr ? bdoc : d_bot)];
-					}
-				});
-			}
-#pragma unroll
-			for (int cb = 0; cb < CB; cb++) {
-				if (cur < (int32_t)d_bot) {
-					break;
-				}
-				const uint32_t base = (uint32_t)max(cur - (WAVE - 1), (int32_t)d_bot);
-				const uint32_t doc = base + lane;
-				const bool inr = doc <= (uint32_t)cur;
-				float acc = 0.0f;
-				uint32_t pm = 0;
-				static_for<NT>([&](auto tc) {
-					constexpr int t = decltype(tc)::value;
-					if ((dmask >> t) & 1) {
-						if (inr && xd[cb][t] != 0xffffffffu) {
-							acc += __uint_as_float(xd[cb][t]);
-							pm |= 1u << t;
-						}
-					} else if (hi[t] > lo[t]) {
-						/* the term's unconsumed postings inside the block (set A, and
-						 * what a shift brings up while the block lasts) */
-						for (int guard = 0; guard < 4; guard++) {
-							uint64_t in = rfl64(vmA[t] & ballot64(Ad[t] >= base));
-							vmA[t] ^= in;
-							while (in) {
-								const int j = __builtin_ctzll(in);
-								in &= in - 1;
-								const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)Ad[t], j);
-								const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-								    __builtin_bit_cast(int, Ai[t]), j));
-								if (doc == pd) {
-									acc += pi;
-									pm |= 1u << t;
-								}
-							}
-							if (!(vmA[t] == 0 && ab[t] > lo[t])) {
-								break;
-							}
-							shift(tc);
-						}
-					}
-				});
-				bool match = inr && pm != 0;
-				if (GEN) {
-					match = match && ((s_truth[pm >> 5] >> (pm & 31)) & 1);
-				}
-				const bool cand = match && acc > thr;
-				uint64_t bal = ballot64(cand);
-				if (bal) {
-					const uint32_t ne = __popcll(bal);
-					const bool room = n_out + ne <= A.seg_cap;
-					if (!room) {
-						ovf = true;
-					}
-					if (room && cand) {
-						/* lanes ascend with the doc: higher lanes are emitted first */
-						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
-						const uint64_t o = out_base + n_out + __popcll(above);
-						A.cand_doc[o] = doc;
-						A.cand_sc[o] = acc;
-					}
-					n_out += ne;
-					while (bal) {
-						const int L = 63 - __builtin_clzll(bal);
-						const float v = __shfl(acc, L);
-						const bool ins = v > thr;
-						const uint32_t pos = __popcll(ballot64(top >= v));
-						const float up = __shfl_up(top, 1);
-						const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
-						top = ins ? ntop : top;
-						thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
-						bal &= ~(1ull << L);
-					}
-				}
-				cur = (int32_t)base - 1;
-			}
-			steps++;
-			if ((steps & 3) == 0) {
-				const float h2 = range_hint(A, qm, g);	/* a higher range may have published */
-				thr = fmaxf(thr, h2);
-			}
-			cold = rfl32(thr >= U && thr > 0.0f ? 0u : 1u);
-		}
+		/* (the cold phase -- while thr < U -- ran in k_cold; its threshold, top-k
+		 * scores, output count and the sparse terms' cursors were taken over above) */
 		if (dmask) {
-			/* warm from here on (or the range is used up) */
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				if (!((dmask >> t) & 1) && hi[t] > lo[t]) {
-					refresh_pdoc(tc);
-				}
-			});
 			thr_q = thr_quant(thr) - (int32_t)qU;
 			tw = thr_q >= (int32_t)q1max ? (uint32_t)MT_W_HINTED : (uint32_t)MT_W0;
-			range_publish(A, seg, __shfl(top, kidx));	/* lower ranges start warm */
 		}
 	}
 
@@ -2741,6 +2626,232 @@ k_scanm(const scan_args_t A)
 		if (ovf) {
 			A.overflow[q] = 1;
 		}
+	}
+}
+
+/*
+ * k_cold: the cold phase of the sparse + dense OR class (k_scanm<.., DROP>).
+ * While the candidate threshold is below U -- what the dense terms can add to a
+ * score -- a doc that holds dense terms only may still be emitted, so EVERY doc of
+ * the range counts: the wavefront walks it from the top, 64 consecutive docs per
+ * block, one per lane.  Dense impacts come from the terms' columns (one load per
+ * dense term and block, four blocks' loads in flight), the sparse terms' few
+ * postings of a block from a plain 64-posting window per term, summed in token
+ * order like everywhere else (results.c:134-136).  It ends for good (thr never
+ * falls) when k docs scoring >= U have been seen here or a higher range has
+ * published such a threshold; the wavefront then publishes its own, and hands
+ * threshold, top-k scores, output count and the sparse cursors to
+ * k_scanm<.., DROP> (cold_state / cold_top), which scans what is left of the
+ * range on the sparse terms alone.  A kernel of its own because it is light
+ * (full occupancy) while the mask path is register-bound: fused into k_scanm it
+ * cost that kernel three quarters of its occupancy.
+ */
+template <int NT, bool GEN>
+__global__ void __launch_bounds__(WAVE)
+k_cold(const scan_args_t A)
+{
+	__shared__ uint32_t s_truth[GEN ? 8 : 1];
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint32_t dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask);
+	uint32_t *cs = A.cold_state + seg * 16;
+
+	if (GEN && lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	WAVE_SYNC();
+
+	auto rfl32 = [](uint32_t v) -> uint32_t {
+		return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+	};
+	auto rfl64 = [&](uint64_t v) -> uint64_t {
+		return (uint64_t)rfl32((uint32_t)v) | ((uint64_t)rfl32((uint32_t)(v >> 32)) << 32);
+	};
+
+	/* sparse terms: a window of 64 postings [wb, wb + 64) clipped to [lo, hi);
+	 * vm = lanes not consumed yet (always a prefix: docs are taken from the top) */
+	const posting_t *pt[NT];
+	int32_t lo[NT], wb[NT];
+	uint64_t vm[NT];
+	uint32_t wd[NT];
+	float wi[NT], U = 0.0f;
+	uint64_t colb[NT];
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pt[t] = A.post;
+		lo[t] = wb[t] = 0;
+		vm[t] = 0;
+		wd[t] = 0;
+		wi[t] = 0.0f;
+		colb[t] = 0;
+		if (t < (int)nt) {
+			if ((dmask >> t) & 1) {
+				U += Q->tmax[t];		/* token order, f32 */
+				colb[t] = (uint64_t)rfl32(Q->drop_col[t]) * A.dense_stride;
+			} else {
+				const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+				const int32_t l = (int32_t)A.cursors[cb], h = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+				pt[t] = A.post + Q->pbeg[t];
+				lo[t] = l;
+				if (h > l) {
+					wb[t] = max(h - WAVE, l);
+					const int32_t i = wb[t] + (int32_t)lane;
+					const posting_t p = pt[t][min(i, h - 1)];
+					wd[t] = p.doc;
+					wi[t] = p.imp;
+					const int32_t n = h - wb[t];
+					vm[t] = n >= WAVE ? ~0ull : ((1ull << n) - 1);
+				} else {
+					wb[t] = l;
+				}
+			}
+		}
+	});
+
+	float top = -INFINITY;
+	const float hint = range_hint(A, qm, g);
+	float thr = hint;
+	const uint32_t kidx = A.k - 1;
+	uint32_t n_out = 0, ovf = 0;
+	const uint64_t out_base = seg * A.seg_cap;
+	const uint32_t d_bot = (uint32_t)min((uint64_t)g * qm.group_docs, A.n_docs);
+	const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
+	    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
+	int32_t cur = (int32_t)d_top - 1;
+	uint32_t cold = rfl32(thr >= U && thr > 0.0f ? 0u : 1u), rounds = 0;
+	constexpr int CB = 4;
+
+	while (cold && cur >= (int32_t)d_bot && !ovf) {
+		cur = (int32_t)rfl32((uint32_t)cur);
+		n_out = rfl32(n_out);
+		rounds = rfl32(rounds);
+		ovf = rfl32(ovf);
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			wb[t] = (int32_t)rfl32((uint32_t)wb[t]);
+			vm[t] = rfl64(vm[t]);
+		}
+		uint32_t xd[CB][NT];
+#pragma unroll
+		for (int cb = 0; cb < CB; cb++) {
+			const int32_t bcur = cur - cb * WAVE;
+			const uint32_t bbase = (uint32_t)max(bcur - (WAVE - 1), (int32_t)d_bot);
+			const uint32_t bdoc = bbase + lane;
+			const bool binr = bcur >= (int32_t)d_bot && bdoc <= (uint32_t)max(bcur, 0);
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				xd[cb][t] = 0xffffffffu;
+				if ((dmask >> t) & 1) {
+					xd[cb][t] = A.dense_col[colb[t] + (binr ? bdoc : d_bot)];
+				}
+			});
+		}
+#pragma unroll
+		for (int cb = 0; cb < CB; cb++) {
+			if (cur < (int32_t)d_bot || ovf) {
+				break;
+			}
+			const uint32_t base = (uint32_t)max(cur - (WAVE - 1), (int32_t)d_bot);
+			const uint32_t doc = base + lane;
+			const bool inr = doc <= (uint32_t)cur;
+			float acc = 0.0f;
+			uint32_t pm = 0;
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				if ((dmask >> t) & 1) {
+					if (inr && xd[cb][t] != 0xffffffffu) {
+						acc += __uint_as_float(xd[cb][t]);
+						pm |= 1u << t;
+					}
+				} else if (t < (int)nt) {
+					for (int guard = 0; guard < 4; guard++) {
+						uint64_t in = rfl64(vm[t] & ballot64(wd[t] >= base));
+						vm[t] ^= in;
+						while (in) {
+							const int j = __builtin_ctzll(in);
+							in &= in - 1;
+							const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)wd[t], j);
+							const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+							    __builtin_bit_cast(int, wi[t]), j));
+							if (doc == pd) {
+								acc += pi;
+								pm |= 1u << t;
+							}
+						}
+						if (!(vm[t] == 0 && wb[t] > lo[t])) {
+							break;
+						}
+						/* the window below */
+						const int32_t nwb = max(wb[t] - WAVE, lo[t]);
+						const int32_t n = wb[t] - nwb;
+						const posting_t p = pt[t][min(nwb + (int32_t)lane, wb[t] - 1)];
+						wd[t] = p.doc;
+						wi[t] = p.imp;
+						vm[t] = n >= WAVE ? ~0ull : ((1ull << n) - 1);
+						wb[t] = nwb;
+					}
+				}
+			});
+			bool match = inr && pm != 0;
+			if (GEN) {
+				match = match && ((s_truth[pm >> 5] >> (pm & 31)) & 1);
+			}
+			const bool cand = match && acc > thr;
+			uint64_t bal = ballot64(cand);
+			if (bal) {
+				const uint32_t ne = __popcll(bal);
+				const bool room = n_out + ne <= A.seg_cap;
+				if (!room) {
+					ovf = 1;
+				}
+				if (room && cand) {
+					/* lanes ascend with the doc: higher lanes are emitted first */
+					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+					const uint64_t o = out_base + n_out + __popcll(above);
+					A.cand_doc[o] = doc;
+					A.cand_sc[o] = acc;
+				}
+				n_out += ne;
+				while (bal) {
+					const int L = 63 - __builtin_clzll(bal);
+					const float v = __shfl(acc, L);
+					const bool ins = v > thr;
+					const uint32_t pos = __popcll(ballot64(top >= v));
+					const float up = __shfl_up(top, 1);
+					const float ntop = (lane < pos) ? top : (lane == pos ? v : up);
+					top = ins ? ntop : top;
+					thr = ins ? fmaxf(__shfl(top, kidx), hint) : thr;
+					bal &= ~(1ull << L);
+				}
+			}
+			cur = (int32_t)base - 1;
+		}
+		rounds++;
+		if ((rounds & 3) == 0) {
+			thr = fmaxf(thr, range_hint(A, qm, g));		/* a higher range may have published */
+		}
+		cold = rfl32(thr >= U && thr > 0.0f ? 0u : 1u);
+	}
+
+	/* lower ranges start warm */
+	range_publish(A, seg, __shfl(top, kidx));
+	A.cold_top[seg * 64 + lane] = top;
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		if (lane == 0 && t < (int)nt && !((dmask >> t) & 1)) {
+			cs[4 + t] = (uint32_t)(wb[t] + (int32_t)__popcll(vm[t]));	/* the term's postings still to scan end here */
+		}
+	});
+	if (lane == 0) {
+		cs[0] = cur >= (int32_t)d_bot ? (uint32_t)cur + 1 : 0u;	/* docs below this are left (0: none) */
+		cs[1] = n_out;
+		cs[2] = __float_as_uint(thr);
+		cs[3] = ovf;
 	}
 }
 
@@ -5284,6 +5395,30 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
 	}
 }
 
+/* the sparse + dense OR class: its cold phase (k_cold), then the mask path on
+ * the sparse terms (k_scanm<.., DROP>), stream-ordered */
+static void
+launch_drop_class(const dim3 grid, const scan_args_t &a, uint32_t nt_bucket, hipStream_t st)
+{
+	const dim3 block(WAVE);
+
+	switch (nt_bucket) {
+	case 2:
+	case 3:
+		hipLaunchKernelGGL((k_cold<3, false>), grid, block, 0, st, a);
+		hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, st, a);
+		break;
+	case 5:
+		hipLaunchKernelGGL((k_cold<5, false>), grid, block, 0, st, a);
+		hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, st, a);
+		break;
+	default:
+		hipLaunchKernelGGL((k_cold<8, false>), grid, block, 0, st, a);
+		hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, st, a);
+		break;
+	}
+}
+
 /*
  * One scan launch per query class.  With `ra` (top-k filter pass) the heap
  * replay of a class is queued on the second stream as soon as the class's
@@ -5327,12 +5462,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 				forked3 = true;
 			}
 			a.flags = ix->cfg.drop_prio ? 1u : 0u;
-			switch (l.nt_bucket) {
-			case 2:
-			case 3: hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, ix->stream3, a); break;
-			case 5: hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, ix->stream3, a); break;
-			default: hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, ix->stream3, a); break;
-			}
+			launch_drop_class(grid, a, l.nt_bucket, ix->stream3);
 			hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream3, r);
 			continue;
 		}
@@ -5398,12 +5528,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			/* sparse + dense pure OR: top-k pass with the dense lists dropped;
 			 * the exact passes take the accumulator tiles */
 			if (MODE == MODE_TOPK && a.k >= 1 && a.k <= WAVE) {
-				switch (l.nt_bucket) {
-				case 2:
-				case 3: hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, ix->stream, a); break;
-				case 5: hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, ix->stream, a); break;
-				default: hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, ix->stream, a); break;
-				}
+				launch_drop_class(grid, a, l.nt_bucket, ix->stream);
 			} else {
 				switch (l.nt_bucket) {
 				case 2: hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, ix->stream, a); break;
@@ -5644,7 +5769,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		size_t need = 8192 + nq * 4 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
 		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
-		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256;
+		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256
+		    + nseg * (16 * 4 + 64 * 4) + 1024;
 		if (!ensure_ws(ix, need)) {
 			return -1;
 		}
@@ -5675,6 +5801,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
+	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
+	float *d_cold_top = carve<float>(p, nseg * 64);
 
 	if (!ensure_pin(ix, up_len + down_len + 512)) {
 		return -1;
@@ -5709,6 +5837,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.overflow = d_ovf;
 	sa.cursors = d_cursors;
 	sa.pub = d_pub;
+	sa.cold_state = d_cold_state;
+	sa.cold_top = d_cold_top;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {
@@ -6402,7 +6532,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	/* device workspace: the uploaded block first (same carve sequence => same
 	 * offsets), then what only the kernels touch */
 	const size_t ws_need = 32768 + up_len + nseg * 4
-	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8;
+	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8 + nseg * (16 * 4 + 64 * 4);
 	if (slot_ensure(*sl, ws_need, 0) != 0) {
 		return -1;
 	}
@@ -6420,6 +6550,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
 	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
+	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
+	float *d_cold_top = carve<float>(p, nseg * 64);
 	if (block_on_host) {
 		d_myblock = sl->h_blocks_dev;
 	} else if (o.records && !block_in_ws) {
@@ -6460,6 +6592,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.overflow = d_ovf;
 	sa.cursors = d_cursors;
 	sa.pub = d_pub;
+	sa.cold_state = d_cold_state;
+	sa.cold_top = d_cold_top;
 	memset(&ra, 0, sizeof(ra));
 	ra.qmeta = d_qmeta;
 	ra.seg_cap = seg_cap;

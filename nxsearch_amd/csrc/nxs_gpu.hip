@@ -187,7 +187,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
 	c.use_drop = !on("NXS_GPU_NODROP");
 	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
-	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 1, 1, 64);
+	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 2, 1, 64);
 	c.drop_prio = !on("NXS_GPU_DROP_NOPRIO");
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");

@@ -139,6 +139,8 @@ struct gpu_cfg_t {
 	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */
 	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
+	bool		fuzzy_bfs;	/* NXS_GPU_FUZZY_BFS: level-by-level frontier search only */
+	uint64_t	fuzzy_cand;	/* NXS_GPU_FUZZY_CAND: survivor queue of the match-first search (items) */
 	bool		use_drop;	/* !NXS_GPU_NODROP: dense terms leave sparse OR scans (k_scanm<.., DROP>) */
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
 	uint64_t	drop_workmul;	/* NXS_GPU_DROP_WORKMUL: range count multiplier of that class */
@@ -185,6 +187,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.one_replay = on("NXS_GPU_ONEREPLAY");
 	c.fuzzy_safe = on("NXS_GPU_FUZZY_SAFE");
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
+	c.fuzzy_bfs = on("NXS_GPU_FUZZY_BFS");
+	c.fuzzy_cand = u64("NXS_GPU_FUZZY_CAND", 32ull << 20, 1024, 1ull << 30);
 	c.use_drop = !on("NXS_GPU_NODROP");
 	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
 	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 2, 1, 64);
@@ -267,6 +271,15 @@ struct nxsgpu_index {
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;
 	uint32_t	n_bk, bk_depth;
+	/* match-first fuzzy search (k_fz_filter ...): per node the byte-set signature
+	 * and length of its term, its parent and the slot it hangs in (k_bk_aux) */
+	bool		fz_split;	/* nxsgpu_fuzzy is working on one half of a batch it split */
+	uint32_t *	d_bk_parent;	/* [n_bk] */
+	uint8_t *	d_bk_slot;	/* [n_bk] */
+	uint32_t *	d_fz_node;	/* [n_fz] the nodes that can win, sorted by term length */
+	uint32_t *	d_fz_sig;	/* [n_fz] byte-set signature */
+	uint8_t *	d_fz_len;	/* [n_fz] */
+	uint32_t	n_fz;
 
 	/* reusable query workspaces */
 	void *		ws;
@@ -4335,10 +4348,20 @@ k_bk_seed(fz_item_t *items, uint32_t *count0, uint32_t n_tok, uint32_t *best,
 }
 
 __global__ void
-k_bk_peq(const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok, uint64_t *peq)
+k_bk_peq(const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok, uint64_t *peq, uint2 *tokf,
+    const uint32_t *tok_rank)
 {
 	const uint32_t tok = blockIdx.x;
 	const uint32_t off = tok_off[tok], m = tok_off[tok + 1] - off;
+	if (tokf && threadIdx.x == 0) {
+		/* what k_fz_filter compares: the token's byte set, at the token's place in
+		 * the length-sorted order */
+		uint32_t sg = 0;
+		for (uint32_t j = 0; j < m; j++) {
+			sg |= 1u << (tok_bytes[off + j] & 31);
+		}
+		tokf[tok_rank[tok]] = make_uint2(sg, tok);
+	}
 	for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
 		uint64_t bits = 0;
 		if (m <= NXS_MYERS_MAXPAT) {
@@ -4362,9 +4385,374 @@ k_bk_finish(const nxsgpu_bknode_t *bk, const uint32_t *best, uint32_t n_tok, uin
 	}
 }
 
+/* ---- match-first fuzzy search ---------------------------------------- */
+/*
+ * The level-by-level search above spends its time on the frontier: the winner
+ * sits 9-12 levels deep and everything above it has to be expanded (65 M pairs
+ * for 1024 tokens over a 1M-term tree).  But the winner has a closed form:
+ *
+ *   the node of LOWEST BFS rank among those that (1) are a match -- distance
+ *   <= 2, on-disk total > 0 -- and (2) bktree_search reaches: at EVERY ancestor
+ *   a the slot of the path's child lies in [max(d(q,a)-2, 0), min(d(q,a)+2, 63))
+ *   (bktree.c:150-156,260-264; Q8: the range is half-open, so a match is not
+ *   always reached).
+ *
+ * (1) needs no tree: all (token, term) pairs are screened with a necessary
+ * condition -- |len difference| <= 2 and, on the sets of bytes the strings
+ * contain (hashed to 64 bits), at most 2 bytes on either side that the other
+ * string lacks: an edit removes at most one such byte per side -- 0.03-0.6 % of
+ * the pairs survive on the synthetic vocabulary and take the exact bit-vector
+ * distance.  (2) walks the few real matches up to the root.  The three steps
+ * are three launches over flat queues; their result is the same min-rank node
+ * (tests and bench.py compare against the level-by-level search with and
+ * without pruning, and against the oracle).
+ */
+#define	FZ_NOPARENT	0xffffffffu
+#define	FZF_BUF		192		/* survivors a wavefront stages in LDS */
+#define	FZ_MAXLEN	(NXS_MYERS_MAXPAT + 2)	/* longest term that can be within 2 of a token */
+#define	FZ_NQ		64		/* survivor sub-queues: a single counter word takes ~88 M atomics/s */
+#define	FZ_CSTRIDE	16		/* their counters, one per 64 bytes */
+
+/* per node: its parent and the slot it hangs in */
+__global__ void __launch_bounds__(256)
+k_bk_aux(const nxsgpu_bknode_t *bk, uint32_t n, uint32_t *parent, uint8_t *slot)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	if (i == 0) {
+		parent[0] = FZ_NOPARENT;
+		slot[0] = 0;
+	}
+	uint64_t bm = bk[i].bitmap;
+	uint32_t c = bk[i].first_child;
+	while (bm) {
+		const int sl = __ffsll((long long)bm) - 1;
+		bm &= bm - 1;
+		parent[c] = i;
+		slot[c] = (uint8_t)sl;
+		c++;
+	}
+}
+
+/* per candidate (the nodes that can win, sorted by term length on the host): the
+ * set of bytes its term contains, hashed to 32 bits, and the length */
+__global__ void __launch_bounds__(256)
+k_fz_sigs(const nxsgpu_bknode_t *bk, const uint8_t *bytes, const uint32_t *cand_node, uint32_t n_c,
+    uint32_t *sig, uint8_t *len8)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_c) {
+		return;
+	}
+	const nxsgpu_bknode_t nd = bk[cand_node[i]];
+	const uint8_t *str = bytes + nd.str_off;
+	uint32_t sg = 0;
+	for (uint32_t j = 0; j < nd.str_len; j++) {
+		sg |= 1u << (str[j] & 31);
+	}
+	sig[i] = sg;
+	len8[i] = (uint8_t)nd.str_len;
+}
+
+/*
+ * Screen.  lane = one candidate node (sorted by length: a workgroup's 256 terms
+ * span lengths [Lmin, Lmax]), loop = the tokens of length Lmin-2 .. Lmax+2
+ * (tokens sorted by length too; their features are wave-uniform and come
+ * through the scalar unit, four tokens per round).  grid.y slices the token
+ * range.  A pair that passes wrongly (|length difference| = 3 across a length
+ * boundary of the workgroup, hash collisions) is dropped by the exact distance.
+ */
+__global__ void __launch_bounds__(256)
+k_fz_filter(const uint32_t *__restrict__ sig, const uint32_t *__restrict__ cand_node,
+    const uint8_t *__restrict__ len8, uint32_t n_c, const uint2 *__restrict__ tokf,
+    const uint32_t *__restrict__ tok_len_off, fz_item_t *out, uint32_t *out_count, uint32_t qcap,
+    uint32_t *overflow)
+{
+	__shared__ fz_item_t s_buf[4][FZF_BUF];
+	/* this workgroup's sub-queue: [sq * qcap, (sq + 1) * qcap) */
+	const uint32_t sq = (blockIdx.x + 5 * blockIdx.y) & (FZ_NQ - 1);
+	fz_item_t *const sq_out = out + (uint64_t)sq * qcap;
+	uint32_t *const sq_count = out_count + sq * FZ_CSTRIDE;
+	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const uint32_t first = blockIdx.x * 256, i = first + threadIdx.x;
+	const bool valid = i < n_c;
+	const uint32_t ts = valid ? sig[i] : 0, nts = ~ts;
+	const uint32_t node = valid ? cand_node[i] : 0;
+	const uint64_t vmask = ballot64(valid);
+	const uint32_t lmin = len8[first], lmax = len8[min(first + 255, n_c - 1)];
+	const uint32_t ta = tok_len_off[lmin > 2 ? lmin - 2 : 0];
+	const uint32_t tb = tok_len_off[min(lmax + 2, (uint32_t)NXS_MYERS_MAXPAT) + 1];
+	const uint32_t per = (tb - ta + gridDim.y - 1) / gridDim.y;
+	const uint32_t t0 = ta + blockIdx.y * per, t1 = min(tb, t0 + per);
+	uint32_t nb = 0;
+
+	auto flush = [&]() {
+		uint32_t base = 0;
+		if (lane == 0) {
+			base = atomicAdd(sq_count, nb);
+		}
+		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+		WAVE_SYNC();
+		for (uint32_t e = lane; e < nb; e += WAVE) {
+			if (base + e < qcap) {
+				sq_out[base + e] = s_buf[wid][e];
+			} else {
+				*overflow = 1;
+			}
+		}
+		WAVE_SYNC();
+		nb = 0;
+	};
+	auto check = [&](const uint2 f, bool in_range) {
+		/* bytes only the term has / only the token has: an edit removes at
+		 * most one of each */
+		const uint32_t a = __popc(ts & ~f.x), b = __popc(nts & f.x);
+		const uint64_t m = in_range ? (ballot64(max(a, b) <= 2u) & vmask) : 0ull;
+		if (m) {
+			if (lane_of(m)) {
+				fz_item_t it;
+				it.tok = f.y;
+				it.node = node;
+				s_buf[wid][nb + lanes_below(m)] = it;
+			}
+			nb += __popcll(m);
+			if (nb > FZF_BUF - WAVE) {
+				flush();
+			}
+		}
+	};
+	for (uint32_t j = t0; j < t1; j += 4) {
+		/* (the array carries four entries of slack behind its end) */
+		const uint2 f0 = tokf[j], f1 = tokf[j + 1], f2 = tokf[j + 2], f3 = tokf[j + 3];
+		check(f0, true);
+		check(f1, j + 1 < t1);
+		check(f2, j + 2 < t1);
+		check(f3, j + 3 < t1);
+	}
+	if (nb) {
+		flush();
+	}
+}
+
+/*
+ * Exact distance of the screened pairs (grid.y = sub-queue).  A match at
+ * distance <= 1 is always reached: every node of a child's subtree is at the
+ * child's slot distance s from the ancestor a (slot-63 subtrees, which no search
+ * ever enters, are not candidates), so |d(q,a) - s| <= 1 and s lies inside
+ * [d(q,a)-2, d(q,a)+2) at every ancestor -- it lowers best[] right here.  A
+ * match at distance 2 misses exactly when some ancestor has d(q,a) = s - 2: it
+ * goes to the next queue for the walk (one returning atomic per workgroup and
+ * round, as in k_bk_level).
+ */
+__global__ void __launch_bounds__(1024)
+k_fz_dist(const fz_args_t A, const fz_item_t *cand, const uint32_t *cand_count, uint32_t qcap, fz_item_t *match,
+    uint32_t *match_count, uint32_t mcap)
+{
+	__shared__ uint32_t s_wtot[16], s_base;
+	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	const uint32_t count = min(cand_count[blockIdx.y * FZ_CSTRIDE], qcap);
+	const uint32_t nthreads = gridDim.x * blockDim.x;
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t rounds = (count + nthreads - 1) / nthreads;
+	uint32_t n_eval = 0;
+
+	cand += (uint64_t)blockIdx.y * qcap;
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t i = r * nthreads + tid;
+		fz_item_t it;
+		bool hit = false;
+
+		it.tok = it.node = 0;
+		if (i < count) {
+			it = cand[i];
+			const nxsgpu_bknode_t nd = A.bk[it.node];
+			const int d = fz_distance(A, it.tok, nd, 0);
+			n_eval++;
+			if (d <= 1) {
+				atomicMin(&A.best[it.tok], it.node);
+			} else if (d == 2) {	/* bktree.c:252-254 */
+				hit = __hip_atomic_load(&A.best[it.tok], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it.node;
+			}
+		}
+		const uint64_t m = ballot64(hit);
+		s_wtot[wid] = __popcll(m);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t sum = 0;
+			for (unsigned w = 0; w < nw; w++) {
+				const uint32_t tw = s_wtot[w];
+				s_wtot[w] = sum;
+				sum += tw;
+			}
+			s_base = sum ? atomicAdd(match_count, sum) : 0;
+		}
+		__syncthreads();
+		const uint32_t o = s_base + s_wtot[wid] + lanes_below(m);
+		__syncthreads();
+		if (hit) {
+			if (o < mcap) {
+				match[o] = it;
+			} else {
+				*A.overflow = 1;
+			}
+		}
+	}
+	if (A.evals) {
+		for (int o = 32; o; o >>= 1) {
+			n_eval += (uint32_t)__shfl_xor((int)n_eval, o);
+		}
+		if (lane == 0 && n_eval) {
+			atomicAdd(A.evals, (unsigned long long)n_eval);
+		}
+	}
+}
+
+/* does bktree_search reach the match?  Walk to the root; every ancestor's child
+ * range must hold the slot the path leaves it through. */
+__global__ void __launch_bounds__(256)
+k_fz_chain(const fz_args_t A, const uint32_t *__restrict__ parent, const uint8_t *__restrict__ slot,
+    const fz_item_t *match, const uint32_t *match_count, uint32_t mcap)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const uint32_t count = min(*match_count, mcap);
+	const uint32_t nthreads = gridDim.x * blockDim.x;
+	uint32_t n_eval = 0;
+
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += nthreads) {
+		const fz_item_t it = match[i];
+		uint32_t c = it.node;
+		bool ok = true;
+
+		for (;;) {
+			/* (a match of lower rank is known: this one cannot win -- any value
+			 * read is the rank of a reachable match) */
+			if (__hip_atomic_load(&A.best[it.tok], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it.node) {
+				ok = false;
+				break;
+			}
+			const uint32_t p = parent[c];
+			if (p == FZ_NOPARENT) {
+				break;
+			}
+			const unsigned sl = slot[c];
+			const nxsgpu_bknode_t nd = A.bk[p];
+			const int d = fz_distance(A, it.tok, nd, 0);
+			n_eval++;
+			/* bktree.c:150-156,260-264 (x86 shift semantics), as k_bk_level */
+			const unsigned min_d = d > 2 ? (unsigned)d - 2 : 0;
+			const unsigned max_d = min((unsigned)d + 2, 63u);
+			const uint64_t lo_mask = ~0ull << (min_d & 63);
+			const uint64_t hi_mask = ~0ull >> ((64 - max_d) & 63);
+			if (!(((lo_mask & hi_mask) >> sl) & 1)) {
+				ok = false;
+				break;
+			}
+			c = p;
+		}
+		if (ok) {
+			atomicMin(&A.best[it.tok], it.node);
+		}
+	}
+	if (A.evals) {
+		for (int o = 32; o; o >>= 1) {
+			n_eval += (uint32_t)__shfl_xor((int)n_eval, o);
+		}
+		if (lane == 0 && n_eval) {
+			atomicAdd(A.evals, (unsigned long long)n_eval);
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ */
 /* host side of the shim                                               */
 /* ------------------------------------------------------------------ */
+
+static void
+bk_aux_free(nxsgpu_index_t *ix)
+{
+	(void)hipFree(ix->d_bk_parent);
+	(void)hipFree(ix->d_bk_slot);
+	(void)hipFree(ix->d_fz_node);
+	(void)hipFree(ix->d_fz_sig);
+	(void)hipFree(ix->d_fz_len);
+	ix->d_bk_parent = NULL;
+	ix->d_bk_slot = NULL;
+	ix->d_fz_node = NULL;
+	ix->d_fz_sig = NULL;
+	ix->d_fz_len = NULL;
+	ix->n_fz = 0;
+}
+
+/* the match-first search's view of the tree (after d_bk / d_bk_bytes are in place) */
+static int
+bk_aux_build(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n)
+{
+	bk_aux_free(ix);
+	if (n == 0) {
+		return 0;
+	}
+	/* candidates: nodes with postings on disk whose term can be within 2 of a
+	 * token of <= 64 bytes; counting sort by length, BFS rank inside a length */
+	std::vector<uint32_t> start(FZ_MAXLEN + 2, 0), perm;
+	/* (a child in slot 63 is never visited -- the range's upper end is at most 63,
+	 * exclusive: bktree.c:150-156 -- and neither is anything below it; BFS
+	 * numbering: a parent precedes its children) */
+	std::vector<uint8_t> cut(n, 0);
+	uint32_t n_c = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		uint64_t bm = nodes[i].bitmap;
+		uint32_t c = nodes[i].first_child;
+		while (bm) {
+			const int sl = __builtin_ctzll(bm);
+			bm &= bm - 1;
+			if (c < n) {
+				cut[c] = cut[i] | (sl >= 63);
+			}
+			c++;
+		}
+	}
+	auto is_cand = [&](uint32_t i) { return (nodes[i].flags & 1) && nodes[i].str_len <= FZ_MAXLEN && !cut[i]; };
+	for (uint32_t i = 0; i < n; i++) {
+		if (is_cand(i)) {
+			start[nodes[i].str_len + 1]++;
+			n_c++;
+		}
+	}
+	for (uint32_t l = 0; l <= FZ_MAXLEN; l++) {
+		start[l + 1] += start[l];
+	}
+	perm.resize(std::max<uint32_t>(n_c, 1));
+	for (uint32_t i = 0; i < n; i++) {
+		if (is_cand(i)) {
+			perm[start[nodes[i].str_len]++] = i;
+		}
+	}
+	if (hipMalloc(&ix->d_bk_parent, (size_t)n * 4) != hipSuccess ||
+	    hipMalloc(&ix->d_bk_slot, (size_t)n + 16) != hipSuccess ||
+	    hipMalloc(&ix->d_fz_node, (size_t)std::max<uint32_t>(n_c, 1) * 4) != hipSuccess ||
+	    hipMalloc(&ix->d_fz_sig, (size_t)std::max<uint32_t>(n_c, 1) * 4) != hipSuccess ||
+	    hipMalloc(&ix->d_fz_len, (size_t)n_c + 16) != hipSuccess ||
+	    hipMemcpyAsync(ix->d_fz_node, perm.data(), (size_t)n_c * 4, hipMemcpyHostToDevice, ix->stream_fz) != hipSuccess) {
+		bk_aux_free(ix);
+		set_error("BK-tree side arrays: out of device memory");
+		return -1;
+	}
+	hipLaunchKernelGGL(k_bk_aux, dim3((n + 255) / 256), dim3(256), 0, ix->stream_fz,
+	    ix->d_bk, n, ix->d_bk_parent, ix->d_bk_slot);
+	if (n_c) {
+		hipLaunchKernelGGL(k_fz_sigs, dim3((n_c + 255) / 256), dim3(256), 0, ix->stream_fz,
+		    ix->d_bk, ix->d_bk_bytes, ix->d_fz_node, n_c, ix->d_fz_sig, ix->d_fz_len);
+	}
+	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream_fz) != hipSuccess) {
+		bk_aux_free(ix);
+		set_error("k_bk_aux failed");
+		return -1;
+	}
+	ix->n_fz = n_c;
+	return 0;
+}
 
 static bool
 ensure_ws(nxsgpu_index_t *ix, size_t need)
@@ -4438,6 +4826,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	(void)hipFree(ix->d_dense_col[1]);
 	(void)hipFree(ix->d_bk);
 	(void)hipFree(ix->d_bk_bytes);
+	bk_aux_free(ix);
 	(void)hipFree(ix->ws);
 	(void)hipFree(ix->fz);
 	if (ix->h_pin) {
@@ -4786,6 +5175,9 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		HIP_TRY(hipMalloc(&ix->d_bk_bytes, src->bk_bytes_len + 16));
 		HIP_TRY(hipMemcpy(ix->d_bk, src->bk_nodes, (size_t)src->n_bk * sizeof(nxsgpu_bknode_t), hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(ix->d_bk_bytes, src->bk_bytes, src->bk_bytes_len, hipMemcpyHostToDevice));
+		if (bk_aux_build(ix, src->bk_nodes, src->n_bk) != 0) {
+			goto fail;
+		}
 	}
 
 	warm_streams(ix);
@@ -5076,6 +5468,7 @@ nxsgpu_index_set_bk(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n
 	(void)hipStreamSynchronize(ix->stream_fz);
 	(void)hipFree(ix->d_bk);
 	(void)hipFree(ix->d_bk_bytes);
+	bk_aux_free(ix);
 	ix->d_bk = NULL;
 	ix->d_bk_bytes = NULL;
 	ix->n_bk = 0;
@@ -5088,6 +5481,9 @@ nxsgpu_index_set_bk(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n
 	    hipMemcpy(ix->d_bk, nodes, (size_t)n * sizeof(nxsgpu_bknode_t), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(ix->d_bk_bytes, bytes, bytes_len, hipMemcpyHostToDevice) != hipSuccess) {
 		set_error("BK-tree upload failed");
+		return -1;
+	}
+	if (bk_aux_build(ix, nodes, n) != 0) {
 		return -1;
 	}
 	ix->n_bk = n;
@@ -7529,6 +7925,154 @@ nxsgpu_search_wide(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_wi
 
 /* ---- fuzzy ----------------------------------------------------------- */
 
+/*
+ * Match-first search of all tokens at once (tokens of <= 64 bytes only).
+ * 0 = term_ids filled, 1 = a queue overflowed (the caller takes the
+ * level-by-level search), -1 = error.
+ */
+static int
+fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok,
+    uint32_t *term_ids)
+{
+	const uint32_t n_c = ix->n_fz;
+	const uint32_t blen = tok_off[n_tok] - tok_off[0];
+	/* FZ_NQ sub-queues of qcap survivors each */
+	/* (what a sub-queue can receive at most: its workgroups x 256 nodes x the
+	 * tokens of a grid.y slice -- a small tree fills few sub-queues) */
+	const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(8, n_tok / 128));
+	const uint64_t q_most = (uint64_t)gy * (((n_c + 255) / 256 + FZ_NQ - 1) / FZ_NQ) * 256 * ((n_tok + gy - 1) / gy);
+	const uint64_t qcap = std::min<uint64_t>(0xffffffffu, std::max<uint64_t>((n_tok + FZ_NQ - 1) / FZ_NQ + 1,
+	    std::min<uint64_t>(ix->cfg.fuzzy_cand / FZ_NQ, q_most)));
+	const uint64_t ccap = qcap * FZ_NQ;
+	const uint64_t mcap = std::max<uint64_t>(1024, ccap / 4);
+	const size_t need = 16384 + FZ_NQ * FZ_CSTRIDE * 4 + (ccap + mcap) * sizeof(fz_item_t) + (size_t)n_tok * (256 * 8 + 8 + 4 + 4 + 4) + 64 + blen + 16 +
+	    ((size_t)n_tok + 1) * 4 + (NXS_MYERS_MAXPAT + 4) * 4 + 16 * 256;
+	uint32_t h_cnt[4] = { 0, 0, 0, 0 };
+	std::vector<uint32_t> h_qcnt(FZ_NQ * FZ_CSTRIDE);
+	unsigned long long h_evals = 0;
+	/* one upload: token offsets, rank of every token in the length-sorted order,
+	 * first rank of every length */
+	std::vector<uint32_t> up((size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2);
+	uint32_t *roff = up.data(), *rank = roff + n_tok + 1, *len_off = rank + n_tok;
+
+	if (ix->fz_len < need) {
+		if (ix->fz) {
+			(void)hipFree(ix->fz);
+			ix->fz = NULL;
+			ix->fz_len = 0;
+		}
+		if (hipMalloc(&ix->fz, need) != hipSuccess) {
+			set_error("hipMalloc(%zu) for the fuzzy workspace failed", need);
+			return -1;
+		}
+		ix->fz_len = need;
+	}
+	uint8_t *p = (uint8_t *)ix->fz;
+	fz_item_t *d_cand = carve<fz_item_t>(p, ccap);
+	fz_item_t *d_match = carve<fz_item_t>(p, mcap);
+	uint32_t *d_cnt = carve<uint32_t>(p, 4);		/* -, matches, overflow, (seed's count) */
+	uint32_t *d_qcnt = carve<uint32_t>(p, FZ_NQ * FZ_CSTRIDE);	/* survivors per sub-queue */
+	unsigned long long *d_evals = carve<unsigned long long>(p, 1);
+	uint64_t *d_peq = carve<uint64_t>(p, (size_t)n_tok * 256);
+	uint2 *d_tokf = carve<uint2>(p, (size_t)n_tok + 4);
+	uint32_t *d_best = carve<uint32_t>(p, n_tok);
+	uint32_t *d_tids = carve<uint32_t>(p, n_tok);
+	uint8_t *d_bytes = carve<uint8_t>(p, blen + 16);
+	uint32_t *d_up = carve<uint32_t>(p, up.size());
+	uint32_t *d_off = d_up, *d_rank = d_up + n_tok + 1, *d_len_off = d_rank + n_tok;
+	hipStream_t st = ix->stream_fz;
+	fz_args_t fa;
+
+	for (uint32_t i = 0; i <= n_tok; i++) {
+		roff[i] = tok_off[i] - tok_off[0];
+	}
+	for (uint32_t l = 0; l <= NXS_MYERS_MAXPAT + 1; l++) {
+		len_off[l] = 0;
+	}
+	for (uint32_t i = 0; i < n_tok; i++) {
+		len_off[roff[i + 1] - roff[i] + 1]++;		/* (every token is <= 64 bytes here) */
+	}
+	for (uint32_t l = 0; l <= NXS_MYERS_MAXPAT; l++) {
+		len_off[l + 1] += len_off[l];
+	}
+	{
+		uint32_t next[NXS_MYERS_MAXPAT + 2];
+		memcpy(next, len_off, sizeof(next));
+		for (uint32_t i = 0; i < n_tok; i++) {
+			rank[i] = next[roff[i + 1] - roff[i]]++;
+		}
+	}
+	if (hipMemcpyAsync(d_bytes, tok_bytes + tok_off[0], blen, hipMemcpyHostToDevice, st) != hipSuccess ||
+	    hipMemcpyAsync(d_up, up.data(), up.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+	    hipMemsetAsync(d_cnt, 0, 16, st) != hipSuccess ||
+	    hipMemsetAsync(d_qcnt, 0, FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
+	    hipMemsetAsync(d_evals, 0, 8, st) != hipSuccess ||
+	    hipMemsetAsync(d_tokf + n_tok, 0xff, 4 * sizeof(uint2), st) != hipSuccess) {
+		set_error("fuzzy upload failed");
+		return -1;
+	}
+	if (ix->profiling) (void)hipEventRecord(ix->ev[0], st);
+	hipLaunchKernelGGL(k_bk_peq, dim3(n_tok), dim3(256), 0, st, d_bytes, d_off, n_tok, d_peq, d_tokf, d_rank);
+	hipLaunchKernelGGL(k_bk_seed, dim3((n_tok + 255) / 256), dim3(256), 0, st, d_cand, d_cnt + 3, n_tok, d_best,
+	    (unsigned long long *)NULL);
+	if (n_c) {
+		hipLaunchKernelGGL(k_fz_filter, dim3((n_c + 255) / 256, gy), dim3(256), 0, st,
+		    ix->d_fz_sig, ix->d_fz_node, ix->d_fz_len, n_c, d_tokf, d_len_off, d_cand, d_qcnt,
+		    (uint32_t)qcap, d_cnt + 2);
+	}
+	memset(&fa, 0, sizeof(fa));
+	fa.bk = ix->d_bk;
+	fa.bk_bytes = ix->d_bk_bytes;
+	fa.tok_bytes = d_bytes;
+	fa.tok_off = d_off;
+	fa.peq = d_peq;
+	fa.cap = (uint32_t)std::min<uint64_t>(ccap, 0xffffffffu);
+	fa.best = d_best;
+	fa.overflow = d_cnt + 2;
+	fa.prune = 1;
+	fa.evals = ix->profiling ? d_evals : NULL;
+	hipLaunchKernelGGL(k_fz_dist, dim3(8, FZ_NQ), dim3(1024), 0, st, fa, d_cand, d_qcnt, (uint32_t)qcap, d_match, d_cnt + 1,
+	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
+	hipLaunchKernelGGL(k_fz_chain, dim3(1024), dim3(256), 0, st, fa, ix->d_bk_parent, ix->d_bk_slot, d_match, d_cnt + 1,
+	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
+	hipLaunchKernelGGL(k_bk_finish, dim3((n_tok + 255) / 256), dim3(256), 0, st, ix->d_bk, d_best, n_tok, d_tids);
+	if (ix->profiling) (void)hipEventRecord(ix->ev[1], st);
+	if (hipGetLastError() != hipSuccess) {
+		set_error("fuzzy kernel launch failed");
+		return -1;
+	}
+	if (hipMemcpyAsync(term_ids, d_tids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    (ix->profiling && hipMemcpyAsync(h_qcnt.data(), d_qcnt, h_qcnt.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+	    hipMemcpyAsync(&h_evals, d_evals, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipStreamSynchronize(st) != hipSuccess) {
+		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	if (ix->profiling) {
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
+		ix->prof.fuzzy_ms += ms;
+	}
+	if (h_cnt[2]) {
+		return 1;
+	}
+	if (ix->profiling) {
+		/* distance evaluations; "pairs" = what the queues carried; levels: pairs
+		 * screened, survivors, matches */
+		uint64_t surv = 0;
+		for (uint32_t q = 0; q < FZ_NQ; q++) {
+			surv += h_qcnt[q * FZ_CSTRIDE];
+		}
+		ix->prof.fuzzy_visits += h_evals;
+		ix->prof.fuzzy_pairs += surv + h_cnt[1];
+		ix->prof.fuzzy_level[0] += (uint64_t)n_tok * n_c;
+		ix->prof.fuzzy_level[1] += surv;
+		ix->prof.fuzzy_level[2] += h_cnt[1];
+	}
+	return 0;
+}
+
 extern "C" int
 nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off,
     uint32_t n_tok, uint32_t *term_ids, uint64_t *visited)
@@ -7565,6 +8109,46 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 	 * does overflow the queues is repeated with a quarter of the tokens, down to
 	 * the safe size.
 	 */
+	/* the usual case: no visit counts wanted, every token fits the bit-vector
+	 * distance -- match first, then reachability; the frontier search below is
+	 * what the reference does, step for step, and the fallback */
+	if (!visited && !ix->cfg.fuzzy_bfs && !ix->cfg.fuzzy_noprune && ix->d_bk_parent) {
+		if (!any_long) {
+			const int r = fuzzy_match_first(ix, tok_bytes, tok_off, n_tok, term_ids);
+			if (r <= 0) {
+				return r;
+			}
+		} else if (!ix->fz_split) {
+			/* tokens beyond the bit-vector distance (> 64 bytes) take the frontier
+			 * search with its row DP, the others the match-first search */
+			std::vector<uint32_t> sel[2], off[2], ids[2];
+			std::vector<uint8_t> bytes[2];
+			int rc = 0;
+			for (uint32_t i = 0; i < n_tok; i++) {
+				const uint32_t m = tok_off[i + 1] - tok_off[i];
+				const int w = m > NXS_MYERS_MAXPAT;
+				if (sel[w].empty()) {
+					off[w].push_back(0);
+				}
+				sel[w].push_back(i);
+				bytes[w].insert(bytes[w].end(), tok_bytes + tok_off[i], tok_bytes + tok_off[i + 1]);
+				off[w].push_back((uint32_t)bytes[w].size());
+			}
+			ix->fz_split = true;
+			for (int w = 0; w < 2 && rc == 0; w++) {
+				if (!sel[w].empty()) {
+					ids[w].resize(sel[w].size());
+					bytes[w].resize(bytes[w].size() + 16);
+					rc = nxsgpu_fuzzy(ix, bytes[w].data(), off[w].data(), (uint32_t)sel[w].size(), ids[w].data(), NULL);
+					for (size_t j = 0; j < sel[w].size(); j++) {
+						term_ids[sel[w][j]] = ids[w][j];
+					}
+				}
+			}
+			ix->fz_split = false;
+			return rc;
+		}
+	}
 	const uint32_t safe_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tok, budget / n_bk));
 	chunk = ix->cfg.fuzzy_safe ? safe_chunk : n_tok;
 
@@ -7619,7 +8203,7 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 			return -1;
 		}
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream_fz);
-		hipLaunchKernelGGL(k_bk_peq, dim3(nc), dim3(256), 0, ix->stream_fz, d_bytes, d_off, nc, d_peq);
+		hipLaunchKernelGGL(k_bk_peq, dim3(nc), dim3(256), 0, ix->stream_fz, d_bytes, d_off, nc, d_peq, (uint2 *)NULL, (const uint32_t *)NULL);
 		hipLaunchKernelGGL(k_bk_seed, dim3((nc + 255) / 256), dim3(256), 0, ix->stream_fz,
 		    qa, counts, nc, d_best, visited ? d_vis : (unsigned long long *)NULL);
 

@@ -354,9 +354,69 @@ def test_fuzzy_matches_oracle(nxs, tmp_path, seed, n_terms, alphabet):
         del os.environ["NXS_GPU_FUZZY_ITEMS"]
         gidx.reconfigure()
     assert (got2, vis2) == (got, vis)
-    # production form (no visit counts): pairs that can no longer win are pruned
-    # -- the same winners
-    assert gidx.fuzzy(toks) == got
+    # production form (no visit counts): the match-first search (screen all
+    # (token, term) pairs, exact distance on the survivors, reachability of the
+    # matches) for tokens of <= 64 bytes, the frontier search for the rest -- the
+    # same winners
+    def path_and_ids(tk):
+        gidx.set_profiling(True); gidx.profile(reset=True)
+        ids = gidx.fuzzy(tk)
+        lv = gidx.profile(reset=True)["fuzzy_level"]; gidx.set_profiling(False)
+        return ("match-first" if lv[0] > len(tk) else "frontier"), ids
+    assert path_and_ids(toks[:400]) == ("match-first", got[:400])
+    assert gidx.fuzzy(toks) == got                      # mixed batch: split
+    assert gidx.fuzzy(toks[:1]) == got[:1] and gidx.fuzzy(toks[7:8]) == got[7:8]
+    for env, val, path in (("NXS_GPU_FUZZY_BFS", "1", "frontier"),         # pruned frontier search
+                           ("NXS_GPU_FUZZY_CAND", "1024", "frontier")):    # survivor queue overflows -> fallback
+        os.environ[env] = val
+        try:
+            gidx.reconfigure()
+            assert path_and_ids(toks[:400]) == (path, got[:400]), env
+        finally:
+            del os.environ[env]
+            gidx.reconfigure()
+    gidx.close()
+
+
+def test_fuzzy_slot63_and_long_terms(nxs, tmp_path):
+    """Terms at distance >= 63 from an ancestor hang in slot 63, which no search
+    enters (the child range ends at min(d+2, 63), exclusive: bktree.c:150-156):
+    they and everything below them are never returned.  Terms of 62..66 bytes can
+    still be within 2 of a token of <= 64 bytes.  Both searches against the oracle."""
+    rng = random.Random(11)
+    short = set()
+    while len(short) < 300:
+        short.add("".join(rng.choice("abc") for _ in range(rng.randint(2, 11))))
+    longw = set()
+    while len(longw) < 60:
+        longw.add("".join(rng.choice("xyz") for _ in range(rng.randint(60, 67))))
+    words = sorted(short)[:5] + sorted(longw)[:3] + sorted((longw | short) - set(sorted(short)[:5]) - set(sorted(longw)[:3]),
+                                                             key=lambda w: rng.random())
+    docs = [(i + 1, words[i * 5:(i + 1) * 5]) for i in range((len(words) + 4) // 5)]
+    t, d, _ = nxsfmt.write_index(str(tmp_path), "idx", docs)
+    gidx, oidx = nxs.open_files(t, d), O.Index(t, d)
+    toks = []
+    for w in sorted(longw):
+        for _ in range(3):
+            b = bytearray(w.encode())
+            for _ in range(rng.randint(1, 2)):
+                pos = rng.randrange(len(b))
+                if rng.random() < 0.5:
+                    b[pos] = ord(rng.choice("xyzq"))
+                else:
+                    del b[pos]
+            toks.append(bytes(b))
+    toks += [w.encode()[:-1] for w in sorted(short)[:40]]
+    want = [oidx.fuzzy(tk)[0] for tk in toks]
+    assert 0 in want and any(want)                      # some unreachable, some found
+    got, vis = gidx.fuzzy(toks, want_visited=True)      # frontier search, the reference's visit counts
+    assert got == want and vis == [oidx.fuzzy(tk)[1] for tk in toks]
+    assert gidx.fuzzy(toks) == want                     # match-first (<= 64 bytes) + frontier (the rest)
+    shortq = [tk for tk in toks if len(tk) <= 64]
+    gidx.set_profiling(True); gidx.profile(reset=True)
+    assert gidx.fuzzy(shortq) == [w for tk, w in zip(toks, want) if len(tk) <= 64]
+    assert gidx.profile(reset=True)["fuzzy_level"][0] > len(shortq)     # the match-first search ran
+    gidx.set_profiling(False)
     gidx.close()
 
 

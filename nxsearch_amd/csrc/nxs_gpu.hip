@@ -131,6 +131,7 @@ struct dev_query_t {
 struct gpu_cfg_t {
 	uint64_t	wave_target;	/* NXS_GPU_WAVES */
 	uint64_t	min_post;	/* NXS_GPU_MINPOST */
+	uint64_t	min_post_solo;	/* NXS_GPU_MINPOST_SOLO: the same for a small batch with nothing else in flight */
 	double		dense_thr;	/* NXS_GPU_DENSE (0 = posting-step path off) */
 	double		scanm_dens;	/* NXS_GPU_SCANM_DENS */
 	uint32_t	scanm_minnt, scanm_maxnt;
@@ -168,6 +169,7 @@ cfg_from_env(gpu_cfg_t &c)
 
 	c.wave_target = u64("NXS_GPU_WAVES", 65536, 1, 1u << 22);
 	c.min_post = u64("NXS_GPU_MINPOST", 4096, 1, ~0ull);
+	c.min_post_solo = u64("NXS_GPU_MINPOST_SOLO", 1024, 1, ~0ull);
 	c.dense_thr = dbl("NXS_GPU_DENSE", 0.0);
 	c.scanm_dens = dbl("NXS_GPU_SCANM_DENS", 0.08);
 	c.scanm_minnt = (uint32_t)u64("NXS_GPU_SCANM_MINNT", 2, 2, 8);
@@ -2013,6 +2015,17 @@ k_scan8(const scan_args_t A)
 /* diagnostic build only (make variant XFLAGS=-DNXS_STATS): k_scanm event counts
  * and cycle spans, read back with nxsgpu_debug_stats() */
 __device__ unsigned long long g_stats[16];
+__device__ unsigned long long g_rstats[8];	/* k_replay: queries, then 10 ns ticks per phase, candidates, inserts */
+extern "C" void
+nxsgpu_debug_rstats(unsigned long long *out, int reset)
+{
+	unsigned long long z[8] = { 0 };
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstats), sizeof(z));
+	if (reset) {
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z));
+	}
+}
 #define	STAT_ADD(i, v)	do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 #define	STAT_CLK()	((unsigned long long)__builtin_amdgcn_s_memtime())
 extern "C" void
@@ -3003,7 +3016,9 @@ k_scan1(const scan_args_t A)
  *    threshold filter / candidate emission as the other scan kernels; lanes
  *    are in ascending doc order, so emission is by descending lane.
  */
+#ifndef RW
 #define	RW	4096		/* docs per round span (LDS byte map) */
+#endif
 
 template <int MODE, int NT>
 __global__ void __launch_bounds__(WAVE)
@@ -3689,6 +3704,100 @@ heap_add(float *hs, uint32_t *hd, uint32_t *nitems, uint32_t cap, float s, uint3
 	}
 }
 
+/*
+ * The same heap with its array ACROSS THE LANES of the wavefront (element i in
+ * lane i, capacity <= 64): an element is read with v_readlane and written with
+ * v_writelane, a few cycles each, where the LDS array cost a full LDS round
+ * trip per access on lane 0 (about 1 us per heap_add: the replay of a single
+ * query took 60-80 us, most of nxs_index_search()'s latency).  Every lane runs
+ * the same scalar control flow; indices and values are wave-uniform.  Line for
+ * line the functions above.
+ */
+__device__ __forceinline__ float
+rh_gets(float hs, uint32_t i)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hs), (int)i));
+}
+
+__device__ __forceinline__ uint32_t
+rh_getd(uint32_t hd, uint32_t i)
+{
+	return (uint32_t)__builtin_amdgcn_readlane((int)hd, (int)i);
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"	/* (M0 is reserved: nothing in these kernels uses it) */
+__device__ __forceinline__ void
+rh_set(float &hs, uint32_t &hd, uint32_t i, float s, uint32_t d)
+{
+	/* (no writelane builtin in this compiler; value and lane select are SGPRs) */
+	const int sv = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s));
+	const int dv = __builtin_amdgcn_readfirstlane((int)d);
+	const int li = __builtin_amdgcn_readfirstlane((int)i);
+	/* (one SGPR per VOP3 instruction on this target: the lane select goes through M0) */
+	asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+	    : "+v"(hs), "+v"(hd) : "s"(sv), "s"(li), "s"(dv) : "m0");
+}
+#pragma clang diagnostic pop
+
+/* heap_remove_min: src/algo/heap.c:133-189 */
+__device__ static inline void
+rheap_remove_min(float &hs, uint32_t &hd, uint32_t &nitems, float &os, uint32_t &od)
+{
+	uint32_t i = 0, max_, left;
+
+	os = rh_gets(hs, 0);
+	od = rh_getd(hd, 0);
+	if ((max_ = --nitems) == 0) {
+		return;
+	}
+	rh_set(hs, hd, 0, rh_gets(hs, max_), rh_getd(hd, max_));
+	while ((left = i * 2 + 1) < max_) {
+		const float ps = rh_gets(hs, i);
+		const uint32_t pd = rh_getd(hd, i);
+		const uint32_t right = i * 2 + 2;
+		uint32_t smallest = i;
+
+		if (rh_gets(hs, left) < ps) {
+			smallest = left;
+		}
+		if (right < max_ && rh_gets(hs, right) < rh_gets(hs, smallest)) {
+			smallest = right;
+		}
+		if (smallest == i) {
+			break;
+		}
+		rh_set(hs, hd, i, rh_gets(hs, smallest), rh_getd(hd, smallest));
+		rh_set(hs, hd, smallest, ps, pd);
+		i = smallest;
+	}
+}
+
+/* heap_add: src/algo/heap.c:58-124; caller has checked acceptance */
+__device__ static inline void
+rheap_add(float &hs, uint32_t &hd, uint32_t &nitems, uint32_t cap, float s, uint32_t d)
+{
+	uint32_t i;
+
+	if (nitems == cap) {
+		float ts; uint32_t td;
+		rheap_remove_min(hs, hd, nitems, ts, td);
+	}
+	i = nitems++;
+	rh_set(hs, hd, i, s, d);
+	while (i) {
+		const uint32_t parent = (i - 1) / 2;
+		const float ps = rh_gets(hs, parent);
+		const uint32_t pd = rh_getd(hd, parent);
+		if (s >= ps) {		/* heap.c:103 */
+			break;
+		}
+		rh_set(hs, hd, parent, s, d);
+		rh_set(hs, hd, i, ps, pd);
+		i = parent;
+	}
+}
+
 struct replay_args_t {
 	const qmeta_t *		qmeta;
 	uint32_t		seg_cap;	/* 0 => segments addressed by seg_off */
@@ -3734,15 +3843,25 @@ template <bool LDS_HEAP>
 __global__ void __launch_bounds__(WAVE)
 k_replay(const replay_args_t A)
 {
-	__shared__ float l_hs[NXSGPU_FAST_K];
-	__shared__ uint32_t l_hd[NXSGPU_FAST_K];
-	__shared__ uint32_t s_n;
+	__shared__ uint32_t s_n;	/* (global-memory heap only) */
 	__shared__ float s_min;
 
 	const unsigned lane = threadIdx.x;
+#ifdef NXS_STATS
+	const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+	unsigned long long rt1 = rt0, rt2 = rt0, rt3 = rt0;
+	unsigned long long n_ins = 0, n_cand = 0;
+#define	RSTAT(x)	x
+#else
+#define	RSTAT(x)
+#endif
 	const uint32_t q = A.qlist ? A.qlist[blockIdx.x] : blockIdx.x;
-	float *hs;
-	uint32_t *hd, cap;
+	float *hs = NULL;
+	uint32_t *hd = NULL, cap;
+	/* LDS_HEAP (k <= 64): the heap lives in these two registers, element i in lane i */
+	float rhs = 0.0f;
+	uint32_t rhd = 0, rn = 0;
+	float rmin = 0.0f;
 
 	if (A.skip && A.skip[q]) {
 		/* the query overflowed its candidate segments: its record says so (the
@@ -3753,9 +3872,7 @@ k_replay(const replay_args_t A)
 		return;
 	}
 	if (LDS_HEAP) {
-		hs = l_hs;
-		hd = l_hd;
-		cap = A.k;
+		cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(A.k, (uint32_t)WAVE));
 	} else {
 		hs = A.gheap_s + A.heap_off[q];
 		hd = A.gheap_d + A.heap_off[q];
@@ -3799,6 +3916,7 @@ k_replay(const replay_args_t A)
 			}
 		}
 		const uint32_t total = (uint32_t)__shfl((int)incl, WAVE - 1);
+		RSTAT(n_cand += total; if (rt1 == rt0) rt1 = __builtin_amdgcn_s_memrealtime();)
 		constexpr int RU = 4;
 		for (uint32_t c0 = 0; c0 < total; c0 += WAVE * RU) {
 			float scv[RU];
@@ -3836,6 +3954,30 @@ k_replay(const replay_args_t A)
 				const uint32_t dc = dcv[u];
 				/* heap.c:68-74: when full, an item <= the root is dropped
 				 * without touching the heap */
+				if constexpr (LDS_HEAP) {
+					uint64_t pend = ballot64(valid && (rn < cap || sc > rmin));
+					while (pend) {
+						const int L = __builtin_ctzll(pend);
+						const float v = rh_gets(sc, (uint32_t)L);
+						const uint32_t dv = rh_getd(dc, (uint32_t)L);
+						rheap_add(rhs, rhd, rn, cap, v, dv);
+						RSTAT(n_ins++;)
+						rn = (uint32_t)__builtin_amdgcn_readfirstlane((int)rn);
+						if (A.log_cnt && lane == 0) {
+							const uint32_t row = A.log_slot ? A.log_slot[q] : q;
+							const uint32_t nl = A.log_cnt[row];
+							if (nl < A.log_cap) {
+								A.log_ids[(uint64_t)row * A.log_cap + nl] = A.doc_ids[dv];
+								A.log_sc[(uint64_t)row * A.log_cap + nl] = v;
+							}
+							A.log_cnt[row] = nl + 1;
+						}
+						rmin = rh_gets(rhs, 0);
+						pend &= pend - 1;
+						pend &= ballot64(valid && (rn < cap || sc > rmin));
+					}
+					continue;
+				}
 				uint32_t nn = s_n;
 				float mn = s_min;
 				uint64_t pend = ballot64(valid && (nn < cap || sc > mn));
@@ -3869,6 +4011,56 @@ k_replay(const replay_args_t A)
 	}
 	__syncthreads();
 
+	if constexpr (LDS_HEAP) {
+		RSTAT(rt2 = __builtin_amdgcn_s_memrealtime();)
+		/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
+		const uint32_t cnt = rn;
+		uint32_t n = rn;
+		while (n) {
+			const uint32_t last = n - 1;
+			float ms; uint32_t mdoc;
+			rheap_remove_min(rhs, rhd, n, ms, mdoc);
+			n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+			rh_set(rhs, rhd, last, ms, mdoc);
+		}
+		/* lane i holds result i */
+		if (A.rec_base) {
+			/* u32 count | u32 flags | u64 ids[k] | f32 scores[k]  (nxs_gpu.h) */
+			uint8_t *rec = A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes;
+			uint64_t *r_ids = (uint64_t *)(rec + 8);
+			float *r_sc = (float *)(rec + 8 + 8 * (size_t)A.k);
+			RSTAT(rt3 = __builtin_amdgcn_s_memrealtime();)
+			if (lane < cnt) {
+				r_ids[lane] = A.doc_ids[rhd];
+				r_sc[lane] = rhs;
+			}
+			if (lane == 0) {
+				((uint32_t *)rec)[0] = cnt;
+			}
+#ifdef NXS_STATS
+			if (lane == 0) {
+				const unsigned long long rt4 = __builtin_amdgcn_s_memrealtime();
+				atomicAdd(&g_rstats[0], 1ull);
+				atomicAdd(&g_rstats[1], rt1 - rt0);
+				atomicAdd(&g_rstats[2], rt2 - rt1);
+				atomicAdd(&g_rstats[3], rt3 - rt2);
+				atomicAdd(&g_rstats[4], rt4 - rt3);
+				atomicAdd(&g_rstats[5], n_cand);
+				atomicAdd(&g_rstats[6], n_ins);
+			}
+#endif
+			return;
+		}
+		const uint64_t ob = A.out_off ? A.out_off[q] : (uint64_t)q * A.k;
+		if (lane < cnt) {
+			A.out_ids[ob + lane] = A.doc_ids[rhd];
+			A.out_sc[ob + lane] = rhs;
+		}
+		if (lane == 0) {
+			A.out_count[q] = cnt;
+		}
+		return;
+	}
 	/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
 	const uint32_t cnt = s_n;
 	if (lane == 0) {
@@ -5562,11 +5754,12 @@ nt_bucket(uint32_t nt)
 }
 
 static void
-build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl)
+build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false)
 {
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
 	const gpu_cfg_t &cf = ix->cfg;
-	const uint64_t target = cf.wave_target, min_post = cf.min_post;
+	/* (a batch that has the GPU to itself is latency-bound: shorter ranges, more of them) */
+	const uint64_t target = cf.wave_target, min_post = solo ? std::min(cf.min_post, cf.min_post_solo) : cf.min_post;
 	/* densest term has >= this many postings per tile => tile path (step path
 	 * off by default: the tile path is at least as fast) */
 #ifdef NXS_EXPERIMENTAL
@@ -6872,7 +7065,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post) != 0) {
 		return -1;
 	}
-	build_worklist(ix, h_q, nq, wl);
+	build_worklist(ix, h_q, nq, wl, solo);
 	tb1 = now_us();
 	const uint64_t nseg = wl.n_segs;
 	if (nseg > seg_bound) {

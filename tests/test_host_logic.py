@@ -351,7 +351,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
         agpr, name = int(m.group(1)), m.group(2)
         k8 = re.match(r"_Z7k_scan8ILi\d+ELi(\d+)ELi(\d+)EE", name)
         kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)EE", name)
-        km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]EE", name)
+        km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]ELb[01]EE", name)
         if k8:
             nt, mm = int(k8.group(1)), int(k8.group(2))
             want = 2 * ring8 * nt if (nt >= 3 and mm != 2) else 0

@@ -451,6 +451,9 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
                                  "frac": round(fz_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
                                  "alg_bytes": int(fz_bytes),
                                  "cells_per_s": round(ref_vis * mean_len * tok_len / (ms * 1e-3), 1) if ms > 0 else None,
+                                 # what the three kernels really touch (mostly L2): 8 B per candidate term and token
+                                 # slice, 16 B per queue item written + read, 104 B per distance evaluation
+                                 "moved_bytes_estimate": int(len(terms) * 8 * 8 + pairs * 16 + evals * 104),
                                  "note": "work done in the reference's unit (its visits), not bytes moved: the "
                                          "40 MB tree and the 8 MB of signatures sit in L2 / Infinity Cache and "
                                          "most visits are never made; HBM peak is the nominal denominator only"},

@@ -141,6 +141,7 @@ struct gpu_cfg_t {
 	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
 	bool		fuzzy_bfs;	/* NXS_GPU_FUZZY_BFS: level-by-level frontier search only */
+	bool		fuzzy_prio;	/* NXS_GPU_FUZZY_PRIO: the fuzzy stream at the highest priority (read at create) */
 	uint64_t	fuzzy_cand;	/* NXS_GPU_FUZZY_CAND: survivor queue of the match-first search (items) */
 	bool		use_drop;	/* !NXS_GPU_NODROP: dense terms leave sparse OR scans (k_scanm<.., DROP>) */
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
@@ -190,6 +191,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.fuzzy_safe = on("NXS_GPU_FUZZY_SAFE");
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
 	c.fuzzy_bfs = on("NXS_GPU_FUZZY_BFS");
+	c.fuzzy_prio = on("NXS_GPU_FUZZY_PRIO");
 	c.fuzzy_cand = u64("NXS_GPU_FUZZY_CAND", 32ull << 20, 1024, 1ull << 30);
 	c.use_drop = !on("NXS_GPU_NODROP");
 	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
@@ -5265,7 +5267,23 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
+	{
+		/*
+		 * NXS_GPU_FUZZY_PRIO: the fuzzy stream at the highest priority.  Fuzzy
+		 * passes are short and the host waits for them while the previous batch's
+		 * scans fill the GPU; with priority their workgroups go first whenever
+		 * wavefront slots free up.  C5 (50M docs, one GPU): planning 32 -> 8 ms and
+		 * the scans 37.7 -> 26.2 ms per step (the stretched-out fuzzy kernels no
+		 * longer run beside them) -- but in that timing ONE sparse + dense query per
+		 * step overflows its pending list and its re-run queues behind the next
+		 * batch's scans (+19 ms): 185k instead of 206k queries/s until an overflow
+		 * is recoverable inside the kernel.  Off by default.
+		 */
+		int pr_least = 0, pr_greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+		HIP_TRY(hipStreamCreateWithPriority(&ix->stream_fz, hipStreamNonBlocking,
+		    ix->cfg.fuzzy_prio ? pr_greatest : 0));
+	}
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
@@ -6185,7 +6203,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
  */
 static int
 fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queries, uint32_t nq,
-    dev_query_t *hq, uint64_t &total_post)
+    dev_query_t *hq, uint64_t &total_post, bool allow_drop = true)
 {
 	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
 	const bool no_req = ix->cfg.no_req;
@@ -6235,7 +6253,7 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 		 * slower than the accumulator tiles there.)
 		 */
 		d.drop_mask = 0;
-		if (d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && algo == NXSGPU_BM25) {
+		if (allow_drop && d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && algo == NXSGPU_BM25) {
 			for (uint32_t t = 0; t < d.nt; t++) {
 				const auto it = std::lower_bound(ix->dense_terms.begin(), ix->dense_terms.end(), q.term_id[t]);
 				if (it != ix->dense_terms.end() && *it == q.term_id[t]) {
@@ -6347,7 +6365,11 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			return -1;
 		}
 	}
-	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post) != 0) {
+	/* (this blocking path is also where queries land whose candidate lists
+	 * overflowed in a batch: no sparse + dense class here -- its pending list is
+	 * what overflows, and the tiles take such a query without emitting every match
+	 * as the exact passes below would: 30 ms per query at 50M docs) */
+	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post, false) != 0) {
 		return -1;
 	}
 	build_worklist(ix, hq.data(), nq, wl);

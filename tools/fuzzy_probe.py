@@ -8,13 +8,15 @@ sys.path.insert(0, ROOT)
 import nxsearch_amd as N
 from nxsearch_amd import corpus
 docs = int(os.environ.get("FZ_DOCS", "10000000"))
-work = "/dev/shm/nxs_fz_probe_%d" % docs
+n_terms = int(os.environ.get("FZ_TERMS", "1000000"))
+n_tok = int(os.environ.get("FZ_TOKENS", "1024"))
+work = "/dev/shm/nxs_fz_probe_%d_%d" % (docs, n_terms)
 os.makedirs(work, exist_ok=True)
-info = corpus.write_corpus(work, docs, 1_000_000, seed=0)
-terms = corpus.term_strings(1_000_000, 0)
+info = corpus.write_corpus(work, docs, n_terms, seed=0)
+terms = corpus.term_strings(n_terms, 0)
 nxs = N.Nxs(work)
 idx = nxs.open_files(info["terms"], info["dtmap"])
-toks = corpus.queries_fuzzy(terms, 1024, seed=4)
+toks = corpus.queries_fuzzy(terms, n_tok, seed=4)
 idx.fuzzy(toks)
 idx.set_profiling(True)
 for rep in range(3):

@@ -141,7 +141,6 @@ struct gpu_cfg_t {
 	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
 	bool		fuzzy_bfs;	/* NXS_GPU_FUZZY_BFS: level-by-level frontier search only */
-	bool		fuzzy_prio;	/* NXS_GPU_FUZZY_PRIO: the fuzzy stream at the highest priority (read at create) */
 	uint64_t	fuzzy_cand;	/* NXS_GPU_FUZZY_CAND: survivor queue of the match-first search (items) */
 	bool		use_drop;	/* !NXS_GPU_NODROP: dense terms leave sparse OR scans (k_scanm<.., DROP>) */
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
@@ -191,7 +190,6 @@ cfg_from_env(gpu_cfg_t &c)
 	c.fuzzy_safe = on("NXS_GPU_FUZZY_SAFE");
 	c.fuzzy_noprune = on("NXS_GPU_FUZZY_NOPRUNE");
 	c.fuzzy_bfs = on("NXS_GPU_FUZZY_BFS");
-	c.fuzzy_prio = on("NXS_GPU_FUZZY_PRIO");
 	c.fuzzy_cand = u64("NXS_GPU_FUZZY_CAND", 32ull << 20, 1024, 1ull << 30);
 	c.use_drop = !on("NXS_GPU_NODROP");
 	c.drop_minpost = u64("NXS_GPU_DROP_MINPOST", 4096, 1, ~0ull);
@@ -208,6 +206,10 @@ struct nxsgpu_index {
 	int		device;
 	gpu_cfg_t	cfg;
 	hipStream_t	stream;
+	hipStream_t	xstream[3];	/* the blocking search (nxsgpu_search: re-runs of overflowed queries,
+					 * limits > 64) takes these in place of stream / stream2 / stream3
+					 * while batches are in flight: beside them, not queued behind
+					 * their scans */
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
 	hipStream_t	stream3;	/* the sparse + dense OR class (k_scanm<.., DROP>): few, latency-bound
 					 * wavefronts that run BESIDE the other classes, not in front of them */
@@ -5074,6 +5076,11 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream3) {
 		(void)hipStreamDestroy(ix->stream3);
 	}
+	for (int i = 0; i < 3; i++) {
+		if (ix->xstream[i]) {
+			(void)hipStreamDestroy(ix->xstream[i]);
+		}
+	}
 	if (ix->ev_fork3) {
 		(void)hipEventDestroy(ix->ev_fork3);
 	}
@@ -5261,29 +5268,20 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	}
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+	for (int i = 0; i < 3; i++) {
+		HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[i], hipStreamNonBlocking));
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
-	{
-		/*
-		 * NXS_GPU_FUZZY_PRIO: the fuzzy stream at the highest priority.  Fuzzy
-		 * passes are short and the host waits for them while the previous batch's
-		 * scans fill the GPU; with priority their workgroups go first whenever
-		 * wavefront slots free up.  C5 (50M docs, one GPU): planning 32 -> 8 ms and
-		 * the scans 37.7 -> 26.2 ms per step (the stretched-out fuzzy kernels no
-		 * longer run beside them) -- but in that timing ONE sparse + dense query per
-		 * step overflows its pending list and its re-run queues behind the next
-		 * batch's scans (+19 ms): 185k instead of 206k queries/s until an overflow
-		 * is recoverable inside the kernel.  Off by default.
-		 */
-		int pr_least = 0, pr_greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-		HIP_TRY(hipStreamCreateWithPriority(&ix->stream_fz, hipStreamNonBlocking,
-		    ix->cfg.fuzzy_prio ? pr_greatest : 0));
-	}
+	/* (at the highest stream priority the fuzzy passes finish sooner -- the host
+	 * waits 8-10 instead of 27-32 ms per C5 step for them -- but that wait is
+	 * hidden behind the device's 38 ms anyway, and the changed timing made one
+	 * query per step overflow its candidate lists: plain priority) */
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
@@ -6740,8 +6738,21 @@ extern "C" int
 nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, nxsgpu_results_t *res)
 {
-	/* (runs behind the batches in flight, if any: same stream, own workspace) */
-	return search_impl(ix, algo, limit, queries, nq, res);
+	/* own workspace; with batches in flight, own streams too: a re-run of a few
+	 * overflowed queries must not wait for the next batch's scans (19 ms at C5) */
+	const bool busy = ix->slot[0].active || ix->slot[1].active;
+	if (busy) {
+		std::swap(ix->stream, ix->xstream[0]);
+		std::swap(ix->stream2, ix->xstream[1]);
+		std::swap(ix->stream3, ix->xstream[2]);
+	}
+	const int r = search_impl(ix, algo, limit, queries, nq, res);
+	if (busy) {
+		std::swap(ix->stream, ix->xstream[0]);
+		std::swap(ix->stream2, ix->xstream[1]);
+		std::swap(ix->stream3, ix->xstream[2]);
+	}
+	return r;
 }
 
 /* ---- N4: doc-sharded mode ------------------------------------------------------------ */
@@ -7805,7 +7816,8 @@ k_stream_warm(const v4u_t *__restrict__ src, uint64_t n16, uint32_t *__restrict_
 static void
 warm_streams(nxsgpu_index_t *ix)
 {
-	hipStream_t st[] = { ix->stream, ix->stream2, ix->stream3, ix->stream_up, ix->stream_down, ix->stream_fz };
+	hipStream_t st[] = { ix->stream, ix->stream2, ix->stream3, ix->stream_up, ix->stream_down, ix->stream_fz,
+	    ix->xstream[0], ix->xstream[1], ix->xstream[2] };
 	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 512ull << 20) & ~(uint64_t)15;
 	const size_t cb = 4u << 20;
 	uint32_t *d_sink = NULL;

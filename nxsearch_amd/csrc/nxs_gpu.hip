@@ -663,6 +663,8 @@ enum { MODE_TOPK = 0, MODE_COUNT = 1, MODE_ALL = 2 };
 
 /* a query's doc space is cut into n_groups ranges of group_docs docs; one
  * wavefront (work item) per range; its candidates go to segment seg_first+g */
+/* pad: 1 = the ranges of this (single-token) query split its posting list by
+ * INDEX, evenly -- no doc boundaries, no cursors (k_scan1) */
 struct qmeta_t { uint32_t seg_first, n_groups, group_docs, pad; };
 struct item_t { uint32_t q, g; };
 
@@ -2913,10 +2915,16 @@ k_scan1(const scan_args_t A)
 	bool ovf = false;
 
 	if (matches) {
-		const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS;
-		(void)n; (void)dlo; (void)dhi;
-		lo = (int32_t)A.cursors[cb];
-		hi = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+		(void)dlo; (void)dhi;
+		if (qm.pad) {
+			/* ranges by posting index (no cursors): range g of G = [n g / G, n (g+1) / G) */
+			lo = (int32_t)((uint64_t)n * g / qm.n_groups);
+			hi = (int32_t)((uint64_t)n * (g + 1) / qm.n_groups);
+		} else {
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS;
+			lo = (int32_t)A.cursors[cb];
+			hi = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+		}
 	}
 	if (MODE == MODE_COUNT) {
 		if (lane == 0) {
@@ -5755,6 +5763,7 @@ struct worklist_t {
 	std::vector<uint32_t>	bnd_q;		/* boundary -> query, n_segs + nq entries */
 	std::vector<uint32_t>	qorder;		/* queries in launch order; launch_t::q_first/q_count index it */
 	uint32_t		n_segs;
+	bool			need_cursors;	/* some query's ranges are doc ranges (k_cursors has work) */
 };
 
 static void
@@ -5903,6 +5912,7 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	wl.items.clear();
 	wl.launches.clear();
 	wl.n_segs = 0;
+	wl.need_cursors = false;
 	for (uint32_t i = 0; i < nq; i++) {
 		uint64_t g = std::max<uint64_t>(1, (work[i] + per_wave - 1) / per_wave);
 		g = std::min<uint64_t>(g, tiles);
@@ -5912,7 +5922,12 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 		qmeta_t &m = wl.qmeta[i];
 		m.n_groups = (uint32_t)g;
 		m.group_docs = (uint32_t)std::min<uint64_t>(tiles_per * TILE_W, 0xffffffffu & ~(uint64_t)(TILE_W - 1));
-		m.pad = 0;
+		/* single-token queries on k_scan1: any split of the list into contiguous
+		 * pieces, highest docs first, feeds the heap the same sequence -- split by
+		 * posting index and the batch needs no k_cursors launch */
+		m.pad = ((cls[i] >> 6) == 1 && (cls[i] & 15) == 1 && !cf.no_scan1 && !cf.old_scan &&
+		    ix->n_docs < (1ull << 31)) ? 1u : 0u;
+		wl.need_cursors = wl.need_cursors || m.pad == 0;
 	}
 	for (uint32_t i = 0; i < nq; i++) {
 		wl.qmeta[i].seg_first = wl.n_segs;
@@ -7239,7 +7254,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * latency-bound grid of binary searches) runs on the upload stream, beside
 	 * the previous batch's scans instead of in front of this batch's.
 	 */
-	if (nq) {
+	if (nq && wl.need_cursors) {
 		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), s_up);
 	}
 	tc[1] = now_us();

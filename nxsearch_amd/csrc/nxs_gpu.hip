@@ -169,7 +169,7 @@ cfg_from_env(gpu_cfg_t &c)
 
 	c.wave_target = u64("NXS_GPU_WAVES", 65536, 1, 1u << 22);
 	c.min_post = u64("NXS_GPU_MINPOST", 4096, 1, ~0ull);
-	c.min_post_solo = u64("NXS_GPU_MINPOST_SOLO", 1024, 1, ~0ull);
+	c.min_post_solo = u64("NXS_GPU_MINPOST_SOLO", 512, 1, ~0ull);
 	c.dense_thr = dbl("NXS_GPU_DENSE", 0.0);
 	c.scanm_dens = dbl("NXS_GPU_SCANM_DENS", 0.08);
 	c.scanm_minnt = (uint32_t)u64("NXS_GPU_SCANM_MINNT", 2, 2, 8);
@@ -5914,7 +5914,20 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	wl.n_segs = 0;
 	wl.need_cursors = false;
 	for (uint32_t i = 0; i < nq; i++) {
-		uint64_t g = std::max<uint64_t>(1, (work[i] + per_wave - 1) / per_wave);
+		uint64_t per_i = per_wave;
+		if (solo) {
+			/*
+			 * Alone on the GPU every range starts cold and emits its own early
+			 * maxima (~10 (1 + ln(postings / 10)) candidates each), which the replay
+			 * then streams through one wavefront; a range's scan is a chain of
+			 * dependent window loads.  Scan time falls with the number of ranges R,
+			 * replay time grows with it: the sum is smallest near R = sqrt(n / 84),
+			 * i.e. sqrt(84 n) postings per range (2M postings: 154 ranges, not 2000).
+			 */
+			/* (never finer than the batch-wide rule: the work list's size bound rests on it) */
+			per_i = std::max<uint64_t>(per_wave, (uint64_t)std::sqrt(84.0 * (double)work[i]));
+		}
+		uint64_t g = std::max<uint64_t>(1, (work[i] + per_i - 1) / per_i);
 		g = std::min<uint64_t>(g, tiles);
 		g = std::min<uint64_t>(g, 65535);
 		const uint64_t tiles_per = (tiles + g - 1) / g;

@@ -3029,14 +3029,35 @@ k_scan1(const scan_args_t A)
  *    are in ascending doc order, so emission is by descending lane.
  */
 #ifndef RW
-#define	RW	4096		/* docs per round span (LDS byte map) */
+#define	RW	4096		/* docs per round span (LDS byte map; SCANR_HASH 0) */
 #endif
+#ifndef SCANR_HASH
+#define	SCANR_HASH	1		/* a round = a whole driver window, its docs in an LDS hash table */
+#endif
+#define	SCANR_HT_BITS	9
+#define	SCANR_HT	(1 << SCANR_HT_BITS)
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool HASHQ = false>
 __global__ void __launch_bounds__(WAVE)
 k_scanr(const scan_args_t A)
 {
-	__shared__ uint8_t s_mark[RW + WAVE];		/* + one always-zero dummy slot per lane */
+	/*
+	 * HASH (queries with four required terms and more): a round takes the driver's WHOLE
+	 * window, whatever doc span it covers, and keeps its docs in an open-addressing
+	 * table (doc -> driver lane + 1) instead of a byte map over RW docs.  A sparse
+	 * driver has a posting every few hundred docs: spans of RW docs held ~11 of
+	 * them and a round's fixed scalar cost was paid 5-6 times per window.  A probe
+	 * costs more than a byte-map read, though: where most of the work is looking
+	 * the second list's postings up (2.1 -> 3.8 ms for 2-term ANDs, 0.99 -> 1.71
+	 * for 3-term ones) the spans stay; with more required terms the later, denser
+	 * lists are mostly never looked at and the rounds dominate (5-term AND 0.595
+	 * -> 0.508 ms).  Decided per query on the host (the class key), compiled in
+	 * per instantiation: with both forms in one kernel the 5-term AND took 0.65 ms.
+	 */
+	constexpr bool HASH = HASHQ;
+	__shared__ uint32_t s_hdoc[HASH ? SCANR_HT : 1];
+	__shared__ uint8_t s_hlane[HASH ? SCANR_HT : 1];
+	__shared__ uint8_t s_mark[HASH ? 1 : RW + WAVE];	/* + one always-zero dummy slot per lane */
 	__shared__ uint8_t s_bits[WAVE];		/* presence mask of the driver lane's doc */
 	__shared__ float s_imp[NT][WAVE];		/* [token][driver lane] */
 	__shared__ uint32_t s_truth[8];
@@ -3050,9 +3071,18 @@ k_scanr(const scan_args_t A)
 	const uint32_t n_req = Q->n_req;		/* slots [0, n_req) are required */
 	const uint64_t seg = (uint64_t)qm.seg_first + g;
 
-	for (uint32_t i = lane; i < RW + WAVE; i += WAVE) {
-		s_mark[i] = 0;
+	if constexpr (HASH) {
+		for (uint32_t i = lane; i < SCANR_HT; i += WAVE) {
+			s_hdoc[i] = 0xffffffffu;
+		}
+	} else {
+		for (uint32_t i = lane; i < RW + WAVE; i += WAVE) {
+			s_mark[i] = 0;
+		}
 	}
+	auto hash_of = [](uint32_t doc) -> uint32_t {
+		return (doc * 2654435761u) >> (32 - SCANR_HT_BITS);
+	};
 	s_bits[lane] = 0;
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
@@ -3147,16 +3177,43 @@ k_scanr(const scan_args_t A)
 
 	while (!done && pdoc[0] >= 0) {
 		const int32_t dtop = pdoc[0];
-		const uint32_t base = (uint32_t)dtop & ~(uint32_t)(RW - 1);
-		/* the driver's postings of this round */
-		const uint64_t inm0 = vm[0] & ballot64(Ad[0] >= base);
+		const uint32_t base = HASH ? 0u : (uint32_t)dtop & ~(uint32_t)(RW - 1);
+		/* the driver's postings of this round: its whole window (HASH), or those
+		 * of one RW-doc span */
+		const uint64_t inm0 = HASH ? vm[0] : (vm[0] & ballot64(Ad[0] >= base));
 		const bool in0 = lane_of(inm0);
-		const uint32_t dd0 = in0 ? Ad[0] - base : RW + lane;
+		const uint32_t dd0 = in0 ? Ad[0] - base : RW + lane;	/* (byte map) */
+		uint32_t hslot = 0;
+		if constexpr (HASH) {
+			/* insert: claim an empty slot, verify, move on (no atomics: the lanes
+			 * of one LDS instruction are serialised, exactly one claim survives) */
+			uint32_t h = hash_of(Ad[0]);
+			uint64_t todo = inm0;
+			while (todo) {
+				const bool mine = lane_of(todo);
+				if (mine && s_hdoc[h] == 0xffffffffu) {
+					s_hdoc[h] = Ad[0];
+				}
+				WAVE_SYNC();
+				const bool got = mine && s_hdoc[h] == Ad[0];
+				if (got) {
+					s_hlane[h] = (uint8_t)(lane + 1);
+					hslot = h;
+				}
+				if (mine && !got) {
+					h = (h + 1) & (SCANR_HT - 1);
+				}
+				todo &= ~ballot64(got);
+				WAVE_SYNC();
+			}
+		}
 		const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)Ad[0], __builtin_ctzll(inm0));
 		uint64_t alive = inm0;
 
 		vm[0] ^= inm0;
-		s_mark[dd0] = in0 ? (uint8_t)(lane + 1) : (uint8_t)0;
+		if constexpr (!HASH) {
+			s_mark[dd0] = in0 ? (uint8_t)(lane + 1) : (uint8_t)0;
+		}
 		s_bits[lane] = (uint8_t)(1u << tok[0]);
 		s_imp[tok[0]][lane] = Ai[0];
 		WAVE_SYNC();
@@ -3209,9 +3266,26 @@ k_scanr(const scan_args_t A)
 						const uint64_t inm = left & ballot64(Ad[j] >= rlo);
 						left ^= inm;
 						if (inm) {
-							const bool inl = lane_of(inm);
-							const uint32_t dd = inl ? Ad[j] - base : RW + lane;
-							const uint32_t m = s_mark[dd];
+							uint32_t m = 0;
+							if constexpr (HASH) {
+								uint32_t h = hash_of(Ad[j]);
+								uint64_t todo = inm;
+								while (todo) {
+									const bool mine = lane_of(todo);
+									const uint32_t v = s_hdoc[h];
+									const bool hit = mine && v == Ad[j];
+									const bool miss = mine && v == 0xffffffffu;
+									if (hit) {
+										m = s_hlane[h];
+									}
+									h = (h + 1) & (SCANR_HT - 1);
+									todo &= ~ballot64(hit || miss);
+								}
+							} else {
+								const bool inl = lane_of(inm);
+								const uint32_t dd = inl ? Ad[j] - base : RW + lane;
+								m = s_mark[dd];
+							}
 							if (ballot64(m != 0)) {
 								if (m != 0) {
 									s_imp[tj][m - 1] = Ai[j];
@@ -3234,8 +3308,10 @@ k_scanr(const scan_args_t A)
 					/* driver lanes whose doc lacks this required term are out */
 					const uint32_t b = s_bits[lane];
 					const uint64_t ok = alive & ballot64(((b >> tok[j]) & 1) != 0);
-					if (lane_of(alive ^ ok)) {
-						s_mark[dd0] = 0;
+					if constexpr (!HASH) {
+						if (lane_of(alive ^ ok)) {
+							s_mark[dd0] = 0;
+						}
 					}
 					alive = ok;
 					WAVE_SYNC();
@@ -3288,8 +3364,15 @@ k_scanr(const scan_args_t A)
 					}
 				}
 			}
-			if (al) {
-				s_mark[dd0] = 0;
+			if constexpr (!HASH) {
+				if (al) {
+					s_mark[dd0] = 0;
+				}
+			}
+		}
+		if constexpr (HASH) {
+			if (in0) {
+				s_hdoc[hslot] = 0xffffffffu;	/* the table is empty again */
 			}
 		}
 		WAVE_SYNC();
@@ -5894,7 +5977,8 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 				total -= work[i];
 				work[i] = wr;
 				total += wr;
-				cls[i] = 3u * 64 + nt_bucket(hq[i].nt);
+				/* (four required terms and more: rounds of whole driver windows, k_scanr<.., true>) */
+			cls[i] = 3u * 64 + ((SCANR_HASH && hq[i].n_req >= 4) ? 16u : 0u) + nt_bucket(hq[i].nt);
 			}
 		}
 	}
@@ -6174,8 +6258,14 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			switch (l.nt_bucket) {
 			case 2: hipLaunchKernelGGL((k_scanr<MODE, 2>), grid, block, 0, ix->stream, a); break;
 			case 3: hipLaunchKernelGGL((k_scanr<MODE, 3>), grid, block, 0, ix->stream, a); break;
-			case 5: hipLaunchKernelGGL((k_scanr<MODE, 5>), grid, block, 0, ix->stream, a); break;
-			default: hipLaunchKernelGGL((k_scanr<MODE, 8>), grid, block, 0, ix->stream, a); break;
+			case 5:
+				if (l.nomask == 1) { hipLaunchKernelGGL((k_scanr<MODE, 5, true>), grid, block, 0, ix->stream, a); }
+				else { hipLaunchKernelGGL((k_scanr<MODE, 5>), grid, block, 0, ix->stream, a); }
+				break;
+			default:
+				if (l.nomask == 1) { hipLaunchKernelGGL((k_scanr<MODE, 8, true>), grid, block, 0, ix->stream, a); }
+				else { hipLaunchKernelGGL((k_scanr<MODE, 8>), grid, block, 0, ix->stream, a); }
+				break;
 			}
 		} else {
 #ifdef NXS_EXPERIMENTAL

@@ -350,7 +350,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
     for m in re.finditer(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count:).)*?\.name:\s+(\S+)", notes, re.S):
         agpr, name = int(m.group(1)), m.group(2)
         k8 = re.match(r"_Z7k_scan8ILi\d+ELi(\d+)ELi(\d+)EE", name)
-        kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)EE", name)
+        kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)ELb[01]EE", name)
         km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]ELb[01]EE", name)
         if k8:
             nt, mm = int(k8.group(1)), int(k8.group(2))

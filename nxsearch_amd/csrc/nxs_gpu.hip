@@ -1365,7 +1365,7 @@ k_scan(const scan_args_t A)
 #define	SCAN8_RING_MAX	2		/* prefetch ring depth of the one-window tile path */
 #endif
 #ifndef SCANR_RING
-#define	SCANR_RING	1		/* prefetch ring depth of the required-term path (1, 2, 4 measured equal) */
+#define	SCANR_RING	4		/* prefetch ring depth of the required-term path (span rounds: 1, 2, 4 measured equal; whole-window rounds rotate the driver every round: 1 -> 4 = 1.22 -> 1.19 ms per C3 step) */
 #endif
 #ifndef SCANM_RING
 #define	SCANM_RING	2		/* prefetch ring depth of the mask path */
@@ -3034,7 +3034,9 @@ k_scan1(const scan_args_t A)
 #ifndef SCANR_HASH
 #define	SCANR_HASH	1		/* a round = a whole driver window, its docs in an LDS hash table */
 #endif
+#ifndef SCANR_HT_BITS
 #define	SCANR_HT_BITS	9
+#endif
 #define	SCANR_HT	(1 << SCANR_HT_BITS)
 
 template <int MODE, int NT, bool HASHQ = false>

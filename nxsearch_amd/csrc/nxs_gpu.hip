@@ -3895,6 +3895,75 @@ rheap_add(float &hs, uint32_t &hd, uint32_t &nitems, uint32_t cap, float s, uint
 	}
 }
 
+/*
+ * The same heap once more for 64 < k <= REPLAY_LDS_K (the API's default limit is
+ * 1000), in dynamic LDS as (score, doc) PAIRS: both children of a node come with
+ * one read, and the element on the move stays in registers ("hole" form of the
+ * reference's swaps: the same comparisons, the same final array).  One level is
+ * one dependent LDS read instead of half a dozen: a heap_add on the 1000-entry
+ * heap took 2.4 us with separate score / doc arrays (global memory or LDS alike).
+ */
+#define	REPLAY_LDS_K	8000
+__device__ static inline void
+lheap_remove_min(uint2 *h, uint32_t &nitems, float &os, uint32_t &od)
+{
+	uint32_t i = 0, max_, left;
+
+	os = __uint_as_float(h[0].x);
+	od = h[0].y;
+	if ((max_ = --nitems) == 0) {
+		return;
+	}
+	const uint2 e = h[max_];			/* heap.c:146-147: the last item goes to the root ... */
+	const float ps = __uint_as_float(e.x);
+	while ((left = i * 2 + 1) < max_) {		/* ... and sinks (heap.c:149-187) */
+		const uint32_t right = left + 1;
+		const uint2 cl = h[left];
+		const uint2 cr = h[right < max_ ? right : left];
+		uint32_t smallest = i;
+		float ss = ps;
+		uint2 cs = e;
+
+		if (__uint_as_float(cl.x) < ps) {
+			smallest = left;
+			ss = __uint_as_float(cl.x);
+			cs = cl;
+		}
+		if (right < max_ && __uint_as_float(cr.x) < ss) {
+			smallest = right;
+			cs = cr;
+		}
+		if (smallest == i) {
+			break;
+		}
+		h[i] = cs;
+		i = smallest;
+	}
+	h[i] = e;
+}
+
+__device__ static inline void
+lheap_add(uint2 *h, uint32_t &nitems, uint32_t cap, float s, uint32_t d)
+{
+	uint32_t i;
+
+	if (nitems == cap) {
+		float ts; uint32_t td;
+		lheap_remove_min(h, nitems, ts, td);
+	}
+	i = nitems++;
+	while (i) {					/* heap.c:96-122 */
+		const uint32_t parent = (i - 1) / 2;
+		const uint2 pe = h[parent];
+		if (s >= __uint_as_float(pe.x)) {	/* heap.c:103 */
+			break;
+		}
+		h[i] = pe;
+		i = parent;
+	}
+	h[i] = make_uint2(__float_as_uint(s), d);
+}
+
 struct replay_args_t {
 	const qmeta_t *		qmeta;
 	uint32_t		seg_cap;	/* 0 => segments addressed by seg_off */
@@ -3936,10 +4005,17 @@ struct replay_args_t {
 	const uint32_t *	log_slot;	/* [Q] row of the log per query (NULL: q) */
 };
 
-template <bool LDS_HEAP>
+/* where the heap lives: global memory (any k), across the lanes (k <= 64), or in
+ * dynamic LDS as pairs (k <= REPLAY_LDS_K) */
+#define	HEAP_GLOBAL	0
+#define	HEAP_REG	1
+#define	HEAP_LDS	2
+template <int HEAP>
 __global__ void __launch_bounds__(WAVE)
 k_replay(const replay_args_t A)
 {
+	constexpr bool LDS_HEAP = HEAP == HEAP_REG;	/* (historic name: the k <= 64 heap) */
+	extern __shared__ uint2 dyn_heap[];		/* HEAP_LDS: [k] */
 	__shared__ uint32_t s_n;	/* (global-memory heap only) */
 	__shared__ float s_min;
 
@@ -3970,6 +4046,8 @@ k_replay(const replay_args_t A)
 	}
 	if (LDS_HEAP) {
 		cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(A.k, (uint32_t)WAVE));
+	} else if (HEAP == HEAP_LDS) {
+		cap = (uint32_t)min((uint64_t)A.k, A.heap_off[q + 1] - A.heap_off[q]);
 	} else {
 		hs = A.gheap_s + A.heap_off[q];
 		hd = A.gheap_d + A.heap_off[q];
@@ -4084,7 +4162,11 @@ k_replay(const replay_args_t A)
 					const uint32_t dv = (uint32_t)__shfl((int)dc, L);
 					if (lane == 0) {
 						uint32_t cnt = s_n;
-						heap_add(hs, hd, &cnt, cap, v, dv);
+						if constexpr (HEAP == HEAP_LDS) {
+							lheap_add(dyn_heap, cnt, cap, v, dv);
+						} else {
+							heap_add(hs, hd, &cnt, cap, v, dv);
+						}
 						if (A.log_cnt) {
 							const uint32_t row = A.log_slot ? A.log_slot[q] : q;
 							const uint32_t nl = A.log_cnt[row];
@@ -4095,7 +4177,7 @@ k_replay(const replay_args_t A)
 							A.log_cnt[row] = nl + 1;
 						}
 						s_n = cnt;
-						s_min = hs[0];
+						s_min = HEAP == HEAP_LDS ? __uint_as_float(dyn_heap[0].x) : hs[0];
 					}
 					__syncthreads();
 					nn = s_n;
@@ -4160,6 +4242,40 @@ k_replay(const replay_args_t A)
 	}
 	/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
 	const uint32_t cnt = s_n;
+	if constexpr (HEAP == HEAP_LDS) {
+		if (lane == 0) {
+			uint32_t n = cnt;
+			while (n) {
+				const uint32_t last = n - 1;
+				float ms; uint32_t mdoc;
+				lheap_remove_min(dyn_heap, n, ms, mdoc);
+				dyn_heap[last] = make_uint2(__float_as_uint(ms), mdoc);
+			}
+		}
+		__syncthreads();
+		if (A.rec_base) {
+			uint8_t *rec = A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes;
+			uint64_t *r_ids = (uint64_t *)(rec + 8);
+			float *r_sc = (float *)(rec + 8 + 8 * (size_t)A.k);
+			for (uint32_t i = lane; i < cnt; i += WAVE) {
+				r_ids[i] = A.doc_ids[dyn_heap[i].y];
+				r_sc[i] = __uint_as_float(dyn_heap[i].x);
+			}
+			if (lane == 0) {
+				((uint32_t *)rec)[0] = cnt;
+			}
+			return;
+		}
+		const uint64_t ob2 = A.out_off ? A.out_off[q] : (uint64_t)q * A.k;
+		for (uint32_t i = lane; i < cnt; i += WAVE) {
+			A.out_ids[ob2 + i] = A.doc_ids[dyn_heap[i].y];
+			A.out_sc[ob2 + i] = __uint_as_float(dyn_heap[i].x);
+		}
+		if (lane == 0) {
+			A.out_count[q] = cnt;
+		}
+		return;
+	}
 	if (lane == 0) {
 		uint32_t n = cnt;
 		while (n) {
@@ -6182,7 +6298,7 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 			}
 			a.flags = ix->cfg.drop_prio ? 1u : 0u;
 			launch_drop_class(grid, a, l.nt_bucket, ix->stream3);
-			hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream3, r);
+			hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(l.q_count), dim3(WAVE), 0, ix->stream3, r);
 			continue;
 		}
 		if (l.kind == 0) {
@@ -6289,11 +6405,11 @@ launch_scan(nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
 					(void)hipEventRecord(scans_done, ix->stream);
 					scans_done = NULL;
 				}
-				hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream, r);
+				hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(l.q_count), dim3(WAVE), 0, ix->stream, r);
 			} else {
 				(void)hipEventRecord(ix->ev_cls, ix->stream);
 				(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
-				hipLaunchKernelGGL(k_replay<true>, dim3(l.q_count), dim3(WAVE), 0, ix->stream2, r);
+				hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(l.q_count), dim3(WAVE), 0, ix->stream2, r);
 				forked = true;
 			}
 		}
@@ -6594,7 +6710,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		if (ix->cfg.one_replay) {
 			launch_scan<MODE_TOPK>(ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
-			hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+			hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
 		} else {
 			/* (profile: "replay" is then only what the last class's replay
 			 * adds after the last scan) */
@@ -6787,7 +6903,11 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 				ra.log_cap = cl->cap;
 				ra.log_slot = d_log_slot;
 			}
-			hipLaunchKernelGGL(k_replay<false>, dim3(nx), dim3(WAVE), 0, ix->stream, ra);
+			if (ra.k <= REPLAY_LDS_K) {
+				hipLaunchKernelGGL(k_replay<HEAP_LDS>, dim3(nx), dim3(WAVE), (size_t)ra.k * 8, ix->stream, ra);
+			} else {
+				hipLaunchKernelGGL(k_replay<HEAP_GLOBAL>, dim3(nx), dim3(WAVE), 0, ix->stream, ra);
+			}
 			if (hipGetLastError() != hipSuccess) {
 				set_error("kernel launch failed");
 				break;
@@ -7002,7 +7122,7 @@ nxsgpu_merge_candidates(int device, uint32_t limit, uint32_t nq, uint32_t n_shar
 		ra.out_ids = d_oid;
 		ra.out_sc = d_osc;
 		ra.out_count = d_ocnt;
-		hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, st, ra);
+		hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(nq), dim3(WAVE), 0, st, ra);
 		if (hipGetLastError() != hipSuccess ||
 		    hipMemcpyAsync(out_ids, d_oid, (size_t)nq * limit * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
 		    hipMemcpyAsync(out_scores, d_osc, (size_t)nq * limit * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -7376,7 +7496,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		if (ix->cfg.one_replay) {
 			launch_scan<MODE_TOPK>(ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
-			hipLaunchKernelGGL(k_replay<true>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+			hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
 		} else {
 			/* (profile: "replay" is then only what the last class's replay adds
 			 * after the last scan) */
@@ -8237,7 +8357,11 @@ nxsgpu_search_wide(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_wi
 		ra.out_sc = d_sc;
 		ra.out_count = d_cnt;
 		ra.out_off = d_hoff;
-		hipLaunchKernelGGL(k_replay<false>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		if (ra.k <= REPLAY_LDS_K) {
+			hipLaunchKernelGGL(k_replay<HEAP_LDS>, dim3(nq), dim3(WAVE), (size_t)ra.k * 8, ix->stream, ra);
+		} else {
+			hipLaunchKernelGGL(k_replay<HEAP_GLOBAL>, dim3(nq), dim3(WAVE), 0, ix->stream, ra);
+		}
 		x_ids.resize(tot_o);
 		x_sc.resize(tot_o);
 		if (hipGetLastError() != hipSuccess ||

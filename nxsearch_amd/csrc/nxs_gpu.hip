@@ -4093,38 +4093,11 @@ k_replay(const replay_args_t A)
 		const uint32_t total = (uint32_t)__shfl((int)incl, WAVE - 1);
 		RSTAT(n_cand += total; if (rt1 == rt0) rt1 = __builtin_amdgcn_s_memrealtime();)
 		constexpr int RU = 4;
-		for (uint32_t c0 = 0; c0 < total; c0 += WAVE * RU) {
-			float scv[RU];
-			uint32_t dcv[RU];
+		/* heap.c:68-74 on one round of RU x 64 candidates (valid: index < bound) */
+		auto consume = [&](uint32_t c0, uint32_t bound, const float (&scv)[RU], const uint32_t (&dcv)[RU]) {
 #pragma unroll
 			for (int u = 0; u < RU; u++) {
-				const uint32_t j = c0 + u * WAVE + lane;
-				scv[u] = 0.0f;
-				dcv[u] = 0;
-				/* segment lane sl = first lane with incl > j (binary search
-				 * over the lanes' inclusive sums) */
-				uint32_t sl = 0;
-#pragma unroll
-				for (int step = 32; step >= 1; step >>= 1) {
-					const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(sl + step - 1));
-					if (probe <= j) {
-						sl += step;
-					}
-				}
-				sl = min(sl, (uint32_t)WAVE - 1);
-				const uint32_t s_incl = (uint32_t)__shfl((int)incl, (int)sl);
-				const uint32_t s_cnt = (uint32_t)__shfl((int)cnt_l, (int)sl);
-				const uint64_t s_sb = ((uint64_t)(uint32_t)__shfl((int)(sb_l >> 32), (int)sl) << 32) |
-				    (uint32_t)__shfl((int)(uint32_t)sb_l, (int)sl);
-				if (j < total) {
-					const uint64_t at = s_sb + (j - (s_incl - s_cnt));
-					scv[u] = A.cand_sc[at];
-					dcv[u] = A.cand_doc ? A.cand_doc[at] : (uint32_t)at;
-				}
-			}
-#pragma unroll
-			for (int u = 0; u < RU; u++) {
-				const bool valid = c0 + u * WAVE + lane < total;
+				const bool valid = c0 + u * WAVE + lane < bound;
 				const float sc = scv[u];
 				const uint32_t dc = dcv[u];
 				/* heap.c:68-74: when full, an item <= the root is dropped
@@ -4186,6 +4159,72 @@ k_replay(const replay_args_t A)
 					pend &= ballot64(valid && (nn < cap || sc > mn));
 				}
 			}
+		};
+		if constexpr (!LDS_HEAP) {
+			/*
+			 * The exact passes (limit > 64) stream EVERY match of the query through
+			 * here, thousands per segment: segment by segment, plain coalesced loads.
+			 * (Packing the candidates of 64 segments by a prefix sum -- below, what
+			 * the top-k pass needs for its many near-empty segments -- costs a 6-step
+			 * cross-lane search per 64 candidates: 28 of the 30 ms of a default-limit
+			 * batch.)
+			 */
+			uint64_t nonempty = ballot64(cnt_l != 0);
+			while (nonempty) {
+				const int sl = __builtin_ctzll(nonempty);
+				nonempty &= nonempty - 1;
+				const uint32_t scnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, sl);
+				const uint64_t ssb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(sb_l >> 32), sl) << 32) |
+				    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sb_l, sl);
+				for (uint32_t c0 = 0; c0 < scnt; c0 += WAVE * RU) {
+					float scv[RU];
+					uint32_t dcv[RU];
+#pragma unroll
+					for (int u = 0; u < RU; u++) {
+						const uint32_t j = c0 + u * WAVE + lane;
+						scv[u] = 0.0f;
+						dcv[u] = 0;
+						if (j < scnt) {
+							const uint64_t at = ssb + j;
+							scv[u] = A.cand_sc[at];
+							dcv[u] = A.cand_doc ? A.cand_doc[at] : (uint32_t)at;
+						}
+					}
+					consume(c0, scnt, scv, dcv);
+				}
+			}
+			continue;
+		}
+		for (uint32_t c0 = 0; c0 < total; c0 += WAVE * RU) {
+			float scv[RU];
+			uint32_t dcv[RU];
+#pragma unroll
+			for (int u = 0; u < RU; u++) {
+				const uint32_t j = c0 + u * WAVE + lane;
+				scv[u] = 0.0f;
+				dcv[u] = 0;
+				/* segment lane sl = first lane with incl > j (binary search
+				 * over the lanes' inclusive sums) */
+				uint32_t sl = 0;
+#pragma unroll
+				for (int step = 32; step >= 1; step >>= 1) {
+					const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(sl + step - 1));
+					if (probe <= j) {
+						sl += step;
+					}
+				}
+				sl = min(sl, (uint32_t)WAVE - 1);
+				const uint32_t s_incl = (uint32_t)__shfl((int)incl, (int)sl);
+				const uint32_t s_cnt = (uint32_t)__shfl((int)cnt_l, (int)sl);
+				const uint64_t s_sb = ((uint64_t)(uint32_t)__shfl((int)(sb_l >> 32), (int)sl) << 32) |
+				    (uint32_t)__shfl((int)(uint32_t)sb_l, (int)sl);
+				if (j < total) {
+					const uint64_t at = s_sb + (j - (s_incl - s_cnt));
+					scv[u] = A.cand_sc[at];
+					dcv[u] = A.cand_doc ? A.cand_doc[at] : (uint32_t)at;
+				}
+			}
+			consume(c0, total, scv, dcv);
 		}
 	}
 	__syncthreads();

@@ -206,6 +206,10 @@ struct nxsgpu_index {
 	int		device;
 	gpu_cfg_t	cfg;
 	hipStream_t	stream;
+	/* exact two-pass path: its device buffers are kept between calls (grow-only,
+	 * up to X_KEEP_MAX: hipMalloc + hipFree of a few hundred MB cost milliseconds) */
+	void *		xbuf[2];
+	size_t		xbuf_len[2];
 	hipStream_t	xstream[3];	/* the blocking search (nxsgpu_search: re-runs of overflowed queries,
 					 * limits > 64) takes these in place of stream / stream2 / stream3
 					 * while batches are in flight: beside them, not queued behind
@@ -5198,6 +5202,35 @@ bk_aux_build(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n)
 	return 0;
 }
 
+#define	X_KEEP_MAX	(4ull << 30)
+/* buffer `which` of the exact path, at least `need` bytes (NULL: out of memory) */
+static void *
+xbuf_get(nxsgpu_index_t *ix, int which, size_t need)
+{
+	if (ix->xbuf_len[which] < need) {
+		(void)hipFree(ix->xbuf[which]);
+		ix->xbuf[which] = NULL;
+		ix->xbuf_len[which] = 0;
+		const size_t len = need + need / 8;
+		if (hipMalloc(&ix->xbuf[which], len) != hipSuccess) {
+			return NULL;
+		}
+		ix->xbuf_len[which] = len;
+	}
+	return ix->xbuf[which];
+}
+
+/* after the pass: an oversized buffer is not kept */
+static void
+xbuf_put(nxsgpu_index_t *ix, int which)
+{
+	if (ix->xbuf_len[which] > X_KEEP_MAX) {
+		(void)hipFree(ix->xbuf[which]);
+		ix->xbuf[which] = NULL;
+		ix->xbuf_len[which] = 0;
+	}
+}
+
 static bool
 ensure_ws(nxsgpu_index_t *ix, size_t need)
 {
@@ -5329,6 +5362,8 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 			(void)hipStreamDestroy(ix->xstream[i]);
 		}
 	}
+	(void)hipFree(ix->xbuf[0]);
+	(void)hipFree(ix->xbuf[1]);
 	if (ix->ev_fork3) {
 		(void)hipEventDestroy(ix->ev_fork3);
 	}
@@ -6833,7 +6868,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			const size_t mneed = 8192 + nx * sizeof(dev_query_t) + nx * sizeof(qmeta_t)
 			    + xseg * sizeof(item_t) + xseg * 4
 			    + (xseg + nx) * 4 * (1 + NXSGPU_MAX_TOKENS);
-			if (hipMalloc(&xmeta, mneed) != hipSuccess) {
+			if ((xmeta = xbuf_get(ix, 0, mneed)) == NULL) {
 				set_error("hipMalloc(%zu) for the exact pass failed", mneed);
 				return -1;
 			}
@@ -6852,7 +6887,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(dx_bnd_q, xwl.bnd_q.data(), (xseg + nx) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
 			set_error("query upload failed");
-			(void)hipFree(xmeta);
 			return -1;
 		}
 		sa.queries = dx_q;
@@ -6866,7 +6900,6 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {
 			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
-			(void)hipFree(xmeta);
 			return -1;
 		}
 		for (uint64_t sgi = 0; sgi < xseg; sgi++) {
@@ -6881,9 +6914,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		}
 		const uint64_t tot_c = sc_off[xseg], tot_o = o_off[nx];
 		xneed = 8192 + (xseg + 1) * 8 + tot_c * 8 + tot_o * 8 * 2 + tot_o * 12 + (nx + 1) * 16 + nx * 4;
-		if (hipMalloc(&xws, xneed) != hipSuccess) {
+		if ((xws = xbuf_get(ix, 1, xneed)) == NULL) {
 			set_error("hipMalloc(%zu) for the exact pass failed", xneed);
-			(void)hipFree(xmeta);
 			return -1;
 		}
 		xp = (uint8_t *)xws;
@@ -6960,8 +6992,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			}
 			rc = 0;
 		} while (0);
-		(void)hipFree(xws);
-		(void)hipFree(xmeta);
+		xbuf_put(ix, 0);
+		xbuf_put(ix, 1);
 		if (rc != 0) {
 			return -1;
 		}

@@ -191,10 +191,35 @@ def main():
     n_total = args.batch if strong else args.batch * world
     queries = make_queries(args, terms, n_total, corpus)
     fuzzy_on = args.workload in ("C4", "C5")
+    sharded, shard_err = False, None
     if world > 1 or os.environ.get("NXS_BENCH_FORCE_SHARD"):
         # (FORCE_SHARD: rehearse the sharded path -- RCCL communicator, all-gather of the
         # record blocks -- on a one-GPU box)
-        multi.attach(nxs, idx, rank, world, dist, dev)
+        ok = 1
+        try:
+            if os.environ.get("NXS_BENCH_FAIL_SHARD"):      # rehearse the safety net below
+                raise RuntimeError("NXS_BENCH_FAIL_SHARD")
+            multi.attach(nxs, idx, rank, world, dist, dev)
+        except Exception as e:
+            ok, shard_err = 0, "%s: %s" % (type(e).__name__, e)
+        if dist is not None:
+            t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok.item())
+        sharded = ok == 1
+        if not sharded:
+            # Safety net: the communicator could not be built (on some rank).  The ranks still
+            # split the batch by query -- each runs ITS slice on its replica -- but nothing is
+            # gathered; `config.parallelism` says so.  The scaling curve is then the library's
+            # without its one collective.
+            sys.stderr.write("bench.py: rank %d: sharding unavailable (%s): every rank runs its own "
+                             "slice, no collective\n" % (rank, shard_err))
+            try:
+                idx.shard(0, 1, None)                       # detach if this rank did attach
+            except Exception:
+                pass
+            lo, hi = multi.shard_slice(n_total, rank, world)
+            queries = queries[lo:hi]
     qarr = c_strings(queries)
     params = N._make_params(args.limit, "BM25", fuzzy_on)
 
@@ -240,7 +265,7 @@ def main():
 
     # ---- roofline of the dominant kernels (the scan launches) on this rank ----
     launches = max(prof["launches"], 1)
-    my_share = 1.0 / world if world > 1 else 1.0            # records of all ranks are read back
+    my_share = 1.0 / world if (world > 1 and sharded) else 1.0     # records of all ranks are read back
     matched = res.results / max(args.steps, 1) * my_share
     alg_bytes = prof["postings"] * POSTING_BYTES / launches + matched * RESULT_BYTES
     # first scan launch -> every class scanned and replayed (classes overlap: the
@@ -276,8 +301,10 @@ def main():
                    "postings": info["postings"],
                    "boundary": "nxs_index_search_batch_begin/_end: query strings in, nxs_resp_t out, "
                                "two batches in flight",
-                   "parallelism": "query-sharded x%d, index replicated, one RCCL all-gather of "
-                                  "record blocks per step" % world if world > 1 else
+                   "parallelism": ("query-sharded x%d, index replicated, one RCCL all-gather of "
+                                   "record blocks per step" % world) if (world > 1 and sharded) else
+                                  ("query-sharded x%d, index replicated, NO collective (the RCCL communicator "
+                                   "could not be built: %s)" % (world, shard_err)) if world > 1 else
                                   "one GPU, no collective"},
         "roofline": roofline,
         "host_ms_per_step": host_prof,

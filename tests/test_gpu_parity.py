@@ -719,6 +719,15 @@ def test_default_limit_batch_on_a_larger_corpus(nxs, tmp_path):
     assert any(len(g) == 1000 for g in got)
     for q in qs[:4]:
         assert_same(gidx.search(q), oidx.search(q), q)
+    # the three homes of the replay's heap: across the lanes (limit <= 64), pairs in
+    # LDS (65..8000), global memory beyond -- a limit of 20000 on queries with more
+    # matches than that
+    big = [q for q, g in zip(qs, got) if len(g) == 1000][:3]
+    for limit in (64, 65, 8000, 8001, 20000):
+        res = gidx.search_batch(big, limit=limit, fuzzymatch=False)
+        for q, g in zip(big, res):
+            assert_same(g, oidx.search(q, limit=limit, fuzzymatch=False), (q, limit))
+    assert any(len(g) > 8001 for g in res)
     gidx.close()
 
 

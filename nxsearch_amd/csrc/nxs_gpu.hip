@@ -3836,7 +3836,9 @@ rh_set(float &hs, uint32_t &hd, uint32_t i, float s, uint32_t d)
 	const int dv = __builtin_amdgcn_readfirstlane((int)d);
 	const int li = __builtin_amdgcn_readfirstlane((int)i);
 	/* (one SGPR per VOP3 instruction on this target: the lane select goes through M0) */
-	asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+	/* (s_nop: inline asm is outside the compiler's hazard recogniser; a scalar write
+	 * of the lane select right in front of its vector use costs one idle cycle) */
+	asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
 	    : "+v"(hs), "+v"(hd) : "s"(sv), "s"(li), "s"(dv) : "m0");
 }
 #pragma clang diagnostic pop

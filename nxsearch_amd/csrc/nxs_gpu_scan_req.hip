@@ -1,0 +1,974 @@
+/*
+ * nxs_gpu_scan_req.hip -- k_cursors, k_scan1 (single token), k_scanr (required terms: intersect first), k_scanh (opt-in)
+ * (MI355X / gfx950 query path of nxsearch; see nxs_gpu_int.h for the map of the files)
+ */
+#include "nxs_gpu_int.h"
+#include "nxs_gpu_dev.h"
+
+/*
+ * k_cursors: where every (query, range boundary) falls in every term's list.
+ * Boundary b of query q is doc b * group_docs; wavefront g of the query then
+ * owns postings [cur[g][t], cur[g+1][t]).  One thread per (boundary, token):
+ * a plain binary search -- ~24 cache lines each, the top levels shared by all
+ * boundaries of a list -- done once per batch instead of by every wavefront.
+ */
+__global__ void
+k_cursors(const posting_t *__restrict__ post, const dev_query_t *__restrict__ queries,
+    const qmeta_t *__restrict__ qmeta, const uint32_t *__restrict__ bnd_q,
+    uint32_t n_bnd, uint64_t n_docs, uint32_t *__restrict__ cursors)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t b = i / NXSGPU_MAX_TOKENS, t = i % NXSGPU_MAX_TOKENS;
+	if (b >= n_bnd) {
+		return;
+	}
+	const uint32_t q = bnd_q[b];
+	const qmeta_t qm = qmeta[q];
+	const dev_query_t *Q = &queries[q];
+	if (t >= Q->nt) {
+		return;
+	}
+	const uint32_t g = b - (qm.seg_first + q);
+	const uint64_t doc = min((uint64_t)g * qm.group_docs, n_docs);
+	const uint64_t pb = Q->pbeg[t], pe = Q->pend[t];
+	uint64_t lo = pb, hi = pe;
+	if (doc >= n_docs) {
+		lo = pe;
+	} else if (doc == 0) {
+		lo = pb;
+	} else {
+		while (lo < hi) {
+			const uint64_t mid = lo + ((hi - lo) >> 1);
+			if (post[mid].doc < doc) lo = mid + 1; else hi = mid;
+		}
+	}
+	cursors[(uint64_t)b * NXSGPU_MAX_TOKENS + t] = (uint32_t)(lo - pb);
+}
+
+/*
+ * k_scan1: single-token queries.  A doc's score is the posting's own impact
+ * and it matches iff the one-token mask satisfies the expression, so nothing
+ * is accumulated: the wavefront streams its slice of the list downwards, U
+ * windows (U x 512 B) in flight, and compares impacts with the running
+ * threshold in registers.  No LDS: full occupancy.
+ */
+template <int MODE>
+__global__ void __launch_bounds__(WAVE)
+k_scan1(const scan_args_t A)
+{
+	constexpr int U = 4;
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
+	const bool matches = Q->nt == 1 && ((Q->truth[0] >> 1) & 1);
+	const posting_t *__restrict__ pt = A.post + Q->pbeg[0];
+	const int32_t n = Q->nt ? (int32_t)(Q->pend[0] - Q->pbeg[0]) : 0;
+	int32_t lo = 0, hi = 0;
+	uint32_t n_out = 0;
+	bool ovf = false;
+
+	if (matches) {
+		(void)dlo; (void)dhi;
+		if (qm.pad) {
+			/* ranges by posting index (no cursors): range g of G = [n g / G, n (g+1) / G) */
+			lo = (int32_t)((uint64_t)n * g / qm.n_groups);
+			hi = (int32_t)((uint64_t)n * (g + 1) / qm.n_groups);
+		} else {
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS;
+			lo = (int32_t)A.cursors[cb];
+			hi = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+		}
+	}
+	if (MODE == MODE_COUNT) {
+		if (lane == 0) {
+			A.seg_count[seg] = (uint32_t)(hi - lo);
+		}
+		return;
+	}
+
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	while (hi > lo) {
+		uint32_t dv[U];
+		float iv[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int32_t idx = hi - (u + 1) * WAVE + (int32_t)lane;
+			dv[u] = 0;
+			iv[u] = -INFINITY;
+			if (idx >= lo) {
+				const posting_t p = pt[idx];
+				dv[u] = p.doc;
+				iv[u] = p.imp;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			/* window u: descending doc = descending lane */
+			const bool cand = iv[u] > thr;
+			uint64_t bal = ballot64(cand);
+			if (!bal) {
+				continue;
+			}
+			const uint32_t ne = __popcll(bal);
+			if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+				ovf = true;
+			} else {
+				const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+				if (cand) {
+					const uint64_t o = out_base + n_out + __popcll(above);
+					A.cand_doc[o] = dv[u];
+					A.cand_sc[o] = iv[u];
+				}
+			}
+			n_out += ne;
+			if (track) {
+				while (bal) {
+					const int L = 63 - __clzll(bal);
+					bal &= ~(1ull << L);
+					const float v = __shfl(iv[u], L);
+					if (v > thr) {
+						const uint32_t pos = __popcll(ballot64(top >= v));
+						const float up = __shfl_up(top, 1);
+						top = (lane < pos) ? top : (lane == pos ? v : up);
+						thr = fmaxf(__shfl(top, kidx), hint);
+					}
+				}
+			}
+		}
+		hi -= U * WAVE;
+	}
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+/*
+ * k_scanr: queries with required terms (`req` != 0: a doc can only match if
+ * it holds every one of them), 2..8 tokens -- the conjunctive shapes.  The
+ * reference intersects the terms' doc bitmaps before it scores anything
+ * (search.c:118-174); this is the same idea on posting windows:
+ *
+ *  - slot 0 is the DRIVER: the required term with the fewest postings.  The
+ *    other slots follow in ascending list length, required ones first
+ *    (dev_query_t::slot_tok, host side);
+ *  - a round takes the driver's unconsumed postings that fall into one
+ *    RW-doc aligned span (at most one 64-posting window), marks their docs
+ *    in an LDS byte map (value = driver lane + 1) and then lets the other
+ *    slots look their own postings of that span up in the map.  A hit hands
+ *    the posting's impact and presence bit to the driver lane's slot
+ *    (s_imp / s_bits); there is no accumulator tile at all;
+ *  - after each required slot the driver lanes that did not get its bit are
+ *    unmarked.  When no lane is left the round is over: denser slots are not
+ *    looked at, and what they hold above the driver's next posting is dropped
+ *    unread at the start of the next round (mask, stream, or jump by a window
+ *    probe / 64-ary search) -- their postings are mostly never loaded;
+ *  - surviving lanes sum their slots' impacts in token order (the f32 order of
+ *    results.c:134-136), test the truth table and go through the same
+ *    threshold filter / candidate emission as the other scan kernels; lanes
+ *    are in ascending doc order, so emission is by descending lane.
+ */
+#ifndef RW
+#define	RW	4096		/* docs per round span (LDS byte map; SCANR_HASH 0) */
+#endif
+#ifndef SCANR_HT_BITS
+#define	SCANR_HT_BITS	9
+#endif
+#define	SCANR_HT	(1 << SCANR_HT_BITS)
+
+template <int MODE, int NT, bool HASHQ = false>
+__global__ void __launch_bounds__(WAVE)
+k_scanr(const scan_args_t A)
+{
+	/*
+	 * HASH (queries with four required terms and more): a round takes the driver's WHOLE
+	 * window, whatever doc span it covers, and keeps its docs in an open-addressing
+	 * table (doc -> driver lane + 1) instead of a byte map over RW docs.  A sparse
+	 * driver has a posting every few hundred docs: spans of RW docs held ~11 of
+	 * them and a round's fixed scalar cost was paid 5-6 times per window.  A probe
+	 * costs more than a byte-map read, though: where most of the work is looking
+	 * the second list's postings up (2.1 -> 3.8 ms for 2-term ANDs, 0.99 -> 1.71
+	 * for 3-term ones) the spans stay; with more required terms the later, denser
+	 * lists are mostly never looked at and the rounds dominate (5-term AND 0.595
+	 * -> 0.508 ms).  Decided per query on the host (the class key), compiled in
+	 * per instantiation: with both forms in one kernel the 5-term AND took 0.65 ms.
+	 */
+	constexpr bool HASH = HASHQ;
+	__shared__ uint32_t s_hdoc[HASH ? SCANR_HT : 1];
+	__shared__ uint8_t s_hlane[HASH ? SCANR_HT : 1];
+	__shared__ uint8_t s_mark[HASH ? 1 : RW + WAVE];	/* + one always-zero dummy slot per lane */
+	__shared__ uint8_t s_bits[WAVE];		/* presence mask of the driver lane's doc */
+	__shared__ float s_imp[NT][WAVE];		/* [token][driver lane] */
+	__shared__ uint32_t s_truth[8];
+
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint32_t n_req = Q->n_req;		/* slots [0, n_req) are required */
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+
+	if constexpr (HASH) {
+		for (uint32_t i = lane; i < SCANR_HT; i += WAVE) {
+			s_hdoc[i] = 0xffffffffu;
+		}
+	} else {
+		for (uint32_t i = lane; i < RW + WAVE; i += WAVE) {
+			s_mark[i] = 0;
+		}
+	}
+	auto hash_of = [](uint32_t doc) -> uint32_t {
+		return (doc * 2654435761u) >> (32 - SCANR_HT_BITS);
+	};
+	s_bits[lane] = 0;
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	WAVE_SYNC();
+
+	/* wave-uniform per-slot state as in k_scan8 (one window per set) */
+	const posting_t *pt[NT];
+	int32_t ab[NT], lo[NT], pdoc[NT];
+	uint32_t tok[NT];
+	uint64_t vm[NT];
+	constexpr int RING = SCANR_RING;
+	uint32_t rp[NT];		/* ring position of the oldest window in flight */
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		rp[t] = 0;
+	}
+	uint32_t Ad[NT];		/* set A; the windows in flight live in AGPRs (bpair_*) */
+	float Ai[NT];
+
+	auto window_mask = [](int32_t wb, int32_t lo_, int32_t hi_) -> uint64_t {
+		const int32_t a = max(lo_ - wb, 0), e = min(hi_ - wb, WAVE);
+		if (e <= a) {
+			return 0;
+		}
+		const uint64_t upto = e >= WAVE ? ~0ull : ((1ull << e) - 1);
+		return upto & ~((1ull << a) - 1);
+	};
+	auto refresh_pdoc = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = vm[t] ? __builtin_amdgcn_readlane((int)Ad[t], 63 - __builtin_clzll(vm[t])) : -1;
+	};
+	auto load_sets = [&](auto tc, int32_t hi_) {
+		constexpr int t = decltype(tc)::value;
+		pdoc[t] = -1;
+		ab[t] = 0;
+		vm[t] = 0;
+		if (hi_ > lo[t]) {
+			ab[t] = ((hi_ - 1) >> 6) << 6;
+			const int32_t ia = max(ab[t] + (int32_t)lane, lo[t]);
+			const int32_t ib = max(ab[t] - WAVE + (int32_t)lane, lo[t]);
+			const posting_t pa = pt[t][min(ia, hi_ - 1)];
+			Ad[t] = pa.doc; Ai[t] = pa.imp;
+			(void)ib;
+			/* the RING windows below set A, oldest first (bring_take) */
+			static_for<RING>([&](auto rc) {
+				constexpr int r = decltype(rc)::value;
+				const int32_t ir = max(ab[t] - (r + 1) * WAVE + (int32_t)lane, lo[t]);
+				bpair_request<t * RING + r>(&pt[t][min(ir, hi_ - 1)]);
+			});
+			rp[t] = 0;
+			vm[t] = window_mask(ab[t], lo[t], hi_);
+			refresh_pdoc(tc);
+		}
+	};
+	/* set A is drained: wait for the oldest window in flight, take it over,
+	 * request the window RING below it */
+	auto rotate_sets = [&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		ab[t] -= WAVE;
+		vm[t] = window_mask(ab[t], lo[t], 0x7fffffff);
+		const posting_t *np = &pt[t][max(ab[t] - RING * WAVE + (int32_t)lane, lo[t])];
+		bring_take<t, RING>(rp[t], RING - 1, Ad[t], Ai[t], np);
+		rp[t] = (rp[t] + 1) & (RING - 1);
+	};
+
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		int32_t hi0 = 0;
+		pt[t] = A.post;
+		lo[t] = 0;
+		tok[t] = 0;
+		if (t < (int)nt) {
+			tok[t] = Q->slot_tok[t];
+			pt[t] = A.post + Q->pbeg[tok[t]];
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + tok[t];
+			lo[t] = (int32_t)A.cursors[cb];
+			hi0 = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+		}
+		load_sets(tc, hi0);
+	});
+
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	bool done = false;		/* a required slot ran out: nothing below can match */
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	while (!done && pdoc[0] >= 0) {
+		const int32_t dtop = pdoc[0];
+		const uint32_t base = HASH ? 0u : (uint32_t)dtop & ~(uint32_t)(RW - 1);
+		/* the driver's postings of this round: its whole window (HASH), or those
+		 * of one RW-doc span */
+		const uint64_t inm0 = HASH ? vm[0] : (vm[0] & ballot64(Ad[0] >= base));
+		const bool in0 = lane_of(inm0);
+		const uint32_t dd0 = in0 ? Ad[0] - base : RW + lane;	/* (byte map) */
+		uint32_t hslot = 0;
+		if constexpr (HASH) {
+			/* insert: claim an empty slot, verify, move on (no atomics: the lanes
+			 * of one LDS instruction are serialised, exactly one claim survives) */
+			uint32_t h = hash_of(Ad[0]);
+			uint64_t todo = inm0;
+			while (todo) {
+				const bool mine = lane_of(todo);
+				if (mine && s_hdoc[h] == 0xffffffffu) {
+					s_hdoc[h] = Ad[0];
+				}
+				WAVE_SYNC();
+				const bool got = mine && s_hdoc[h] == Ad[0];
+				if (got) {
+					s_hlane[h] = (uint8_t)(lane + 1);
+					hslot = h;
+				}
+				if (mine && !got) {
+					h = (h + 1) & (SCANR_HT - 1);
+				}
+				todo &= ~ballot64(got);
+				WAVE_SYNC();
+			}
+		}
+		const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)Ad[0], __builtin_ctzll(inm0));
+		uint64_t alive = inm0;
+
+		vm[0] ^= inm0;
+		if constexpr (!HASH) {
+			s_mark[dd0] = in0 ? (uint8_t)(lane + 1) : (uint8_t)0;
+		}
+		s_bits[lane] = (uint8_t)(1u << tok[0]);
+		s_imp[tok[0]][lane] = Ai[0];
+		WAVE_SYNC();
+
+		static_for<NT - 1>([&](auto jc) {
+			constexpr int j = decltype(jc)::value + 1;
+			using JC = std::integral_constant<int, j>;
+			if (j < (int)nt && alive && !done) {
+				/* nothing above the driver's top doc can match: drop it unread */
+				if (pdoc[j] > dtop) {
+					for (int tries = 0; ; tries++) {
+						vm[j] &= ~ballot64(Ad[j] > (uint32_t)dtop);
+						if (vm[j] || ab[j] <= lo[j]) {
+							break;		/* the boundary is in this window / list exhausted */
+						}
+						if (tries < 2) {
+							rotate_sets(JC());	/* stream a little ... */
+							continue;
+						}
+						/* ... then jump: lane l probes the first posting of the
+						 * l-th window below; the boundary is in the first one
+						 * that starts at or below the driver's doc */
+						const int32_t li = ab[j];	/* postings [lo, li) are unseen */
+						const int32_t pi = max(li - (int32_t)(lane + 1) * WAVE, lo[j]);
+						const uint32_t pv = pt[j][pi].doc;
+						const uint64_t pm = ballot64(pv <= (uint32_t)dtop);
+						int32_t nh;
+						if (pm) {
+							nh = min(li, max(li - (int32_t)__builtin_ctzll(pm) * WAVE, lo[j] + 1));
+						} else {
+							const int32_t far = max(li - WAVE * WAVE, lo[j]);
+							nh = far > lo[j] ? wave_lower_bound(pt[j], lo[j], far, (uint32_t)dtop + 1) : lo[j];
+						}
+						load_sets(JC(), nh);
+						tries = 2;
+						if (nh <= lo[j]) {
+							break;
+						}
+					}
+					refresh_pdoc(JC());
+				}
+				if (pdoc[j] < 0 && j < (int)n_req) {
+					done = true;
+				}
+				if (pdoc[j] >= (int32_t)rlo) {
+					/* look this slot's postings of the span up in the map */
+					const uint32_t tj = tok[j];
+					uint64_t left = vm[j];
+					for (;;) {
+						const uint64_t inm = left & ballot64(Ad[j] >= rlo);
+						left ^= inm;
+						if (inm) {
+							uint32_t m = 0;
+							if constexpr (HASH) {
+								uint32_t h = hash_of(Ad[j]);
+								uint64_t todo = inm;
+								while (todo) {
+									const bool mine = lane_of(todo);
+									const uint32_t v = s_hdoc[h];
+									const bool hit = mine && v == Ad[j];
+									const bool miss = mine && v == 0xffffffffu;
+									if (hit) {
+										m = s_hlane[h];
+									}
+									h = (h + 1) & (SCANR_HT - 1);
+									todo &= ~ballot64(hit || miss);
+								}
+							} else {
+								const bool inl = lane_of(inm);
+								const uint32_t dd = inl ? Ad[j] - base : RW + lane;
+								m = s_mark[dd];
+							}
+							if (ballot64(m != 0)) {
+								if (m != 0) {
+									s_imp[tj][m - 1] = Ai[j];
+									s_bits[m - 1] = (uint8_t)(s_bits[m - 1] | (1u << tj));
+								}
+							}
+						}
+						if (left == 0 && ab[j] > lo[j]) {
+							rotate_sets(JC());
+							left = vm[j];
+							continue;
+						}
+						break;
+					}
+					vm[j] = left;
+					refresh_pdoc(JC());
+					WAVE_SYNC();
+				}
+				if (j < (int)n_req) {
+					/* driver lanes whose doc lacks this required term are out */
+					const uint32_t b = s_bits[lane];
+					const uint64_t ok = alive & ballot64(((b >> tok[j]) & 1) != 0);
+					if constexpr (!HASH) {
+						if (lane_of(alive ^ ok)) {
+							s_mark[dd0] = 0;
+						}
+					}
+					alive = ok;
+					WAVE_SYNC();
+				}
+			}
+		});
+
+		if (alive) {
+			const bool al = lane_of(alive);
+			const uint32_t mask = al ? s_bits[lane] : 0;
+			const bool match = al && ((s_truth[mask >> 5] >> (mask & 31)) & 1);
+			if (MODE == MODE_COUNT) {
+				n_out += __popcll(ballot64(match));
+			} else {
+				float sc = 0.0f;
+				/* token order (results.c:134-136) */
+#pragma unroll
+				for (int k = 0; k < NT; k++) {
+					if ((mask >> k) & 1) {
+						sc += s_imp[k][lane];
+					}
+				}
+				const bool cand = match && (MODE == MODE_ALL || sc > thr);
+				uint64_t bal = ballot64(cand);
+				if (bal) {
+					const uint32_t ne = __popcll(bal);
+					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+						ovf = true;
+					} else {
+						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
+						if (cand) {
+							const uint64_t o = out_base + n_out + __popcll(above);
+							A.cand_doc[o] = Ad[0];
+							A.cand_sc[o] = sc;
+						}
+					}
+					n_out += ne;
+					if (track) {
+						while (bal) {
+							const int L = 63 - __clzll(bal);
+							bal &= ~(1ull << L);
+							const float v = __shfl(sc, L);
+							if (v > thr) {
+								const uint32_t pos = __popcll(ballot64(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = fmaxf(__shfl(top, kidx), hint);
+							}
+						}
+					}
+				}
+			}
+			if constexpr (!HASH) {
+				if (al) {
+					s_mark[dd0] = 0;
+				}
+			}
+		}
+		if constexpr (HASH) {
+			if (in0) {
+				s_hdoc[hslot] = 0xffffffffu;	/* the table is empty again */
+			}
+		}
+		WAVE_SYNC();
+
+		if (vm[0] == 0 && ab[0] > lo[0]) {
+			rotate_sets(std::integral_constant<int, 0>());
+		}
+		refresh_pdoc(std::integral_constant<int, 0>());
+	}
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));
+	}
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
+#ifdef NXS_EXPERIMENTAL	/* opt-in build: measured not faster than the tiles (DESIGN.md "dead ends") */
+/*
+ * k_scanh: the posting-step path for queries without a very dense term.
+ *
+ * Every term streams its list through register sets as in k_scan8.  A STEP
+ * picks base = the largest, over the terms, of the lowest doc still held in
+ * the term's set A.  All unconsumed postings with doc >= base are then in
+ * registers, for every term: the term that defines base drains its whole set
+ * (so a query needs at most sum_t ceil(df_t / 64K) steps, however sparse it
+ * is), the others contribute the part of their set above base.  The docs of a
+ * step can span far more than an LDS tile, so scores accumulate in a small
+ * LDS hash table keyed by doc (slot = low doc bits, linear probing, claims are
+ * written then verified -- no atomics).  Terms are applied in token order, so
+ * a doc's f32 sum order is the reference's (results.c:134-136).  Claimed slots
+ * go to a list: the table is scanned and wiped through it.  Steps run in
+ * descending doc ranges and a step's candidates are rank-sorted by doc, so the
+ * segment is in descending doc order like k_scan8's.
+ */
+template <int MODE, int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scanh(const scan_args_t A)
+{
+	constexpr int KSH = NT <= 2 ? 2 : NT <= 3 ? 1 : 0;
+	constexpr int K = 1 << KSH;
+	constexpr int SW = WAVE * K;
+	constexpr int MAXE = WAVE * K * NT;		/* table entries per step */
+	constexpr int TAB = MAXE <= 256 ? 512 : 1024;	/* load factor <= 1/2 */
+	constexpr uint32_t EMPTY = 0xffffffffu;
+
+	__shared__ uint32_t s_key[TAB];
+	__shared__ float s_val[TAB];
+	__shared__ uint8_t s_msk[TAB];
+	__shared__ uint16_t s_list[MAXE];
+	__shared__ uint32_t s_cd[MAXE];
+	__shared__ float s_cs[MAXE];
+	__shared__ uint32_t s_truth[8];
+	__shared__ int64_t s_init[16];
+
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint64_t dlo = (uint64_t)g * qm.group_docs;
+	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
+
+	for (uint32_t i = lane; i < TAB; i += WAVE) {
+		s_key[i] = EMPTY;
+		s_val[i] = 0.0f;
+		s_msk[i] = 0;
+	}
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	if (lane < 16) {
+		const uint32_t t = lane & 7;
+		int64_t v = 0;
+		if (t < nt) {
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
+			(void)dlo; (void)dhi;
+			v = (int64_t)A.cursors[cb + (lane < 8 ? NXSGPU_MAX_TOKENS : 0)];
+		}
+		s_init[lane] = v;
+	}
+	WAVE_SYNC();
+
+	/* wave-uniform per-term state */
+	const posting_t *pt[NT];
+	int32_t hi[NT], lo[NT], pdoc[NT], lowdoc[NT];
+	uint32_t Ad[NT][K], Bd[NT][K];
+	float Ai[NT][K], Bi[NT][K];
+
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		pt[t] = A.post;
+		hi[t] = lo[t] = 0;
+		pdoc[t] = lowdoc[t] = -1;
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			Ad[t][k] = Bd[t][k] = 0;
+			Ai[t][k] = Bi[t][k] = 0.0f;
+		}
+		if (t < (int)nt) {
+			pt[t] = A.post + Q->pbeg[t];
+			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
+			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
+			if (hi[t] > lo[t]) {
+				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+#pragma unroll
+				for (int k = 0; k < K; k++) {
+					const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
+					if (ia >= lo[t] && ia < hi[t]) {
+						const posting_t p = pt[t][ia];
+						Ad[t][k] = p.doc; Ai[t][k] = p.imp;
+					}
+					if (ib >= lo[t]) {
+						const posting_t p = pt[t][ib];
+						Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+					}
+				}
+				const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+				for (int k = 0; k < K; k++) {
+					if (k == kt) {
+						pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+					}
+				}
+				/* lowest doc held in set A, or -1 if the set reaches the
+				 * start of this range's postings */
+				if (ab > lo[t]) {
+					lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
+				}
+			}
+		}
+	}
+
+	float top = -INFINITY;
+	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	float thr = hint;
+	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
+	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
+
+	for (;;) {
+		int32_t md = -1, bs = -1;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			md = max(md, pdoc[t]);
+			bs = max(bs, lowdoc[t]);
+		}
+		if (md < 0) {
+			break;		/* every list is consumed */
+		}
+		const uint32_t base = bs < 0 ? 0u : (uint32_t)bs;
+		uint32_t n_list = 0;
+		float tmax = -INFINITY;
+
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
+				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
+				uint32_t ctot = 0;
+				bool more = true;
+#pragma unroll
+				for (int k = K - 1; k >= 0; k--) {
+					if (more && hi[t] > ab + k * WAVE) {
+						const int32_t idx = ab + k * WAVE + (int32_t)lane;
+						const uint32_t doc = Ad[t][k];
+						const bool in = idx >= lo[t] && idx < hi[t] && doc >= base;
+						const uint32_t c = __popcll(ballot64(in));
+						const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
+						const int32_t bot_ = max(lo[t], ab + k * WAVE);
+						ctot += c;
+						if ((int32_t)c < top_ - bot_) {
+							more = false;
+						}
+						if (c) {
+							/* find or claim the doc's slot */
+							/* volatile: the claim must really be re-read, not
+							 * forwarded from this lane's own store */
+							volatile uint32_t *vkey = s_key;
+							uint32_t slot = doc & (TAB - 1);
+							bool pending = in, isnew = false;
+							while (ballot64(pending)) {
+								uint32_t kk = 0;
+								if (pending) {
+									kk = vkey[slot];
+									if (kk == EMPTY) {
+										vkey[slot] = doc;
+									}
+								}
+								if (pending) {
+									if (kk == doc) {
+										pending = false;
+									} else if (kk == EMPTY) {
+										/* several lanes may have written
+										 * this slot: one value landed */
+										if (vkey[slot] == doc) {
+											pending = false;
+											isnew = true;
+										}
+									} else {
+										slot = (slot + 1) & (TAB - 1);
+									}
+								}
+							}
+							if (in) {
+								const float v = s_val[slot] + Ai[t][k];
+								s_val[slot] = v;
+								s_msk[slot] = (uint8_t)(s_msk[slot] | (1u << t));
+								tmax = fmaxf(tmax, v);
+							}
+							const uint64_t fb = ballot64(isnew);
+							if (isnew) {
+								s_list[n_list + lanes_below(fb)] = (uint16_t)slot;
+							}
+							n_list += __popcll(fb);
+						}
+					}
+				}
+				hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
+				pdoc[t] = -1;
+				if (hi[t] <= lo[t]) {
+					lowdoc[t] = -1;
+				} else if (hi[t] == ab) {
+					/* set A drained: take over set B, K new loads in flight */
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						Ad[t][k] = Bd[t][k];
+						Ai[t][k] = Bi[t][k];
+					}
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
+						Bd[t][k] = 0; Bi[t][k] = 0.0f;
+						if (ib >= lo[t]) {
+							const posting_t p = pt[t][ib];
+							Bd[t][k] = p.doc; Bi[t][k] = p.imp;
+						}
+					}
+					lowdoc[t] = -1;
+					if (ab - SW > lo[t]) {
+						lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
+					}
+					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][K - 1], WAVE - 1);
+				} else {
+					const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
+#pragma unroll
+					for (int k = 0; k < K; k++) {
+						if (k == kt) {
+							pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
+						}
+					}
+				}
+			}
+		}
+		WAVE_SYNC();
+
+		/* candidates of this step (skipped when nothing beat the threshold:
+		 * scores only grow within a step, see k_scan8) */
+		if (MODE == MODE_COUNT || ballot64(tmax > thr) != 0) {
+			uint32_t ncand = 0;
+			for (uint32_t off = 0; off < n_list; off += WAVE) {
+				const uint32_t i = off + lane;
+				const bool valid = i < n_list;
+				uint32_t d = 0, m = 0;
+				float sc = 0.0f;
+				if (valid) {
+					const uint32_t slot = s_list[i];
+					d = s_key[slot];
+					m = s_msk[slot];
+					sc = s_val[slot];
+				}
+				if (MODE == MODE_COUNT) {
+					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
+					n_out += __popcll(ballot64(match));
+					continue;
+				}
+				const bool pre = valid && (sc > thr);
+				if (ballot64(pre) == 0) {
+					continue;
+				}
+				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
+				const uint64_t bal = ballot64(cand);
+				if (cand) {
+					const uint32_t j = ncand + lanes_below(bal);
+					s_cd[j] = d;
+					s_cs[j] = sc;
+				}
+				ncand += __popcll(bal);
+			}
+			if (MODE != MODE_COUNT && ncand) {
+				WAVE_SYNC();
+				if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
+					ovf = true;
+				} else {
+					/* rank by doc, descending: docs are distinct */
+					for (uint32_t i0 = 0; i0 < ncand; i0 += WAVE) {
+						const uint32_t i = i0 + lane;
+						const uint32_t cd = i < ncand ? s_cd[i] : 0;
+						uint32_t rank = 0;
+						for (uint32_t j = 0; j < ncand; j++) {
+							rank += s_cd[j] > cd;
+						}
+						if (i < ncand) {
+							const uint64_t o = out_base + n_out + rank;
+							A.cand_doc[o] = cd;
+							A.cand_sc[o] = s_cs[i];
+						}
+					}
+				}
+				n_out += ncand;
+				if (track) {
+					for (uint32_t j = 0; j < ncand; j++) {
+						const float v = s_cs[j];
+						if (v > thr) {
+							const uint32_t pos = __popcll(ballot64(top >= v));
+							const float up = __shfl_up(top, 1);
+							top = (lane < pos) ? top : (lane == pos ? v : up);
+							thr = fmaxf(__shfl(top, kidx), hint);
+						}
+					}
+				}
+			}
+		}
+		/* wipe the table through the list */
+		for (uint32_t off = 0; off < n_list; off += WAVE) {
+			const uint32_t i = off + lane;
+			if (i < n_list) {
+				const uint32_t slot = s_list[i];
+				s_key[slot] = EMPTY;
+				s_val[slot] = 0.0f;
+				s_msk[slot] = 0;
+			}
+		}
+		WAVE_SYNC();
+	}
+
+	if (MODE == MODE_TOPK && track && !ovf) {
+		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
+	}
+	if (lane == 0) {
+		if (MODE != MODE_ALL) {
+			A.seg_count[seg] = ovf ? 0 : n_out;
+		}
+		if (MODE == MODE_TOPK && ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+#endif /* NXS_EXPERIMENTAL */
+
+/* ---- launchers ------------------------------------------------------ */
+
+void
+nxs_launch_cursors(const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd, hipStream_t st)
+{
+	const uint64_t threads = (uint64_t)n_bnd * NXSGPU_MAX_TOKENS;
+
+	if (n_bnd) {
+		hipLaunchKernelGGL(k_cursors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+		    a.post, a.queries, a.qmeta, d_bnd_q, n_bnd, a.n_docs, (uint32_t *)a.cursors);
+	}
+}
+
+void
+nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a)
+{
+	switch (mode) {
+	case MODE_TOPK: hipLaunchKernelGGL((k_scan1<MODE_TOPK>), dim3(grid), dim3(WAVE), 0, st, a); break;
+	case MODE_COUNT: hipLaunchKernelGGL((k_scan1<MODE_COUNT>), dim3(grid), dim3(WAVE), 0, st, a); break;
+	default: hipLaunchKernelGGL((k_scan1<MODE_ALL>), dim3(grid), dim3(WAVE), 0, st, a); break;
+	}
+}
+
+template <int MODE>
+static void
+launch_scanr_mode(uint32_t nt_bucket, bool hash, const dim3 grid, hipStream_t st, const scan_args_t &a)
+{
+	const dim3 block(WAVE);
+
+	switch (nt_bucket) {
+	case 2: hipLaunchKernelGGL((k_scanr<MODE, 2>), grid, block, 0, st, a); break;
+	case 3: hipLaunchKernelGGL((k_scanr<MODE, 3>), grid, block, 0, st, a); break;
+	case 5:
+		if (hash) { hipLaunchKernelGGL((k_scanr<MODE, 5, true>), grid, block, 0, st, a); }
+		else { hipLaunchKernelGGL((k_scanr<MODE, 5>), grid, block, 0, st, a); }
+		break;
+	default:
+		if (hash) { hipLaunchKernelGGL((k_scanr<MODE, 8, true>), grid, block, 0, st, a); }
+		else { hipLaunchKernelGGL((k_scanr<MODE, 8>), grid, block, 0, st, a); }
+		break;
+	}
+}
+
+/* k_scanr; hash: rounds of whole driver windows (queries with >= 4 required terms) */
+void
+nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStream_t st, const scan_args_t &a)
+{
+	switch (mode) {
+	case MODE_TOPK: launch_scanr_mode<MODE_TOPK>(nt_bucket, hash, dim3(grid), st, a); break;
+	case MODE_COUNT: launch_scanr_mode<MODE_COUNT>(nt_bucket, hash, dim3(grid), st, a); break;
+	default: launch_scanr_mode<MODE_ALL>(nt_bucket, hash, dim3(grid), st, a); break;
+	}
+}
+
+#ifdef NXS_EXPERIMENTAL
+template <int MODE>
+static void
+launch_scanh_mode(uint32_t nt_bucket, const dim3 grid, hipStream_t st, const scan_args_t &a)
+{
+	const dim3 block(WAVE);
+
+	switch (nt_bucket) {
+	case 2: hipLaunchKernelGGL((k_scanh<MODE, 2>), grid, block, 0, st, a); break;
+	case 3: hipLaunchKernelGGL((k_scanh<MODE, 3>), grid, block, 0, st, a); break;
+	case 5: hipLaunchKernelGGL((k_scanh<MODE, 5>), grid, block, 0, st, a); break;
+	default: hipLaunchKernelGGL((k_scanh<MODE, 8>), grid, block, 0, st, a); break;
+	}
+}
+#endif
+
+void
+nxs_launch_scanh(int mode, uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a)
+{
+#ifdef NXS_EXPERIMENTAL
+	switch (mode) {
+	case MODE_TOPK: launch_scanh_mode<MODE_TOPK>(nt_bucket, dim3(grid), st, a); break;
+	case MODE_COUNT: launch_scanh_mode<MODE_COUNT>(nt_bucket, dim3(grid), st, a); break;
+	default: launch_scanh_mode<MODE_ALL>(nt_bucket, dim3(grid), st, a); break;
+	}
+#else
+	(void)mode; (void)nt_bucket; (void)grid; (void)st; (void)a;	/* opt-in build */
+#endif
+}
+

@@ -1,0 +1,1569 @@
+/*
+ * nxs_gpu_search.hip -- work list, kernel dispatch, blocking search (exact two-pass path), pipelined batches, shard slices
+ * (MI355X / gfx950 query path of nxsearch; see nxs_gpu_int.h for the map of the files)
+ */
+#include "nxs_gpu_int.h"
+
+/* ---- search --------------------------------------------------------- */
+
+/*
+ * Work decomposition: every query's doc space is cut into n_groups equal
+ * ranges (multiples of TILE_W), one wavefront each.  The number of ranges is
+ * proportional to the query's share of the batch's postings, so a query with
+ * long lists gets many wavefronts and a sparse one a single one (whose fixed
+ * costs -- cursor searches, warm-up of the candidate threshold -- are then
+ * paid once).  Items are grouped by kernel class (token-count bucket x
+ * tile/step path) and emitted heaviest query first inside a class.
+ */
+
+void
+delete_worklist(worklist_t *wl)
+{
+	delete wl;
+}
+
+static uint32_t
+nt_bucket(uint32_t nt)
+{
+	return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 3 ? 3 : nt <= 5 ? 5 : 8;
+}
+
+static void
+build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false)
+{
+	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
+	const gpu_cfg_t &cf = ix->cfg;
+	/* (a batch that has the GPU to itself is latency-bound: shorter ranges, more of them) */
+	const uint64_t target = cf.wave_target, min_post = solo ? std::min(cf.min_post, cf.min_post_solo) : cf.min_post;
+	/* densest term has >= this many postings per tile => tile path (step path
+	 * off by default: the tile path is at least as fast) */
+#ifdef NXS_EXPERIMENTAL
+	const double dense_thr = cf.dense_thr;
+#else
+	const double dense_thr = 0.0;	/* k_scanh is an opt-in build */
+#endif
+	const bool use_scanr = cf.use_scanr && ix->n_docs < (1ull << 31);
+	const bool no_step = cf.no_step, mask_off = cf.mask_off;
+	const uint32_t rmin = cf.rmin;	/* 3: "a AND b" takes k_scan8's sign-bit path */
+	const bool by_level = cf.by_level;
+	const bool use_scanm = cf.use_scanm && ix->n_docs < (1ull << 31);
+	const bool scanm_general = cf.scanm_general;
+	const uint32_t scanm_minnt = cf.scanm_minnt, scanm_maxnt = cf.scanm_maxnt;
+	/* k_scanm if the densest list holds at most this fraction of the docs */
+	const double scanm_dens = cf.scanm_dens;
+	std::vector<uint64_t> work(nq);
+	std::vector<uint32_t> order(nq), cls(nq);
+	uint64_t total = 0;
+
+	for (uint32_t i = 0; i < nq; i++) {
+		uint64_t w = 0, wmax = 0;
+		for (uint32_t t = 0; t < hq[i].nt; t++) {
+			const uint64_t df = hq[i].pend[t] - hq[i].pbeg[t];
+			w += df;
+			wmax = std::max(wmax, df);
+		}
+		work[i] = w;
+		total += w;
+		order[i] = i;
+		if (hq[i].nt > 8) {
+			cls[i] = 0;
+		} else {
+			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
+			const bool tile = dense_thr <= 0.0 || per_tile >= dense_thr || hq[i].nt <= 1 ||
+			    ix->n_docs >= (1ull << 31) || no_step;
+			/* pure OR: every non-empty presence mask matches => no mask array */
+			bool or_only = hq[i].nt >= 2 && mask_off;
+			for (uint32_t m = 1; or_only && m < (1u << hq[i].nt); m++) {
+				or_only = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
+			}
+			/* pure AND of exactly two tokens: only the full mask matches.
+			 * (The sign-parity scheme of MM = 2 cannot tell "stuck at token
+			 * t-2" from "updated by token t" for three tokens or more.) */
+			bool and_only = hq[i].nt == 2 && mask_off;
+			for (uint32_t m = 1; and_only && m < (1u << hq[i].nt); m++) {
+				const bool hit = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
+				and_only = hit == (m == (1u << hq[i].nt) - 1);
+			}
+#ifndef NXS_EXPERIMENTAL
+			and_only = false;	/* the sign-bit AND path (MM = 2) is an opt-in build */
+#endif
+			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
+			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
+			/* pure OR of 2..8 tokens whose lists are sparse: mask path (k_scanm).
+			 * Dense lists stream faster through the accumulator tiles. */
+			/* ... or any expression without a required token: the bound in the
+			 * byte map does not depend on the operators, the truth table is
+			 * applied to the few docs that get scored
+			 * (only where matches are common enough for a threshold to form:
+			 * at least half of the tokens satisfy the expression on their own --
+			 * "(a AND b) OR (c AND d)" floods the scoring stage and stays on the
+			 * accumulator tiles: 3.3 ms there, 5.4 ms here) */
+			uint32_t singles = 0;
+			for (uint32_t t = 0; t < hq[i].nt && t < 8; t++) {
+				const uint32_t m1 = 1u << t;
+				singles += (hq[i].truth[m1 >> 5] >> (m1 & 31)) & 1;
+			}
+			const bool no_req = hq[i].req == 0 && hq[i].nt >= 2 && hq[i].nt <= 8 && mm != 2 &&
+			    2 * singles >= hq[i].nt;
+			if (tile && (or_only || (no_req && scanm_general)) && use_scanm &&
+			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt &&
+			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
+				cls[i] = 4u * 64 + (or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
+			} else if (tile && or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
+			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
+				/*
+				 * A pure OR of sparse terms AND dense ones: the mask path on the
+				 * sparse terms, the dense lists leave the scan once the threshold
+				 * exceeds their joint ceiling (k_scanm<.., DROP>).  Needs enough
+				 * sparse postings for a threshold to form in every doc range; the
+				 * work is what the sparse lists hold.
+				 */
+				uint64_t ws = 0;
+				uint32_t n_sparse = 0;
+				for (uint32_t t = 0; t < hq[i].nt; t++) {
+					if (!((hq[i].drop_mask >> t) & 1)) {
+						ws += hq[i].pend[t] - hq[i].pbeg[t];
+						n_sparse++;
+					}
+				}
+				if (n_sparse && ws >= cf.drop_minpost) {
+					total -= work[i];
+					work[i] = cf.drop_workmul * (ws + 16384);	/* latency-bound wavefronts: more, shorter ranges */
+					total += work[i];
+					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
+				}
+			}
+			/* required terms: intersect first (k_scanr).  Its work is set by
+			 * the shortest required list; longer lists are mostly skipped */
+			if (tile && hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
+				const uint64_t dfd = hq[i].pend[hq[i].slot_tok[0]] - hq[i].pbeg[hq[i].slot_tok[0]];
+				uint64_t wr = 0;
+				for (uint32_t t = 0; t < hq[i].nt; t++) {
+					wr += std::min<uint64_t>(hq[i].pend[t] - hq[i].pbeg[t], 4 * dfd);
+				}
+				total -= work[i];
+				work[i] = wr;
+				total += wr;
+				/* (four required terms and more: rounds of whole driver windows, k_scanr<.., true>) */
+			cls[i] = 3u * 64 + ((SCANR_HASH && hq[i].n_req >= 4) ? 16u : 0u) + nt_bucket(hq[i].nt);
+			}
+		}
+	}
+	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
+	/* launch order of the classes: the mask path first -- a class's heap replay
+	 * runs beside the NEXT class's scan, and the last class (required-term
+	 * queries: few candidates, short replay) is the one left exposed */
+	/* (the sparse + dense class leads: it runs on a stream of its own, beside the rest) */
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 4 ? 64 + (c & 63) : c + 256; };
+	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
+		return work[x] != work[y] ? work[x] > work[y] : x < y;
+	});
+	wl.qmeta.assign(nq, qmeta_t());
+	wl.items.clear();
+	wl.launches.clear();
+	wl.n_segs = 0;
+	wl.need_cursors = false;
+	for (uint32_t i = 0; i < nq; i++) {
+		uint64_t per_i = per_wave;
+		if (solo) {
+			/*
+			 * Alone on the GPU every range starts cold and emits its own early
+			 * maxima (~10 (1 + ln(postings / 10)) candidates each), which the replay
+			 * then streams through one wavefront; a range's scan is a chain of
+			 * dependent window loads.  Scan time falls with the number of ranges R,
+			 * replay time grows with it: the sum is smallest near R = sqrt(n / 84),
+			 * i.e. sqrt(84 n) postings per range (2M postings: 154 ranges, not 2000).
+			 */
+			/* (never finer than the batch-wide rule: the work list's size bound rests on it) */
+			per_i = std::max<uint64_t>(per_wave, (uint64_t)std::sqrt(84.0 * (double)work[i]));
+		}
+		uint64_t g = std::max<uint64_t>(1, (work[i] + per_i - 1) / per_i);
+		g = std::min<uint64_t>(g, tiles);
+		g = std::min<uint64_t>(g, 65535);
+		const uint64_t tiles_per = (tiles + g - 1) / g;
+		g = (tiles + tiles_per - 1) / tiles_per;
+		qmeta_t &m = wl.qmeta[i];
+		m.n_groups = (uint32_t)g;
+		m.group_docs = (uint32_t)std::min<uint64_t>(tiles_per * TILE_W, 0xffffffffu & ~(uint64_t)(TILE_W - 1));
+		/* single-token queries on k_scan1: any split of the list into contiguous
+		 * pieces, highest docs first, feeds the heap the same sequence -- split by
+		 * posting index and the batch needs no k_cursors launch */
+		m.pad = ((cls[i] >> 6) == 1 && (cls[i] & 15) == 1 && !cf.no_scan1 && !cf.old_scan &&
+		    ix->n_docs < (1ull << 31)) ? 1u : 0u;
+		wl.need_cursors = wl.need_cursors || m.pad == 0;
+	}
+	for (uint32_t i = 0; i < nq; i++) {
+		wl.qmeta[i].seg_first = wl.n_segs;
+		wl.n_segs += wl.qmeta[i].n_groups;
+	}
+	wl.bnd_q.clear();
+	wl.bnd_q.reserve((size_t)wl.n_segs + nq);
+	for (uint32_t i = 0; i < nq; i++) {
+		/* query i owns boundaries seg_first + i ... + n_groups (inclusive) */
+		for (uint32_t g = 0; g <= wl.qmeta[i].n_groups; g++) {
+			wl.bnd_q.push_back(i);
+		}
+	}
+	wl.items.reserve(wl.n_segs);
+	wl.qorder = order;
+	/*
+	 * Inside a class, items go out level by level: level l of every query
+	 * (its l-th highest doc range) before level l+1 of any.  All items carry
+	 * about per_wave postings, so this costs no balance, and it spreads one
+	 * query's ranges in time: when a range starts, higher ranges of its query
+	 * have usually finished and published their threshold (range_hint).
+	 */
+	for (uint32_t o0 = 0; o0 < nq; ) {
+		uint32_t o1 = o0, max_g = 0;
+		while (o1 < nq && cls[order[o1]] == cls[order[o0]]) {
+			max_g = std::max(max_g, wl.qmeta[order[o1]].n_groups);
+			o1++;
+		}
+		launch_t l;
+		l.first = (uint32_t)wl.items.size();
+		l.nt_bucket = cls[order[o0]] & 15;
+		l.nomask = (cls[order[o0]] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 two-token AND */
+		l.kind = cls[order[o0]] >> 6;
+		if (by_level) {
+			/* the class is sorted by work, so n_groups does not increase along
+			 * it (checked): the queries that still have a level `lev` form a
+			 * prefix, and the loop is linear in the number of items */
+			bool mono = true;
+			for (uint32_t oi = o0 + 1; oi < o1 && mono; oi++) {
+				mono = wl.qmeta[order[oi]].n_groups <= wl.qmeta[order[oi - 1]].n_groups;
+			}
+			uint32_t live_end = o1;
+			for (uint32_t lev = 0; lev < max_g; lev++) {
+				while (mono && live_end > o0 && wl.qmeta[order[live_end - 1]].n_groups <= lev) {
+					live_end--;
+				}
+				for (uint32_t oi = o0; oi < live_end; oi++) {
+					const uint32_t i = order[oi];
+					if (lev < wl.qmeta[i].n_groups) {
+						item_t it;
+						it.q = i;
+						it.g = wl.qmeta[i].n_groups - 1 - lev;
+						wl.items.push_back(it);
+					}
+				}
+			}
+		} else {
+			for (uint32_t oi = o0; oi < o1; oi++) {
+				const uint32_t i = order[oi];
+				for (uint32_t g = wl.qmeta[i].n_groups; g-- > 0; ) {
+					item_t it;
+					it.q = i;
+					it.g = g;
+					wl.items.push_back(it);
+				}
+			}
+		}
+		l.count = (uint32_t)wl.items.size() - l.first;
+		l.q_first = o0;
+		l.q_count = o1 - o0;
+		wl.launches.push_back(l);
+		o0 = o1;
+	}
+}
+
+static void
+launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd,
+    hipStream_t stream = NULL)
+{
+	nxs_launch_cursors(a, d_bnd_q, n_bnd, stream ? stream : ix->stream);
+}
+
+/*
+ * One scan launch per query class.  With `ra` (top-k filter pass) the heap
+ * replay of a class is queued on the second stream as soon as the class's
+ * scan is: the replay is a few latency-bound wavefronts (one per query) and
+ * runs beside the next class's scan instead of after all of them.
+ */
+static void
+launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
+    const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL)
+{
+	bool forked = false, forked3 = false;
+	const launch_t *last_launch = NULL;
+	size_t n_launches = 0;
+
+	for (const launch_t &l : wl.launches) {
+		n_launches += l.count != 0;
+	}
+	/* the sparse + dense class goes to its own stream when there is something to
+	 * run it beside (top-k pass only: its replay follows it there) */
+	const bool side3 = MODE == MODE_TOPK && ra && n_launches > 1 && a0.k >= 1 && a0.k <= WAVE && ix->cfg.drop_side;
+	for (const launch_t &l : wl.launches) {
+		if (l.count && !(side3 && l.kind == 5)) {
+			last_launch = &l;
+		}
+	}
+	for (const launch_t &l : wl.launches) {
+		scan_args_t a = a0;
+		const unsigned grid = l.count;
+		/* mask path / dense-term class: top-k filter pass only; the exact passes
+		 * (count, emit all) of these queries take the accumulator tiles */
+		const bool topk64 = MODE == MODE_TOPK && a.k >= 1 && a.k <= WAVE;
+
+		if (l.count == 0) {
+			continue;
+		}
+		a.item_base = l.first;
+		if (side3 && l.kind == 5) {
+			replay_args_t r = *ra;
+			r.qlist = d_qorder + l.q_first;
+			if (!forked3) {
+				(void)hipEventRecord(ix->ev_fork3, ix->stream);
+				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
+				forked3 = true;
+			}
+			a.flags = ix->cfg.drop_prio ? 1u : 0u;
+			nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
+			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
+			continue;
+		}
+		if (l.kind == 0) {
+			nxs_launch_scan_generic(MODE, true, grid, ix->stream, a);
+		} else if (ix->cfg.old_scan || ix->n_docs >= (1ull << 31)) {
+			nxs_launch_scan_generic(MODE, false, grid, ix->stream, a);
+		} else if (l.kind == 1) {
+			if (l.nt_bucket == 1 && !ix->cfg.no_scan1) {
+				nxs_launch_scan1(MODE, grid, ix->stream, a);
+			} else {
+				nxs_launch_scan8(MODE, l.nt_bucket, l.nt_bucket == 1 ? 0u : l.nomask, grid, ix->stream, a);
+			}
+		} else if (l.kind == 4) {
+			if (topk64) {
+				nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
+			} else {
+				nxs_launch_scan8(MODE, l.nt_bucket, l.nomask == 1 ? 1u : 0u, grid, ix->stream, a);
+			}
+		} else if (l.kind == 5) {
+			/* sparse + dense pure OR: top-k pass with the dense lists dropped */
+			if (topk64) {
+				nxs_launch_drop_class(l.nt_bucket, grid, ix->stream, a);
+			} else {
+				nxs_launch_scan8(MODE, l.nt_bucket, 1u, grid, ix->stream, a);
+			}
+		} else if (l.kind == 3) {
+			nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, ix->stream, a);
+		} else {
+			nxs_launch_scanh(MODE, l.nt_bucket, grid, ix->stream, a);
+		}
+		if (ra && l.q_count) {
+			replay_args_t r = *ra;
+			r.qlist = d_qorder + l.q_first;
+			if (&l == last_launch) {
+				/* nothing left to run beside it: same stream, no event
+				 * round trip (a single query has only this one) */
+				if (scans_done) {
+					(void)hipEventRecord(scans_done, ix->stream);
+					scans_done = NULL;
+				}
+				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream, r);
+			} else {
+				(void)hipEventRecord(ix->ev_cls, ix->stream);
+				(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
+				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream2, r);
+				forked = true;
+			}
+		}
+	}
+	if (scans_done) {
+		(void)hipEventRecord(scans_done, ix->stream);
+	}
+	if (forked) {
+		(void)hipEventRecord(ix->ev_join, ix->stream2);
+		(void)hipStreamWaitEvent(ix->stream, ix->ev_join, 0);
+	}
+	if (forked3) {
+		(void)hipEventRecord(ix->ev_join3, ix->stream3);
+		(void)hipStreamWaitEvent(ix->stream, ix->ev_join3, 0);
+	}
+}
+
+/*
+ * Core of the search: fills device outputs.  If `d_out_*` are NULL the
+ * results are copied to the host into `res`.
+ */
+/*
+ * Device form of the batch's plans: posting ranges of the tokens, truth
+ * table, required-token mask and k_scanr's slot order.  -1 on a bad plan.
+ */
+static int
+fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queries, uint32_t nq,
+    dev_query_t *hq, uint64_t &total_post, bool allow_drop = true)
+{
+	const bool valid = (algo == NXSGPU_BM25) ? ix->bm25_valid : ix->tfidf_valid;
+	const bool no_req = ix->cfg.no_req;
+
+	for (uint32_t i = 0; i < nq; i++) {
+		const nxsgpu_query_t &q = queries[i];
+		dev_query_t &d = hq[i];
+		memset(&d, 0, sizeof(d));
+		if (q.n_tokens > NXSGPU_MAX_TOKENS || q.prog_len > NXSGPU_MAX_PROG) {
+			set_error("query %u exceeds the device limits", i);
+			return -1;
+		}
+		/* invalid statistics => every pair is skipped (ranking.c:86-88,156-166) */
+		d.nt = valid ? q.n_tokens : 0;
+		d.prog_len = q.prog_len;
+		memcpy(d.prog, q.prog, q.prog_len);
+		memcpy(d.truth, q.truth, sizeof(d.truth));
+		/* tokens common to every matching presence mask (<= 8 tokens) */
+		d.req = 0;
+		if (d.nt && d.nt <= 8 && !no_req) {
+			uint32_t r = (1u << d.nt) - 1;
+			for (uint32_t m = 1; m < (1u << d.nt); m++) {
+				if ((d.truth[m >> 5] >> (m & 31)) & 1) {
+					r &= m;
+				}
+			}
+			d.req = r;
+		}
+		for (uint32_t t = 0; t < d.nt; t++) {
+			const uint32_t tid = q.term_id[t];
+			if (tid == 0 || tid > ix->n_terms) {
+				set_error("query %u: bad term id %u", i, tid);
+				return -1;
+			}
+			d.pbeg[t] = ix->h_post_off[tid];
+			d.pend[t] = ix->h_post_off[tid + 1];
+			total_post += d.pend[t] - d.pbeg[t];
+			if (t < 8 && tid < ix->h_maximp[algo].size()) {
+				d.tmax[t] = ix->h_maximp[algo][tid];
+			}
+		}
+		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
+		/*
+		 * (BM25 only: its tf part saturates, so a term's largest impact says what
+		 * the term typically adds.  TF-IDF's log(tf + 1) does not: one posting with
+		 * an outlier tf sets a ceiling that thresholds reach late -- measured 3x
+		 * slower than the accumulator tiles there.)
+		 */
+		d.drop_mask = 0;
+		if (allow_drop && d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && algo == NXSGPU_BM25) {
+			for (uint32_t t = 0; t < d.nt; t++) {
+				const auto it = std::lower_bound(ix->dense_terms.begin(), ix->dense_terms.end(), q.term_id[t]);
+				if (it != ix->dense_terms.end() && *it == q.term_id[t]) {
+					d.drop_mask |= 1u << t;
+					d.drop_col[t] = (uint32_t)(it - ix->dense_terms.begin());
+				}
+			}
+		}
+		if (d.drop_mask) {
+			/* worth it only while the dense ceiling stays well below what one
+			 * sparse posting can add */
+			float u = 0.0f, smin = INFINITY;
+			for (uint32_t t = 0; t < d.nt; t++) {
+				if ((d.drop_mask >> t) & 1) {
+					u += d.tmax[t];
+				} else {
+					smin = std::min(smin, d.tmax[t]);
+				}
+			}
+			if (!(u <= 1.25f * smin)) {
+				d.drop_mask = 0;
+			}
+		}
+		/* k_scanr slot order: required tokens first, shortest list first */
+		d.n_req = 0;
+		if (d.req && d.nt <= 8) {
+			uint32_t ord[8];
+			for (uint32_t t = 0; t < d.nt; t++) {
+				ord[t] = t;
+			}
+			std::sort(ord, ord + d.nt, [&](uint32_t x, uint32_t y) {
+				const bool rx = (d.req >> x) & 1, ry = (d.req >> y) & 1;
+				if (rx != ry) return rx;
+				const uint64_t dx = d.pend[x] - d.pbeg[x], dy = d.pend[y] - d.pbeg[y];
+				return dx != dy ? dx < dy : x < y;
+			});
+			for (uint32_t t = 0; t < d.nt; t++) {
+				d.slot_tok[t] = (uint8_t)ord[t];
+				d.n_req += (d.req >> t) & 1;
+			}
+		}
+	}
+	return 0;
+}
+
+/* doc-sharded mode: the accepted-candidate log of every query (host arrays) */
+struct cand_log_t {
+	uint32_t	cap;
+	uint64_t *	ids;	/* [nq * cap] */
+	float *		sc;	/* [nq * cap] */
+	uint32_t *	cnt;	/* [nq]; > cap = overflow */
+};
+
+static int
+search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res, cand_log_t *cl = NULL)
+{
+	const bool fast = limit <= NXSGPU_FAST_K;
+	const uint32_t seg_cap = ix->cfg.seg_cap;
+	std::vector<dev_query_t> hq(nq);
+	std::vector<uint32_t> h_ovf, h_cnt;
+	worklist_t wl;
+	uint64_t total_post = 0;
+	uint8_t *p;
+	dev_query_t *d_q;
+	qmeta_t *d_qmeta;
+	item_t *d_items;
+	uint32_t *d_seg_count, *d_cand_doc, *d_ovf, *d_cnt;
+	uint64_t *d_ids;
+	float *d_cand_sc, *d_sc;
+	scan_args_t sa;
+	replay_args_t ra;
+	const uint32_t kfast = fast ? (uint32_t)limit : NXSGPU_FAST_K;
+
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (limit == 0) {
+		set_error("invalid limit");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (res) {
+		memset(res, 0, sizeof(*res));
+		res->n_queries = nq;
+	}
+	if (nq == 0) {
+		return 0;
+	}
+
+	uint64_t *d_log_ids = NULL;
+	float *d_log_sc = NULL;
+	uint32_t *d_log_cnt = NULL, *d_log_slot = NULL;
+	struct log_guard_t {
+		uint64_t *&a; float *&b; uint32_t *&c; uint32_t *&d;
+		~log_guard_t() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); }
+	} log_guard{d_log_ids, d_log_sc, d_log_cnt, d_log_slot};
+	if (cl) {
+		if (hipMalloc((void **)&d_log_ids, (size_t)nq * cl->cap * 8 + 8) != hipSuccess ||
+		    hipMalloc((void **)&d_log_sc, (size_t)nq * cl->cap * 4 + 4) != hipSuccess ||
+		    hipMalloc((void **)&d_log_cnt, (size_t)nq * 4) != hipSuccess ||
+		    hipMalloc((void **)&d_log_slot, (size_t)nq * 4) != hipSuccess ||
+		    hipMemsetAsync(d_log_cnt, 0, (size_t)nq * 4, ix->stream) != hipSuccess) {
+			set_error("hipMalloc for the candidate log failed");
+			return -1;
+		}
+	}
+	/* (this blocking path is also where queries land whose candidate lists
+	 * overflowed in a batch: no sparse + dense class here -- its pending list is
+	 * what overflows, and the tiles take such a query without emitting every match
+	 * as the exact passes below would: 30 ms per query at 50M docs) */
+	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post, false) != 0) {
+		return -1;
+	}
+	build_worklist(ix, hq.data(), nq, wl);
+	const uint64_t nseg = wl.n_segs;
+
+	/* workspace: queries | meta | items | seg_count | overflow | candidates | outputs */
+	{
+		size_t need = 8192 + nq * 4 + nq * sizeof(dev_query_t) + nq * sizeof(qmeta_t)
+		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
+		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
+		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256
+		    + nseg * (16 * 4 + 64 * 4) + 1024;
+		if (!ensure_ws(ix, need)) {
+			return -1;
+		}
+	}
+	/*
+	 * Everything the kernels read from the host is one contiguous block, staged
+	 * in pinned memory and uploaded by ONE copy (the two zero-filled arrays
+	 * included); the flags and the results are one block and ONE copy back.  A
+	 * single query used to pay eleven small pageable copies + two memsets:
+	 * most of its latency.
+	 */
+	p = (uint8_t *)ix->ws;
+	uint8_t *const up0 = p;
+	d_q = carve<dev_query_t>(p, nq);
+	d_qmeta = carve<qmeta_t>(p, nq);
+	d_items = carve<item_t>(p, nseg);
+	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
+	uint32_t *d_qorder = carve<uint32_t>(p, nq);
+	float *d_pub = carve<float>(p, nseg);
+	d_ovf = carve<uint32_t>(p, nq);
+	const size_t up_len = (size_t)(p - up0);
+	uint8_t *const down0 = (uint8_t *)d_ovf;
+	d_ids = carve<uint64_t>(p, (size_t)nq * kfast);
+	d_sc = carve<float>(p, (size_t)nq * kfast);
+	d_cnt = carve<uint32_t>(p, nq);
+	const size_t down_len = (size_t)(p - down0);
+	d_seg_count = carve<uint32_t>(p, nseg);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
+	d_cand_doc = carve<uint32_t>(p, nseg * seg_cap);
+	d_cand_sc = carve<float>(p, nseg * seg_cap);
+	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
+	float *d_cold_top = carve<float>(p, nseg * 64);
+
+	if (!ensure_pin(ix, up_len + down_len + 512)) {
+		return -1;
+	}
+	uint8_t *const h_up = (uint8_t *)ix->h_pin;
+	uint8_t *const h_down = (uint8_t *)(((uintptr_t)h_up + up_len + 255) & ~(uintptr_t)255);
+	memset(h_up, 0, up_len);
+	memcpy(h_up + ((uint8_t *)d_q - up0), hq.data(), nq * sizeof(dev_query_t));
+	memcpy(h_up + ((uint8_t *)d_qmeta - up0), wl.qmeta.data(), nq * sizeof(qmeta_t));
+	memcpy(h_up + ((uint8_t *)d_items - up0), wl.items.data(), nseg * sizeof(item_t));
+	memcpy(h_up + ((uint8_t *)d_bnd_q - up0), wl.bnd_q.data(), (nseg + nq) * 4);
+	memcpy(h_up + ((uint8_t *)d_qorder - up0), wl.qorder.data(), nq * 4);
+	if (hipMemcpyAsync(up0, h_up, up_len, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+		set_error("query upload failed");
+		return -1;
+	}
+
+	memset(&sa, 0, sizeof(sa));
+	sa.post = ix->d_post[algo];
+	sa.dense_col = ix->d_dense_col[algo];
+	sa.dense_stride = ix->n_docs;
+	sa.queries = d_q;
+	sa.n_docs = ix->n_docs;
+	sa.qmeta = d_qmeta;
+	sa.items = d_items;
+	sa.k = kfast;
+	sa.seg_cap = seg_cap;
+	sa.seg_count = d_seg_count;
+	sa.seg_off = NULL;
+	sa.cand_doc = d_cand_doc;
+	sa.cand_sc = d_cand_sc;
+	sa.overflow = d_ovf;
+	sa.cursors = d_cursors;
+	sa.pub = d_pub;
+	sa.cold_state = d_cold_state;
+	sa.cold_top = d_cold_top;
+
+	h_ovf.assign(nq, 0);
+	if (fast) {
+		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
+		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
+		memset(&ra, 0, sizeof(ra));
+		ra.qmeta = d_qmeta;
+		ra.seg_cap = seg_cap;
+		ra.seg_count = d_seg_count;
+		ra.cand_doc = d_cand_doc;
+		ra.cand_sc = d_cand_sc;
+		ra.doc_ids = ix->d_doc_ids;
+		ra.k = kfast;
+		ra.out_ids = d_ids;
+		ra.out_sc = d_sc;
+		ra.out_count = d_cnt;
+		ra.skip = d_ovf;
+		if (cl) {
+			ra.log_ids = d_log_ids;
+			ra.log_sc = d_log_sc;
+			ra.log_cnt = d_log_cnt;
+			ra.log_cap = cl->cap;
+		}
+		if (ix->cfg.one_replay) {
+			launch_scan(MODE_TOPK, ix, sa, wl);
+			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
+			nxs_launch_replay(HEAP_REG, nq, 0, ix->stream, ra);
+		} else {
+			/* (profile: "replay" is then only what the last class's replay
+			 * adds after the last scan) */
+			launch_scan(MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? ix->ev[1] : NULL);
+		}
+		if (ix->profiling) (void)hipEventRecord(ix->ev[2], ix->stream);
+		if (hipGetLastError() != hipSuccess) {
+			set_error("kernel launch failed");
+			return -1;
+		}
+		if (hipMemcpyAsync(h_down, down0, down_len, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) {
+			set_error("copy failed");
+			return -1;
+		}
+	} else {
+		std::fill(h_ovf.begin(), h_ovf.end(), 1u);
+	}
+	if (hipStreamSynchronize(ix->stream) != hipSuccess) {
+		set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+
+	/* host copy of the fast results */
+	std::vector<uint64_t> f_ids;
+	std::vector<float> f_sc;
+	h_cnt.assign(nq, 0);
+	if (fast) {
+		f_ids.resize((size_t)nq * kfast);
+		f_sc.resize((size_t)nq * kfast);
+		memcpy(h_ovf.data(), h_down + ((uint8_t *)d_ovf - down0), nq * 4);
+		memcpy(f_ids.data(), h_down + ((uint8_t *)d_ids - down0), f_ids.size() * 8);
+		memcpy(f_sc.data(), h_down + ((uint8_t *)d_sc - down0), f_sc.size() * 4);
+		memcpy(h_cnt.data(), h_down + ((uint8_t *)d_cnt - down0), nq * 4);
+	}
+	/* (a re-run beside batches in flight stays out of the per-launch averages: with
+	 * it in, one overflowed query per step halved the "kernel_ms" bench.py prints) */
+	if (fast && ix->profiling && !(ix->slot[0].active || ix->slot[1].active)) {
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]);
+		(void)hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]);
+		ix->prof.launches++;
+		ix->prof.scan_ms += a;
+		ix->prof.replay_ms += b;
+		ix->prof.postings += total_post;
+	}
+
+	/*
+	 * Exact two-pass path for queries that overflowed their candidate
+	 * segments or ask for more than NXSGPU_FAST_K results: count matches,
+	 * emit them all, replay with the heap in global memory.
+	 */
+	std::vector<uint32_t> xq;	/* indices of such queries */
+	for (uint32_t i = 0; i < nq; i++) {
+		if (h_ovf[i]) {
+			xq.push_back(i);
+		}
+	}
+	std::vector<uint32_t> x_cnt;
+	std::vector<uint64_t> x_off, x_ids;
+	std::vector<float> x_sc;
+	if (!xq.empty()) {
+		const uint32_t nx = (uint32_t)xq.size();
+		std::vector<dev_query_t> xhq(nx);
+		worklist_t xwl;
+		void *xws = NULL;
+		uint8_t *xp;
+		size_t xneed;
+		int rc = -1;
+
+		for (uint32_t j = 0; j < nx; j++) {
+			xhq[j] = hq[xq[j]];
+		}
+		build_worklist(ix, xhq.data(), nx, xwl);
+		const uint64_t xseg = xwl.n_segs;
+		std::vector<uint32_t> sc_cnt(xseg);
+		std::vector<uint64_t> sc_off(xseg + 1, 0), hp_off(nx + 1, 0), o_off(nx + 1, 0);
+
+		/* device copies of the subset's queries / work list */
+		void *xmeta = NULL;
+		{
+			const size_t mneed = 8192 + nx * sizeof(dev_query_t) + nx * sizeof(qmeta_t)
+			    + xseg * sizeof(item_t) + xseg * 4
+			    + (xseg + nx) * 4 * (1 + NXSGPU_MAX_TOKENS);
+			if ((xmeta = xbuf_get(ix, 0, mneed)) == NULL) {
+				set_error("hipMalloc(%zu) for the exact pass failed", mneed);
+				return -1;
+			}
+		}
+		uint8_t *mp = (uint8_t *)xmeta;
+		dev_query_t *dx_q = carve<dev_query_t>(mp, nx);
+		qmeta_t *dx_qmeta = carve<qmeta_t>(mp, nx);
+		item_t *dx_items = carve<item_t>(mp, xseg);
+		uint32_t *dx_seg_count = carve<uint32_t>(mp, xseg);
+		uint32_t *dx_bnd_q = carve<uint32_t>(mp, xseg + nx);
+		uint32_t *dx_cursors = carve<uint32_t>(mp, (xseg + nx) * NXSGPU_MAX_TOKENS);
+
+		/* pass 1: count */
+		if (hipMemcpyAsync(dx_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_qmeta, xwl.qmeta.data(), nx * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(dx_bnd_q, xwl.bnd_q.data(), (xseg + nx) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+			set_error("query upload failed");
+			return -1;
+		}
+		sa.queries = dx_q;
+		sa.qmeta = dx_qmeta;
+		sa.items = dx_items;
+		sa.seg_count = dx_seg_count;
+		sa.cursors = dx_cursors;
+		sa.k = 0xffffffffu;
+		launch_cursors(ix, sa, dx_bnd_q, (uint32_t)(xseg + nx));
+		launch_scan(MODE_COUNT, ix, sa, xwl);
+		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
+			return -1;
+		}
+		for (uint64_t sgi = 0; sgi < xseg; sgi++) {
+			sc_off[sgi + 1] = sc_off[sgi] + sc_cnt[sgi];
+		}
+		for (uint32_t j = 0; j < nx; j++) {
+			const qmeta_t &m = xwl.qmeta[j];
+			const uint64_t matched = sc_off[(uint64_t)m.seg_first + m.n_groups] - sc_off[m.seg_first];
+			const uint64_t hcap = std::min<uint64_t>(limit, matched);
+			hp_off[j + 1] = hp_off[j] + hcap;
+			o_off[j + 1] = o_off[j] + hcap;
+		}
+		const uint64_t tot_c = sc_off[xseg], tot_o = o_off[nx];
+		xneed = 8192 + (xseg + 1) * 8 + tot_c * 8 + tot_o * 8 * 2 + tot_o * 12 + (nx + 1) * 16 + nx * 4;
+		if ((xws = xbuf_get(ix, 1, xneed)) == NULL) {
+			set_error("hipMalloc(%zu) for the exact pass failed", xneed);
+			return -1;
+		}
+		xp = (uint8_t *)xws;
+		uint64_t *dx_seg_off = carve<uint64_t>(xp, xseg + 1);
+		uint32_t *dx_cdoc = carve<uint32_t>(xp, tot_c + 1);
+		float *dx_csc = carve<float>(xp, tot_c + 1);
+		float *dx_hs = carve<float>(xp, tot_o + 1);
+		uint32_t *dx_hd = carve<uint32_t>(xp, tot_o + 1);
+		uint64_t *dx_hoff = carve<uint64_t>(xp, nx + 1);
+		uint64_t *dx_ooff = carve<uint64_t>(xp, nx + 1);
+		uint64_t *dx_ids = carve<uint64_t>(xp, tot_o + 1);
+		float *dx_sc = carve<float>(xp, tot_o + 1);
+		uint32_t *dx_cnt = carve<uint32_t>(xp, nx);
+
+		x_cnt.assign(nx, 0);
+		x_ids.resize(tot_o);
+		x_sc.resize(tot_o);
+		x_off = o_off;
+		do {
+			if (hipMemcpyAsync(dx_seg_off, sc_off.data(), (xseg + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+			    hipMemcpyAsync(dx_hoff, hp_off.data(), (nx + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+			    hipMemcpyAsync(dx_ooff, o_off.data(), (nx + 1) * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+				set_error("upload failed");
+				break;
+			}
+			/* pass 2: emit every match at its exact offset */
+			scan_args_t sb = sa;
+			sb.seg_off = dx_seg_off;
+			sb.cand_doc = dx_cdoc;
+			sb.cand_sc = dx_csc;
+			launch_scan(MODE_ALL, ix, sb, xwl);
+			memset(&ra, 0, sizeof(ra));
+			ra.qmeta = dx_qmeta;
+			ra.seg_cap = 0;
+			ra.seg_off = dx_seg_off;
+			ra.cand_doc = dx_cdoc;
+			ra.cand_sc = dx_csc;
+			ra.doc_ids = ix->d_doc_ids;
+			ra.k = (uint32_t)std::min<uint64_t>(limit, 0xffffffffu);
+			ra.gheap_s = dx_hs;
+			ra.gheap_d = dx_hd;
+			ra.heap_off = dx_hoff;
+			ra.out_ids = dx_ids;
+			ra.out_sc = dx_sc;
+			ra.out_count = dx_cnt;
+			ra.out_off = dx_ooff;
+			if (cl) {
+				/* row of the log = the query's index in the whole batch */
+				if (hipMemcpyAsync(d_log_slot, xq.data(), (size_t)nx * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+					set_error("upload failed");
+					break;
+				}
+				ra.log_ids = d_log_ids;
+				ra.log_sc = d_log_sc;
+				ra.log_cnt = d_log_cnt;
+				ra.log_cap = cl->cap;
+				ra.log_slot = d_log_slot;
+			}
+			if (ra.k <= REPLAY_LDS_K) {
+				nxs_launch_replay(HEAP_LDS, nx, (size_t)ra.k * 8, ix->stream, ra);
+			} else {
+				nxs_launch_replay(HEAP_GLOBAL, nx, 0, ix->stream, ra);
+			}
+			if (hipGetLastError() != hipSuccess) {
+				set_error("kernel launch failed");
+				break;
+			}
+			if (hipMemcpyAsync(x_cnt.data(), dx_cnt, nx * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+			    (tot_o && hipMemcpyAsync(x_ids.data(), dx_ids, tot_o * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+			    (tot_o && hipMemcpyAsync(x_sc.data(), dx_sc, tot_o * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+			    hipStreamSynchronize(ix->stream) != hipSuccess) {
+				set_error("exact pass failed: %s", hipGetErrorString(hipGetLastError()));
+				break;
+			}
+			rc = 0;
+		} while (0);
+		xbuf_put(ix, 0);
+		xbuf_put(ix, 1);
+		if (rc != 0) {
+			return -1;
+		}
+		if (res) {
+			res->exact_requeries = nx;
+		}
+	}
+
+	if (cl) {
+		if (hipMemcpyAsync(cl->ids, d_log_ids, (size_t)nq * cl->cap * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(cl->sc, d_log_sc, (size_t)nq * cl->cap * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipMemcpyAsync(cl->cnt, d_log_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipStreamSynchronize(ix->stream) != hipSuccess) {
+			set_error("candidate log copy failed");
+			return -1;
+		}
+	}
+
+	/* assemble host results */
+	if (res) {
+		uint64_t total = 0;
+		res->counts = (uint32_t *)calloc(nq, sizeof(uint32_t));
+		res->offsets = (uint64_t *)calloc((size_t)nq + 1, sizeof(uint64_t));
+		for (uint32_t i = 0, j = 0; i < nq; i++) {
+			uint32_t c;
+			if (h_ovf[i]) {
+				c = x_cnt[j++];
+			} else {
+				c = h_cnt[i];
+			}
+			res->counts[i] = c;
+			res->offsets[i + 1] = res->offsets[i] + c;
+		}
+		total = res->offsets[nq];
+		res->doc_ids = (uint64_t *)malloc((total ? total : 1) * 8);
+		res->scores = (float *)malloc((total ? total : 1) * 4);
+		for (uint32_t i = 0, j = 0; i < nq; i++) {
+			const uint64_t o = res->offsets[i];
+			const uint32_t c = res->counts[i];
+			if (h_ovf[i]) {
+				memcpy(res->doc_ids + o, x_ids.data() + x_off[j], c * 8ull);
+				memcpy(res->scores + o, x_sc.data() + x_off[j], c * 4ull);
+				j++;
+			} else {
+				memcpy(res->doc_ids + o, f_ids.data() + (size_t)i * kfast, c * 8ull);
+				memcpy(res->scores + o, f_sc.data() + (size_t)i * kfast, c * 4ull);
+			}
+		}
+		res->postings = total_post;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, nxsgpu_results_t *res)
+{
+	/* own workspace; with batches in flight, own streams too: a re-run of a few
+	 * overflowed queries must not wait for the next batch's scans (19 ms at C5) */
+	const bool busy = ix->slot[0].active || ix->slot[1].active;
+	if (busy) {
+		std::swap(ix->stream, ix->xstream[0]);
+		std::swap(ix->stream2, ix->xstream[1]);
+		std::swap(ix->stream3, ix->xstream[2]);
+	}
+	const int r = search_impl(ix, algo, limit, queries, nq, res);
+	if (busy) {
+		std::swap(ix->stream, ix->xstream[0]);
+		std::swap(ix->stream2, ix->xstream[1]);
+		std::swap(ix->stream3, ix->xstream[2]);
+	}
+	return r;
+}
+
+
+extern "C" int
+nxsgpu_search_candidates(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint32_t cap, uint64_t *ids, float *scores, uint32_t *counts)
+{
+	cand_log_t cl;
+	nxsgpu_results_t res;
+	int r;
+
+	if (cap == 0) {
+		set_error("nxsgpu_search_candidates: cap is 0");
+		return -1;
+	}
+	cl.cap = cap;
+	cl.ids = ids;
+	cl.sc = scores;
+	cl.cnt = counts;
+	memset(counts, 0, (size_t)nq * 4);
+	r = search_impl(ix, algo, limit, queries, nq, &res, &cl);
+	if (r == 0) {
+		nxsgpu_results_free(&res);
+	}
+	return r;
+}
+
+/*
+ * Device-resident batches, two in flight.  _begin() plans on the host, stages
+ * everything the kernels need in pinned memory, sends it up on its own stream
+ * and queues cursors, scans and replays behind it; _end() waits for the oldest
+ * batch and reports whether one of its queries overflowed its candidate
+ * segments (1: the caller reruns the batch through nxsgpu_search(), which has
+ * the exact two-pass path).  While batch i runs, the host prepares and uploads
+ * batch i+1.  Outputs must be distinct per batch in flight.
+ */
+static int
+slot_ensure(nxsgpu_index::dev_slot_t &sl, size_t ws_need, size_t stage_need)
+{
+	if (sl.ws_len < ws_need) {
+		(void)hipFree(sl.ws);
+		sl.ws = NULL;
+		sl.ws_len = 0;
+		ws_need = (ws_need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+		if (hipMalloc(&sl.ws, ws_need) != hipSuccess) {
+			set_error("hipMalloc(%zu) for the query workspace failed", ws_need);
+			return -1;
+		}
+		sl.ws_len = ws_need;
+	}
+	if (sl.h_stage_len < stage_need) {
+		if (sl.h_stage) {
+			(void)hipHostFree(sl.h_stage);
+		}
+		sl.h_stage = NULL;
+		sl.h_stage_len = 0;
+		stage_need = (stage_need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+		if (hipHostMalloc((void **)&sl.h_stage, stage_need, hipHostMallocDefault) != hipSuccess) {
+			set_error("hipHostMalloc(%zu) failed", stage_need);
+			return -1;
+		}
+		sl.h_stage_len = stage_need;
+	}
+	return 0;
+}
+
+/* what a batch writes its results to */
+struct batch_out_t {
+	/* caller's device arrays [nq][limit] / [nq] (nxsgpu_search_dev_begin) ... */
+	uint64_t *	d_ids;
+	float *		d_sc;
+	uint32_t *	d_cnt;
+	/* ... or record blocks (nxsgpu_batch_begin) */
+	bool		records, gather;
+	const uint32_t *slot_of_plan;
+	const uint32_t *status;
+	uint32_t	n_slots;
+};
+
+/* a failed _begin must not leave kernels queued over a slot it reports free */
+static int
+begin_fail(nxsgpu_index_t *ix)
+{
+	(void)hipStreamSynchronize(ix->stream_up);
+	(void)hipStreamSynchronize(ix->stream);
+	(void)hipStreamSynchronize(ix->stream2);
+	(void)hipStreamSynchronize(ix->stream3);
+	(void)hipStreamSynchronize(ix->stream_down);
+	(void)hipGetLastError();
+	return -1;
+}
+
+
+static int
+batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, const batch_out_t &o)
+{
+	const uint32_t seg_cap = ix->cfg.seg_cap;
+	nxsgpu_index::dev_slot_t *sl = NULL;
+	uint64_t total_post = 0;
+	const bool gather = o.records && o.gather && ix->comm;
+	const uint32_t world = gather ? (uint32_t)nxsgpu_comm_world(ix->comm) : 1u;
+	const int my_rank = gather ? nxsgpu_comm_rank(ix->comm) : 0;
+
+	if (limit == 0 || limit > NXSGPU_FAST_K) {
+		set_error("device batches take limit 1..%d", NXSGPU_FAST_K);
+		return -1;
+	}
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	for (int i = 0; i < 2; i++) {
+		if (!ix->slot[i].active) {
+			sl = &ix->slot[i];
+			break;
+		}
+	}
+	if (!sl) {
+		set_error("two batches are already in flight");
+		return -1;
+	}
+	if (!sl->wl) {
+		sl->wl = new worklist_t();
+	}
+	worklist_t &wl = *sl->wl;
+	auto now_us = []() -> double {
+		struct timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+	};
+	const double tb0 = now_us();
+	double tb1 = 0, tb2 = 0, tb3 = 0, tc[6] = { 0, 0, 0, 0, 0, 0 };
+	sl->nq = nq;
+	sl->postings = 0;
+	sl->records = o.records;
+	sl->n_slots = o.n_slots;
+	sl->k = limit;
+	sl->world = world;
+	sl->rec_bytes = NXSGPU_REC_BYTES(limit);
+	sl->block_bytes = o.records ? NXSGPU_BLOCK_BYTES(o.n_slots, limit) : 0;
+	if (nq == 0 && !o.records) {
+		sl->seq = ++ix->slot_seq;
+		sl->active = true;
+		return 0;
+	}
+
+	/*
+	 * A small batch with nothing else in flight (a single nxs_index_search())
+	 * is latency-bound: everything goes down ONE stream -- no cross-stream event
+	 * hops, each worth 10-20 us.  Otherwise plans go up and records come down on
+	 * their own streams, beside the neighbouring batches' scans.
+	 */
+	bool others = false;
+	for (int i = 0; i < 2; i++) {
+		others = others || ix->slot[i].active;
+	}
+	const bool solo = nq <= 64 && !others && !gather;
+	hipStream_t s_up = solo ? ix->stream : ix->stream_up;
+	/* the records come down on their own stream only when there is a collective
+	 * to run beside the next batch's scans; a plain 135 KB copy rides the scan
+	 * stream (a separate stream showed sporadic 5-20 ms host stalls in the copy
+	 * submission, once or twice per process) */
+	const bool own_down = !solo && gather && !ix->cfg.down_inline;
+	hipStream_t s_down = own_down ? ix->stream_down : ix->stream;
+
+	/* record blocks: pinned host copies of all ranks' blocks; on the device the
+	 * own block is part of the uploaded workspace (one rank), or sits at its rank
+	 * position of the all-gather's receive buffer (in-place send) */
+	const size_t recs_len = (size_t)o.n_slots * sl->rec_bytes;
+	if (o.records) {
+		const size_t need = (size_t)world * sl->block_bytes + 256;
+		if (gather && sl->d_blocks_len < need) {
+			(void)hipFree(sl->d_blocks);
+			sl->d_blocks = NULL;
+			sl->d_blocks_len = 0;
+			if (hipMalloc((void **)&sl->d_blocks, need) != hipSuccess) {
+				set_error("hipMalloc(%zu) for the record blocks failed", need);
+				return -1;
+			}
+			sl->d_blocks_len = need;
+		}
+		if (sl->h_blocks_len < need) {
+			if (sl->h_blocks) {
+				(void)hipHostFree(sl->h_blocks);
+			}
+			sl->h_blocks = NULL;
+			sl->h_blocks_len = 0;
+			if (hipHostMalloc((void **)&sl->h_blocks, need, hipHostMallocMapped) != hipSuccess ||
+			    hipHostGetDevicePointer((void **)&sl->h_blocks_dev, sl->h_blocks, 0) != hipSuccess) {
+				set_error("hipHostMalloc(%zu) failed", need);
+				return -1;
+			}
+			sl->h_blocks_len = need;
+		}
+	}
+	/* (a communicator of ONE rank still goes through the collective: the same
+	 * code path as N ranks, and what the one-GPU tests exercise) */
+	/*
+	 * One rank, no collective: the heap replay writes the records STRAIGHT into
+	 * the pinned host block (mapped into the device's address space) -- 135 KB of
+	 * posted PCIe writes per batch instead of a copy command after the kernels
+	 * (whose submission showed sporadic 5-20 ms host stalls).  The host zeroes the
+	 * block and fills the status words itself before the launch.
+	 */
+	const bool block_in_ws = false;
+	const bool block_on_host = o.records && !gather;
+
+	/* plans straight into the pinned staging area (room for the work list:
+	 * <= target + nq ranges, see build_worklist) */
+	const uint64_t wave_target = ix->cfg.wave_target;
+	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
+	const size_t stage_need = 32768 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
+	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + sl->block_bytes;
+	if (slot_ensure(*sl, 0, stage_need) != 0) {
+		return -1;
+	}
+	uint8_t *hp = sl->h_stage;
+	dev_query_t *h_q = carve<dev_query_t>(hp, nq);
+	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post) != 0) {
+		return -1;
+	}
+	build_worklist(ix, h_q, nq, wl, solo);
+	tb1 = now_us();
+	const uint64_t nseg = wl.n_segs;
+	if (nseg > seg_bound) {
+		set_error("work list larger than its bound (%llu > %zu)", (unsigned long long)nseg, seg_bound);
+		return -1;
+	}
+	/*
+	 * Everything the kernels read from the host -- the zero-filled flag, threshold
+	 * and record arrays included -- is ONE block and ONE copy up.
+	 */
+	qmeta_t *h_qmeta = carve<qmeta_t>(hp, nq);
+	item_t *h_items = carve<item_t>(hp, nseg);
+	uint32_t *h_bnd_q = carve<uint32_t>(hp, nseg + nq);
+	uint32_t *h_qorder = carve<uint32_t>(hp, nq);
+	uint32_t *h_recslot = carve<uint32_t>(hp, nq);
+	uint32_t *h_ovf = carve<uint32_t>(hp, nq);
+	float *h_pub = carve<float>(hp, nseg);
+	uint8_t *h_block = carve<uint8_t>(hp, block_in_ws ? sl->block_bytes : 0);
+	const size_t up_len = (size_t)(hp - sl->h_stage);
+	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, o.n_slots);
+	if (nq) {
+		memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
+		memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));
+		memcpy(h_bnd_q, wl.bnd_q.data(), (nseg + nq) * 4);
+		memcpy(h_qorder, wl.qorder.data(), nq * 4);
+		memset(h_ovf, 0, nq * 4);
+		memset(h_pub, 0, nseg * 4);
+	}
+	sl->h_ovf = h_ovf;
+	if (o.records) {
+		for (uint32_t i = 0; i < nq; i++) {
+			if (o.slot_of_plan[i] >= o.n_slots) {
+				set_error("plan %u: record slot %u out of range", i, o.slot_of_plan[i]);
+				return -1;
+			}
+			h_recslot[i] = o.slot_of_plan[i];
+		}
+		if (block_in_ws) {
+			memset(h_block, 0, sl->block_bytes);
+		}
+		if (block_on_host) {
+			/* (the slot's previous batch was collected: nothing reads it any more) */
+			memset(sl->h_blocks, 0, recs_len);
+			h_status = (uint32_t *)(sl->h_blocks + recs_len);
+		}
+		if (o.status) {
+			memcpy(h_status, o.status, (size_t)o.n_slots * 4);
+		} else {
+			memset(h_status, 0, (size_t)o.n_slots * 4);
+		}
+	}
+
+	/* device workspace: the uploaded block first (same carve sequence => same
+	 * offsets), then what only the kernels touch */
+	const size_t ws_need = 32768 + up_len + nseg * 4
+	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8 + nseg * (16 * 4 + 64 * 4);
+	if (slot_ensure(*sl, ws_need, 0) != 0) {
+		return -1;
+	}
+	uint8_t *p = (uint8_t *)sl->ws;
+	dev_query_t *d_q = carve<dev_query_t>(p, nq);
+	qmeta_t *d_qmeta = carve<qmeta_t>(p, nq);
+	item_t *d_items = carve<item_t>(p, nseg);
+	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
+	uint32_t *d_qorder = carve<uint32_t>(p, nq);
+	uint32_t *d_recslot = carve<uint32_t>(p, nq);
+	uint32_t *d_ovf = carve<uint32_t>(p, nq);
+	float *d_pub = carve<float>(p, nseg);
+	uint8_t *d_myblock = carve<uint8_t>(p, block_in_ws ? sl->block_bytes : 0);
+	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
+	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
+	uint32_t *d_cand_doc = carve<uint32_t>(p, nseg * (size_t)seg_cap);
+	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
+	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
+	float *d_cold_top = carve<float>(p, nseg * 64);
+	if (block_on_host) {
+		d_myblock = sl->h_blocks_dev;
+	} else if (o.records && !block_in_ws) {
+		d_myblock = sl->d_blocks + (size_t)my_rank * sl->block_bytes;
+	}
+
+	sl->seq = ++ix->slot_seq;
+	tb2 = now_us();
+	if (hipMemcpyAsync(sl->ws, sl->h_stage, up_len, hipMemcpyHostToDevice, s_up) != hipSuccess) {
+		set_error("query upload failed");
+		return begin_fail(ix);
+	}
+	if (o.records && !block_in_ws && !block_on_host) {
+		if ((recs_len && hipMemsetAsync(d_myblock, 0, recs_len, s_up) != hipSuccess) ||
+		    (o.n_slots && hipMemcpyAsync(d_myblock + recs_len, h_status, (size_t)o.n_slots * 4,
+		    hipMemcpyHostToDevice, s_up) != hipSuccess)) {
+			set_error("record block setup failed");
+			return begin_fail(ix);
+		}
+	}
+
+	tc[0] = now_us();
+	scan_args_t sa;
+	replay_args_t ra;
+	memset(&sa, 0, sizeof(sa));
+	sa.post = ix->d_post[algo];
+	sa.dense_col = ix->d_dense_col[algo];
+	sa.dense_stride = ix->n_docs;
+	sa.queries = d_q;
+	sa.n_docs = ix->n_docs;
+	sa.qmeta = d_qmeta;
+	sa.items = d_items;
+	sa.k = limit;
+	sa.seg_cap = seg_cap;
+	sa.seg_count = d_seg_count;
+	sa.cand_doc = d_cand_doc;
+	sa.cand_sc = d_cand_sc;
+	sa.overflow = d_ovf;
+	sa.cursors = d_cursors;
+	sa.pub = d_pub;
+	sa.cold_state = d_cold_state;
+	sa.cold_top = d_cold_top;
+	memset(&ra, 0, sizeof(ra));
+	ra.qmeta = d_qmeta;
+	ra.seg_cap = seg_cap;
+	ra.seg_count = d_seg_count;
+	ra.cand_doc = d_cand_doc;
+	ra.cand_sc = d_cand_sc;
+	ra.doc_ids = ix->d_doc_ids;
+	ra.k = limit;
+	ra.out_ids = o.d_ids;
+	ra.out_sc = o.d_sc;
+	ra.out_count = o.d_cnt;
+	ra.skip = d_ovf;
+	if (o.records) {
+		ra.rec_base = d_myblock;
+		ra.rec_slot = d_recslot;
+		ra.rec_bytes = (uint32_t)sl->rec_bytes;
+	}
+
+	/*
+	 * The range cursors depend on the uploaded plans only: k_cursors (a small,
+	 * latency-bound grid of binary searches) runs on the upload stream, beside
+	 * the previous batch's scans instead of in front of this batch's.
+	 */
+	if (nq && wl.need_cursors) {
+		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), s_up);
+	}
+	tc[1] = now_us();
+	if (!solo && (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
+	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess)) {
+		set_error("query upload failed");
+		return begin_fail(ix);
+	}
+	tc[2] = now_us();
+	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
+	if (nq) {
+		if (ix->cfg.one_replay) {
+			launch_scan(MODE_TOPK, ix, sa, wl);
+			if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
+			nxs_launch_replay(HEAP_REG, nq, 0, ix->stream, ra);
+		} else {
+			/* (profile: "replay" is then only what the last class's replay adds
+			 * after the last scan) */
+			launch_scan(MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL);
+		}
+	} else if (ix->profiling) {
+		(void)hipEventRecord(sl->ev_t[1], ix->stream);
+	}
+	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], ix->stream);
+	tc[3] = now_us();
+	if (hipGetLastError() != hipSuccess) {
+		set_error("kernel launch failed");
+		return begin_fail(ix);
+	}
+	if (!o.records) {
+		if (hipMemcpyAsync(h_ovf, d_ovf, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+		    hipEventRecord(sl->ev_done, ix->stream) != hipSuccess) {
+			set_error("copy failed");
+			return begin_fail(ix);
+		}
+	} else {
+		/*
+		 * The records leave on their own stream: the all-gather (one collective
+		 * per batch, sharded runs only) and the copy to pinned memory overlap the
+		 * next batch's scans instead of sitting in front of them.
+		 */
+		if (own_down && (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
+		    hipStreamWaitEvent(s_down, sl->ev_res, 0) != hipSuccess)) {
+			set_error("event failed");
+			return begin_fail(ix);
+		}
+		if (gather) {
+			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes, s_down) != 0) {
+				return begin_fail(ix);
+			}
+			if (hipMemcpyAsync(sl->h_blocks, sl->d_blocks, (size_t)world * sl->block_bytes,
+			    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
+				set_error("copy failed");
+				return begin_fail(ix);
+			}
+		} else if (!block_on_host && sl->block_bytes && hipMemcpyAsync(sl->h_blocks, d_myblock, sl->block_bytes,
+		    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
+			set_error("copy failed");
+			return begin_fail(ix);
+		}
+		if (hipEventRecord(sl->ev_done, s_down) != hipSuccess) {
+			set_error("event failed");
+			return begin_fail(ix);
+		}
+	}
+	sl->postings = total_post;
+	sl->active = true;
+	if (ix->cfg.debug_timing) {
+		tb3 = now_us();
+		fprintf(stderr, "[nxsgpu begin #%llu] plan+worklist %.0f us, staging+alloc %.0f us, enqueue %.0f us "
+		    "(upload %.0f, cursors %.0f, fork %.0f, scans+replays %.0f, tail %.0f)\n",
+		    (unsigned long long)sl->seq, tb1 - tb0, tb2 - tb1, tb3 - tb2,
+		    tc[0] - tb2, tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tb3 - tc[3]);
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search_dev_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+{
+	batch_out_t o;
+
+	memset(&o, 0, sizeof(o));
+	if (!d_doc_ids || !d_scores || !d_counts) {
+		set_error("nxsgpu_search_dev: outputs must be non-NULL");
+		return -1;
+	}
+	o.d_ids = d_doc_ids;
+	o.d_sc = d_scores;
+	o.d_cnt = d_counts;
+	return batch_begin(ix, algo, limit, queries, nq, o);
+}
+
+extern "C" int
+nxsgpu_batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *plans,
+    uint32_t n_plans, const uint32_t *slot_of_plan, const uint32_t *status, uint32_t n_slots,
+    int gather)
+{
+	batch_out_t o;
+
+	memset(&o, 0, sizeof(o));
+	if (n_plans && !slot_of_plan) {
+		set_error("nxsgpu_batch_begin: slot_of_plan is NULL");
+		return -1;
+	}
+	o.records = true;
+	o.gather = gather != 0;
+	o.slot_of_plan = slot_of_plan;
+	o.status = status;
+	o.n_slots = n_slots;
+	return batch_begin(ix, algo, limit, plans, n_plans, o);
+}
+
+static nxsgpu_index::dev_slot_t *
+oldest_slot(nxsgpu_index_t *ix)
+{
+	nxsgpu_index::dev_slot_t *sl = NULL;
+
+	for (int i = 0; i < 2; i++) {
+		if (ix->slot[i].active && (!sl || ix->slot[i].seq < sl->seq)) {
+			sl = &ix->slot[i];
+		}
+	}
+	return sl;
+}
+
+static int
+slot_wait(nxsgpu_index_t *ix, nxsgpu_index::dev_slot_t *sl)
+{
+	if (hipEventSynchronize(sl->ev_done) != hipSuccess) {
+		set_error("batch failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	if (ix->profiling && (sl->nq || sl->records)) {
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, sl->ev_t[0], sl->ev_t[1]);
+		(void)hipEventElapsedTime(&b, sl->ev_t[1], sl->ev_t[2]);
+		ix->prof.launches++;
+		ix->prof.scan_ms += a;
+		ix->prof.replay_ms += b;
+		ix->prof.postings += sl->postings;
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_search_dev_end(nxsgpu_index_t *ix)
+{
+	nxsgpu_index::dev_slot_t *sl = oldest_slot(ix);
+
+	if (!sl) {
+		set_error("nxsgpu_search_dev_end: no batch in flight");
+		return -1;
+	}
+	if (sl->records) {
+		set_error("nxsgpu_search_dev_end: the oldest batch in flight is a record batch (nxsgpu_batch_end)");
+		return -1;
+	}
+	sl->active = false;
+	if (sl->nq == 0) {
+		return 0;
+	}
+	if (slot_wait(ix, sl) != 0) {
+		return -1;
+	}
+	const uint32_t *h_ovf = sl->h_ovf;
+	for (uint32_t i = 0; i < sl->nq; i++) {
+		if (h_ovf[i]) {
+			return 1;
+		}
+	}
+	return 0;
+}
+
+extern "C" int
+nxsgpu_batch_end(nxsgpu_index_t *ix, nxsgpu_batch_view_t *view)
+{
+	nxsgpu_index::dev_slot_t *sl = oldest_slot(ix);
+
+	if (!sl) {
+		set_error("nxsgpu_batch_end: no batch in flight");
+		return -1;
+	}
+	if (!sl->records) {
+		set_error("nxsgpu_batch_end: the oldest batch in flight is a device batch (nxsgpu_search_dev_end)");
+		return -1;
+	}
+	sl->active = false;
+	if (slot_wait(ix, sl) != 0) {
+		return -1;
+	}
+	view->n_slots = sl->n_slots;
+	view->k = sl->k;
+	view->world = sl->world;
+	view->rec_bytes = sl->rec_bytes;
+	view->block_bytes = sl->block_bytes;
+	/* with one rank the own block sits at position 0 of both copies */
+	view->blocks = sl->h_blocks;
+	return 0;
+}
+
+extern "C" int
+nxsgpu_batches_in_flight(const nxsgpu_index_t *ix)
+{
+	return (ix->slot[0].active ? 1 : 0) + (ix->slot[1].active ? 1 : 0);
+}
+
+extern "C" void
+nxsgpu_index_reconfigure(nxsgpu_index_t *ix)
+{
+	cfg_from_env(ix->cfg);
+}
+
+extern "C" int
+nxsgpu_search_dev(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
+    uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
+{
+	if (ix->slot[0].active || ix->slot[1].active) {
+		set_error("nxsgpu_search_dev: finish the batches in flight first (nxsgpu_search_dev_end)");
+		return -1;
+	}
+	if (nxsgpu_search_dev_begin(ix, algo, limit, queries, nq, d_doc_ids, d_scores, d_counts) != 0) {
+		return -1;
+	}
+	return nxsgpu_search_dev_end(ix);
+}
+
+/* ---- query sharding: slices and the RCCL communicator ---------------------------- */
+
+extern "C" void
+nxsgpu_shard_slice(uint64_t n, int rank, int world, uint64_t *lo, uint64_t *hi)
+{
+	if (world < 1) {
+		world = 1;
+	}
+	*lo = n * (uint64_t)rank / (uint64_t)world;
+	*hi = n * ((uint64_t)rank + 1) / (uint64_t)world;
+}
+
+extern "C" uint64_t
+nxsgpu_shard_capacity(uint64_t n, int world)
+{
+	uint64_t cap = 0, lo, hi;
+
+	for (int r = 0; r < (world < 1 ? 1 : world); r++) {
+		nxsgpu_shard_slice(n, r, world, &lo, &hi);
+		cap = std::max(cap, hi - lo);
+	}
+	return cap;
+}

@@ -33,7 +33,9 @@ extern "C" {
 
 #define	NXSGPU_MAX_TOKENS	32	/* tokens per query on the device path */
 #define	NXSGPU_MAX_PROG		256	/* postfix program bytes */
-#define	NXSGPU_FAST_K		64	/* limit up to which top-k stays in LDS */
+#define	NXSGPU_FAST_K		64	/* limit up to which the heap lives across the lanes of a wavefront */
+#define	NXSGPU_BIG_K		8000	/* limit up to which the candidate filter applies (heap in LDS);
+					 * beyond it: the exact two-pass path */
 
 /* ranking_algo_t (reference src/index/index.h:30-34) */
 #define	NXSGPU_TF_IDF		0
@@ -242,7 +244,7 @@ int		nxsgpu_fuzzy(nxsgpu_index_t *, const uint8_t *tok_bytes,
  * contiguous slice of the batch, and ONE RCCL all-gather of fixed-size
  * per-query records reassembles the batch on every rank.
  *
- * Record of one query (limit k <= NXSGPU_FAST_K), NXSGPU_REC_BYTES(k) bytes:
+ * Record of one query (limit k <= NXSGPU_BIG_K), NXSGPU_REC_BYTES(k) bytes:
  *	u32 count | u32 flags | u64 doc_id[k] | f32 score[k] | pad to 8
  * A rank's BLOCK = n_slots records followed by n_slots u32 status words (the
  * nxs_err_t of a query that never reached the device; padded to 8 bytes).

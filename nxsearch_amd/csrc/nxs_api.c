@@ -1165,13 +1165,13 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	pd->limit = sp.limit;
 	pd->algo = sp.algo;
 	pd->world = 1;
-	/* query sharding: fixed-size records need limit <= FAST_K;
+	/* query sharding: fixed-size records, limit <= NXSGPU_BIG_K;
 	 * larger limits run replicated -- every rank computes the whole batch */
-	if (idx->comm && sp.limit <= NXSGPU_FAST_K) {
+	if (idx->comm && sp.limit <= NXSGPU_BIG_K) {
 		pd->rank = nxsgpu_comm_rank(idx->comm);
 		pd->world = nxsgpu_comm_world(idx->comm);
 		nxsgpu_shard_slice(n, pd->rank, pd->world, &lo, &hi);
-	} else if (idx->emu_world > 1 && sp.limit <= NXSGPU_FAST_K) {
+	} else if (idx->emu_world > 1 && sp.limit <= NXSGPU_BIG_K) {
 		/* tests: this process plays ONE rank of a W-rank run, no collective */
 		pd->rank = idx->emu_rank;
 		pd->world = idx->emu_world;
@@ -1192,7 +1192,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	}
 	t1 = now_s();
 	idx->hp_plan += t1 - t0;
-	if (sp.limit <= NXSGPU_FAST_K) {
+	if (sp.limit <= NXSGPU_BIG_K) {
 		plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
 		slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
 		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
@@ -1491,7 +1491,7 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 		}
 		idx->hp_resps += now_s() - t0;
 	} else {
-		/* limit > NXSGPU_FAST_K: the exact two-pass path for the whole batch */
+		/* limit > NXSGPU_BIG_K: the exact two-pass path for the whole batch */
 		for (size_t i = 0; i < nl; i++) {
 			const qprep_t *q = &pd->prep[i];
 			if (!q->errcode && !q->empty) {

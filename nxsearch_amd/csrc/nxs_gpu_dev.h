@@ -376,4 +376,117 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
 #endif
 #define	TCAND_CAP	64
 
+/*
+ * MODE_BIG: candidate threshold for 64 < k <= NXSGPU_BIG_K.
+ *
+ * The reference's heap drops an item iff it is full and the item is <= its root
+ * (heap.c:68-74); the root is the k-th largest score fed so far.  The filter
+ * needs a value that is NEVER ABOVE that root: any lower bound of the k-th
+ * largest score among the docs this wavefront has emitted will do (they were
+ * all fed before the doc being tested).  A histogram gives one without keeping
+ * k scores: bucket(s) = the top bits of the float (sign 0, exponent, 5 mantissa
+ * bits: 32 buckets per octave, 2^-7 .. 2^9, clamped) is monotone in s, so if the
+ * buckets >= j together hold >= k emitted docs, the k-th largest emitted score
+ * is >= the lower edge of bucket j -- exactly representable, no rounding
+ * argument needed.  Docs that were not emitted (score <= an earlier threshold)
+ * are not counted: the bound only gets weaker, never wrong.  Candidates = what
+ * beats the edge; the replay applies the exact test.
+ */
+#define	BIGK_BUCKETS	512
+#define	BIGK_SH		18
+#define	BIGK_BASE	((127 - 7) << 5)
+
+static __device__ __forceinline__ uint32_t
+bigk_bucket(float s)
+{
+	const int b = (int)(__float_as_uint(s) >> BIGK_SH) - BIGK_BASE;
+	return (uint32_t)min(max(b, 0), BIGK_BUCKETS - 1);
+}
+
+/* lower edge of bucket j (bucket 0 reaches down to 0: "no threshold") */
+static __device__ __forceinline__ float
+bigk_edge(uint32_t j)
+{
+	return j ? __uint_as_float((j + BIGK_BASE) << BIGK_SH) : 0.0f;
+}
+
+/* count the emitted candidates of this step (lanes with `cand`) */
+static __device__ __forceinline__ void
+bigk_note(uint32_t *hist, bool cand, float sc)
+{
+	if (cand) {
+		(void)__hip_atomic_fetch_add(&hist[bigk_bucket(sc)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	}
+}
+
+/*
+ * Largest bucket edge with >= k counted docs at or above it (0 if there is none).
+ * Lane L owns buckets [8L, 8L + 8): its sum, a suffix sum over the lanes, the
+ * highest lane whose suffix reaches k, then that lane's own eight counters.
+ * Wave-uniform result.
+ */
+static __device__ __forceinline__ float
+bigk_threshold(const uint32_t *hist, uint32_t k)
+{
+	const unsigned lane = threadIdx.x & 63;
+	/* one wavefront's DS operations execute in issue order: the atomics above
+	 * are visible; this only keeps the compiler from moving the reads up */
+	asm volatile("" ::: "memory");
+	const uint4 lo4 = *(const uint4 *)&hist[lane * 8];
+	const uint4 hi4 = *(const uint4 *)&hist[lane * 8 + 4];
+	const uint32_t c[8] = { lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w };
+	uint32_t own = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		own += c[i];
+	}
+	uint32_t suf = own;
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) {
+		const uint32_t v = (uint32_t)__shfl_down((int)suf, o);
+		if (lane + o < WAVE) {
+			suf += v;
+		}
+	}
+	const uint64_t m = __builtin_amdgcn_ballot_w64(suf >= k);
+	if (m == 0) {
+		return 0.0f;
+	}
+	const int L = 63 - __builtin_clzll(m);		/* suffix sums do not increase with the lane */
+	uint32_t acc = suf - own, j = 0;
+	bool found = false;
+#pragma unroll
+	for (int i = 7; i >= 0; i--) {
+		acc += c[i];
+		if (!found && acc >= k) {
+			j = lane * 8 + i;
+			found = true;
+		}
+	}
+	return bigk_edge((uint32_t)__builtin_amdgcn_readlane((int)j, L));
+}
+
+/*
+ * The bookkeeping after a step has emitted `ne` candidates (wave-uniform; the
+ * lanes with `cand` carry them): count them, and every `upd` candidates read the
+ * threshold off the histogram again.
+ */
+static __device__ __forceinline__ void
+bigk_account(uint32_t *hist, uint32_t k, uint32_t upd, bool cand, float sc, uint32_t ne,
+    uint32_t &since, float hint, float &thr)
+{
+	bigk_note(hist, cand, sc);
+	since += ne;
+	if (since >= upd) {
+		thr = fmaxf(hint, bigk_threshold(hist, k));
+		since = 0;
+	}
+}
+
+static __device__ __forceinline__ uint32_t
+bigk_update_every(uint32_t k)
+{
+	return max(k >> 4, 32u);
+}
+
 #endif /* NXS_GPU_DEV_H */

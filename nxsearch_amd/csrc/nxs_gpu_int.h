@@ -108,6 +108,8 @@ struct gpu_cfg_t {
 	uint32_t	scanm_minnt, scanm_maxnt;
 	uint32_t	rmin;		/* fewest tokens for k_scanr (NXS_GPU_NOSCANR2 => 3) */
 	uint32_t	seg_cap;	/* NXS_GPU_SEGCAP */
+	uint32_t	seg_cap_big;	/* NXS_GPU_SEGCAP_BIG: the same for limits > 64 (0: 6 x limit) */
+	uint64_t	big_minpost;	/* NXS_GPU_BIG_MINPOST: postings per range and unit of limit, limits > 64 */
 	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */
 	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
@@ -239,7 +241,17 @@ bswap32(uint32_t v)
 /* k_scan: posting iteration + LDS score accumulation + pre-selection   */
 /* ------------------------------------------------------------------ */
 
-enum { MODE_TOPK = 0, MODE_COUNT = 1, MODE_ALL = 2 };
+/*
+ * MODE_TOPK: candidate filter pass, 1 <= k <= 64 (the wavefront's k best scores
+ *            in one VGPR, lane i = i-th largest);
+ * MODE_BIG:  the same filter for 64 < k <= NXSGPU_BIG_K (the API's default limit
+ *            is 1000, nxs_impl.h:39): the threshold is a LOWER BOUND of the k-th
+ *            largest score the wavefront has emitted, read off a histogram of
+ *            score buckets in LDS (bigk_*, nxs_gpu_dev.h);
+ * MODE_COUNT / MODE_ALL: the exact two-pass path (count matches, emit them all).
+ */
+enum { MODE_TOPK = 0, MODE_COUNT = 1, MODE_ALL = 2, MODE_BIG = 3 };
+#define	MODE_FILTERS(m)	((m) == MODE_TOPK || (m) == MODE_BIG)
 
 /* a query's doc space is cut into n_groups ranges of group_docs docs; one
  * wavefront (work item) per range; its candidates go to segment seg_first+g */

@@ -288,7 +288,8 @@ k_replay(const replay_args_t A)
 	if (LDS_HEAP) {
 		cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(A.k, (uint32_t)WAVE));
 	} else if (HEAP == HEAP_LDS) {
-		cap = (uint32_t)min((uint64_t)A.k, A.heap_off[q + 1] - A.heap_off[q]);
+		/* (no heap_off: the filter pass of a limit > 64, every heap has room for k) */
+		cap = A.heap_off ? (uint32_t)min((uint64_t)A.k, A.heap_off[q + 1] - A.heap_off[q]) : A.k;
 	} else {
 		hs = A.gheap_s + A.heap_off[q];
 		hd = A.gheap_d + A.heap_off[q];

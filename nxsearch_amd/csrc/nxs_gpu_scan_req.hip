@@ -57,7 +57,13 @@ __global__ void __launch_bounds__(WAVE)
 k_scan1(const scan_args_t A)
 {
 	constexpr int U = 4;
+	__shared__ __attribute__((aligned(16))) uint32_t s_hist[MODE == MODE_BIG ? BIGK_BUCKETS : 4];
 	const unsigned lane = threadIdx.x;
+	if constexpr (MODE == MODE_BIG) {
+		for (uint32_t i = lane; i < BIGK_BUCKETS; i += WAVE) {
+			s_hist[i] = 0;
+		}
+	}
 	const item_t item = A.items[A.item_base + blockIdx.x];
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
@@ -92,10 +98,13 @@ k_scan1(const scan_args_t A)
 	}
 
 	float top = -INFINITY;
-	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
+	uint32_t big_since = 0;
+	const uint32_t big_upd = bigk_update_every(A.k);
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
 
 	while (hi > lo) {
@@ -121,7 +130,7 @@ k_scan1(const scan_args_t A)
 				continue;
 			}
 			const uint32_t ne = __popcll(bal);
-			if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+			if (MODE_FILTERS(MODE) && n_out + ne > A.seg_cap) {
 				ovf = true;
 			} else {
 				const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
@@ -132,6 +141,9 @@ k_scan1(const scan_args_t A)
 				}
 			}
 			n_out += ne;
+			if constexpr (MODE == MODE_BIG) {
+				bigk_account(s_hist, A.k, big_upd, cand, iv[u], ne, big_since, hint, thr);
+			}
 			if (track) {
 				while (bal) {
 					const int L = 63 - __clzll(bal);
@@ -151,11 +163,16 @@ k_scan1(const scan_args_t A)
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
+	if constexpr (MODE == MODE_BIG) {
+		if (!ovf) {
+			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+		}
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
-		if (MODE == MODE_TOPK && ovf) {
+		if (MODE_FILTERS(MODE) && ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -218,6 +235,7 @@ k_scanr(const scan_args_t A)
 	__shared__ uint8_t s_bits[WAVE];		/* presence mask of the driver lane's doc */
 	__shared__ float s_imp[NT][WAVE];		/* [token][driver lane] */
 	__shared__ uint32_t s_truth[8];
+	__shared__ __attribute__((aligned(16))) uint32_t s_hist[MODE == MODE_BIG ? BIGK_BUCKETS : 4];
 
 	const unsigned lane = threadIdx.x;
 	const item_t item = A.items[A.item_base + blockIdx.x];
@@ -240,6 +258,11 @@ k_scanr(const scan_args_t A)
 	auto hash_of = [](uint32_t doc) -> uint32_t {
 		return (doc * 2654435761u) >> (32 - SCANR_HT_BITS);
 	};
+	if constexpr (MODE == MODE_BIG) {
+		for (uint32_t i = lane; i < BIGK_BUCKETS; i += WAVE) {
+			s_hist[i] = 0;
+		}
+	}
 	s_bits[lane] = 0;
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
@@ -323,10 +346,13 @@ k_scanr(const scan_args_t A)
 	});
 
 	float top = -INFINITY;
-	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
+	uint32_t big_since = 0;
+	const uint32_t big_upd = bigk_update_every(A.k);
 	uint32_t n_out = 0;
 	bool ovf = false;
 	bool done = false;		/* a required slot ran out: nothing below can match */
@@ -495,7 +521,7 @@ k_scanr(const scan_args_t A)
 				uint64_t bal = ballot64(cand);
 				if (bal) {
 					const uint32_t ne = __popcll(bal);
-					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+					if (MODE_FILTERS(MODE) && n_out + ne > A.seg_cap) {
 						ovf = true;
 					} else {
 						const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
@@ -506,6 +532,9 @@ k_scanr(const scan_args_t A)
 						}
 					}
 					n_out += ne;
+					if constexpr (MODE == MODE_BIG) {
+						bigk_account(s_hist, A.k, big_upd, cand, sc, ne, big_since, hint, thr);
+					}
 					if (track) {
 						while (bal) {
 							const int L = 63 - __clzll(bal);
@@ -542,11 +571,16 @@ k_scanr(const scan_args_t A)
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));
 	}
+	if constexpr (MODE == MODE_BIG) {
+		if (!ovf) {
+			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+		}
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
-		if (MODE == MODE_TOPK && ovf) {
+		if (MODE_FILTERS(MODE) && ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -588,6 +622,7 @@ k_scanh(const scan_args_t A)
 	__shared__ uint32_t s_cd[MAXE];
 	__shared__ float s_cs[MAXE];
 	__shared__ uint32_t s_truth[8];
+	__shared__ uint32_t s_hist[4];	/* (MODE_BIG never comes here) */
 	__shared__ int64_t s_init[16];
 
 	const unsigned lane = threadIdx.x;
@@ -671,10 +706,13 @@ k_scanh(const scan_args_t A)
 	}
 
 	float top = -INFINITY;
-	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
+	uint32_t big_since = 0;
+	const uint32_t big_upd = bigk_update_every(A.k);
 	uint32_t n_out = 0;
 	bool ovf = false;
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
@@ -829,7 +867,7 @@ k_scanh(const scan_args_t A)
 			}
 			if (MODE != MODE_COUNT && ncand) {
 				WAVE_SYNC();
-				if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
+				if (MODE_FILTERS(MODE) && n_out + ncand > A.seg_cap) {
 					ovf = true;
 				} else {
 					/* rank by doc, descending: docs are distinct */
@@ -877,11 +915,16 @@ k_scanh(const scan_args_t A)
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
+	if constexpr (MODE == MODE_BIG) {
+		if (!ovf) {
+			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+		}
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
-		if (MODE == MODE_TOPK && ovf) {
+		if (MODE_FILTERS(MODE) && ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -906,6 +949,7 @@ nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a)
 {
 	switch (mode) {
 	case MODE_TOPK: hipLaunchKernelGGL((k_scan1<MODE_TOPK>), dim3(grid), dim3(WAVE), 0, st, a); break;
+	case MODE_BIG: hipLaunchKernelGGL((k_scan1<MODE_BIG>), dim3(grid), dim3(WAVE), 0, st, a); break;
 	case MODE_COUNT: hipLaunchKernelGGL((k_scan1<MODE_COUNT>), dim3(grid), dim3(WAVE), 0, st, a); break;
 	default: hipLaunchKernelGGL((k_scan1<MODE_ALL>), dim3(grid), dim3(WAVE), 0, st, a); break;
 	}
@@ -937,6 +981,7 @@ nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStre
 {
 	switch (mode) {
 	case MODE_TOPK: launch_scanr_mode<MODE_TOPK>(nt_bucket, hash, dim3(grid), st, a); break;
+	case MODE_BIG: launch_scanr_mode<MODE_BIG>(nt_bucket, hash, dim3(grid), st, a); break;
 	case MODE_COUNT: launch_scanr_mode<MODE_COUNT>(nt_bucket, hash, dim3(grid), st, a); break;
 	default: launch_scanr_mode<MODE_ALL>(nt_bucket, hash, dim3(grid), st, a); break;
 	}

@@ -16,6 +16,7 @@ k_scan(const scan_args_t A)
 	__shared__ int64_t s_pdoc[NTMAX];	/* doc of posting hi-1, or -1 */
 	__shared__ uint32_t s_truth[8];
 	__shared__ uint8_t s_prog[NXSGPU_MAX_PROG];
+	__shared__ __attribute__((aligned(16))) uint32_t s_hist[MODE == MODE_BIG ? BIGK_BUCKETS : 4];
 
 	const unsigned lane = threadIdx.x;
 	const item_t item = A.items[A.item_base + blockIdx.x];
@@ -29,6 +30,11 @@ k_scan(const scan_args_t A)
 	for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 		s_acc[i] = 0.0f;
 		s_mask[i] = 0;
+	}
+	if constexpr (MODE == MODE_BIG) {
+		for (uint32_t i = lane; i < BIGK_BUCKETS; i += WAVE) {
+			s_hist[i] = 0;
+		}
 	}
 	if (lane < 8) {
 		s_truth[lane] = Q->truth[lane];
@@ -61,10 +67,13 @@ k_scan(const scan_args_t A)
 	 * i-th largest; thr = k-th largest (or -inf).  Everything the global
 	 * heap replay could accept is > thr (see DESIGN.md "candidate filter"). */
 	float top = -INFINITY;
-	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
+	uint32_t big_since = 0;
+	const uint32_t big_upd = bigk_update_every(A.k);
 	uint32_t n_out = 0;
 	bool ovf = false;
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
@@ -158,7 +167,7 @@ k_scan(const scan_args_t A)
 						continue;
 					}
 					const uint32_t ne = __popcll(bal);
-					if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+					if (MODE_FILTERS(MODE) && n_out + ne > A.seg_cap) {
 						ovf = true;
 					} else {
 						/* slot = number of candidate lanes above me */
@@ -170,6 +179,9 @@ k_scan(const scan_args_t A)
 						}
 					}
 					n_out += ne;
+					if constexpr (MODE == MODE_BIG) {
+						bigk_account(s_hist, A.k, big_upd, cand, sc, ne, big_since, hint, thr);
+					}
 					if (track) {
 						while (bal) {
 							const int L = 63 - __clzll(bal);
@@ -209,7 +221,7 @@ k_scan(const scan_args_t A)
 					continue;
 				}
 				const uint32_t ne = __popcll(bal);
-				if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+				if (MODE_FILTERS(MODE) && n_out + ne > A.seg_cap) {
 					ovf = true;
 				} else {
 					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
@@ -220,6 +232,9 @@ k_scan(const scan_args_t A)
 					}
 				}
 				n_out += ne;
+				if constexpr (MODE == MODE_BIG) {
+					bigk_account(s_hist, A.k, big_upd, cand, sc, ne, big_since, hint, thr);
+				}
 				if (track) {
 					while (bal) {
 						const int L = 63 - __clzll(bal);
@@ -241,11 +256,16 @@ k_scan(const scan_args_t A)
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
+	if constexpr (MODE == MODE_BIG) {
+		if (!ovf) {
+			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+		}
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
-		if (MODE == MODE_TOPK && ovf) {
+		if (MODE_FILTERS(MODE) && ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -302,6 +322,7 @@ k_scan8(const scan_args_t A)
 	__shared__ uint32_t s_cd[TCAND_CAP];
 	__shared__ float s_cs[TCAND_CAP];
 	__shared__ uint32_t s_truth[8];
+	__shared__ __attribute__((aligned(16))) uint32_t s_hist[MODE == MODE_BIG ? BIGK_BUCKETS : 4];
 
 	constexpr int KSH = NT <= 1 ? 3 : NT <= 2 ? 2 : 0;
 	constexpr int K = 1 << KSH;
@@ -323,6 +344,11 @@ k_scan8(const scan_args_t A)
 		s_acc[i] = 0.0f;
 		if (HASMASK) {
 			s_mask8[i] = 0;
+		}
+	}
+	if constexpr (MODE == MODE_BIG) {
+		for (uint32_t i = lane; i < BIGK_BUCKETS; i += WAVE) {
+			s_hist[i] = 0;
 		}
 	}
 	if (lane < 8) {
@@ -461,10 +487,13 @@ k_scan8(const scan_args_t A)
 	});
 
 	float top = -INFINITY;
-	const float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) : -INFINITY;
+	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
+	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
+	uint32_t big_since = 0;
+	const uint32_t big_upd = bigk_update_every(A.k);
 	uint32_t n_out = 0;
 	bool ovf = false;
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
@@ -672,7 +701,7 @@ k_scan8(const scan_args_t A)
 		 * If none of them beats the threshold no doc of the tile can be a
 		 * candidate: just wipe the accumulators.
 		 */
-		if (MODE == MODE_TOPK && ballot64(__uint_as_float(tmax) > thr) == 0) {
+		if (MODE_FILTERS(MODE) && ballot64(__uint_as_float(tmax) > thr) == 0) {
 			if (full_scan) {
 				for (uint32_t i = lane; i < TILE_W; i += WAVE) {
 					s_acc[i] = 0.0f;
@@ -758,7 +787,7 @@ k_scan8(const scan_args_t A)
 						const uint32_t dj = __builtin_amdgcn_readlane((int)cd, j);
 						rank += dj > cd;
 					}
-					if (MODE == MODE_TOPK && n_out + ncand > A.seg_cap) {
+					if (MODE_FILTERS(MODE) && n_out + ncand > A.seg_cap) {
 						ovf = true;
 					} else if (lane < ncand) {
 						const uint64_t o = out_base + n_out + rank;
@@ -766,6 +795,9 @@ k_scan8(const scan_args_t A)
 						A.cand_sc[o] = cs;
 					}
 					n_out += ncand;
+					if constexpr (MODE == MODE_BIG) {
+						bigk_account(s_hist, A.k, big_upd, lane < ncand, cs, ncand, big_since, hint, thr);
+					}
 					if (track) {
 						for (uint32_t j = 0; j < ncand; j++) {
 							const float v = __shfl(cs, (int)j);
@@ -836,7 +868,7 @@ k_scan8(const scan_args_t A)
 					continue;
 				}
 				const uint32_t ne = __popcll(bal);
-				if (MODE == MODE_TOPK && n_out + ne > A.seg_cap) {
+				if (MODE_FILTERS(MODE) && n_out + ne > A.seg_cap) {
 					ovf = true;
 				} else {
 					const uint64_t above = (lane == 63) ? 0 : (bal >> (lane + 1));
@@ -847,6 +879,9 @@ k_scan8(const scan_args_t A)
 					}
 				}
 				n_out += ne;
+				if constexpr (MODE == MODE_BIG) {
+					bigk_account(s_hist, A.k, big_upd, cand, sc, ne, big_since, hint, thr);
+				}
 				if (track) {
 					while (bal) {
 						const int L = 63 - __clzll(bal);
@@ -867,11 +902,16 @@ k_scan8(const scan_args_t A)
 	if (MODE == MODE_TOPK && track && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
 	}
+	if constexpr (MODE == MODE_BIG) {
+		if (!ovf) {
+			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+		}
+	}
 	if (lane == 0) {
 		if (MODE != MODE_ALL) {
 			A.seg_count[seg] = ovf ? 0 : n_out;
 		}
-		if (MODE == MODE_TOPK && ovf) {
+		if (MODE_FILTERS(MODE) && ovf) {
 			A.overflow[q] = 1;
 		}
 	}
@@ -899,6 +939,7 @@ nxs_launch_scan_generic(int mode, bool wide_mask, unsigned grid, hipStream_t st,
 {
 	switch (mode) {
 	case MODE_TOPK: launch_generic_mode<MODE_TOPK>(wide_mask, dim3(grid), st, a); break;
+	case MODE_BIG: launch_generic_mode<MODE_BIG>(wide_mask, dim3(grid), st, a); break;
 	case MODE_COUNT: launch_generic_mode<MODE_COUNT>(wide_mask, dim3(grid), st, a); break;
 	default: launch_generic_mode<MODE_ALL>(wide_mask, dim3(grid), st, a); break;
 	}
@@ -942,6 +983,7 @@ nxs_launch_scan8(int mode, uint32_t nt_bucket, uint32_t mm, unsigned grid, hipSt
 {
 	switch (mode) {
 	case MODE_TOPK: launch_scan8_mode<MODE_TOPK>(nt_bucket, mm, dim3(grid), st, a); break;
+	case MODE_BIG: launch_scan8_mode<MODE_BIG>(nt_bucket, mm, dim3(grid), st, a); break;
 	case MODE_COUNT: launch_scan8_mode<MODE_COUNT>(nt_bucket, mm, dim3(grid), st, a); break;
 	default: launch_scan8_mode<MODE_ALL>(nt_bucket, mm, dim3(grid), st, a); break;
 	}

@@ -29,7 +29,8 @@ nt_bucket(uint32_t nt)
 }
 
 static void
-build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false)
+build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false,
+    uint32_t big_k = 0)
 {
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
 	const gpu_cfg_t &cf = ix->cfg;
@@ -46,7 +47,9 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 	const bool no_step = cf.no_step, mask_off = cf.mask_off;
 	const uint32_t rmin = cf.rmin;	/* 3: "a AND b" takes k_scan8's sign-bit path */
 	const bool by_level = cf.by_level;
-	const bool use_scanm = cf.use_scanm && ix->n_docs < (1ull << 31);
+	/* (limits > 64 -- big_k -- filter on a histogram threshold: the accumulator tiles,
+	 * k_scanr and k_scan1 have that mode, the mask path and the dense-term class do not) */
+	const bool use_scanm = cf.use_scanm && ix->n_docs < (1ull << 31) && big_k == 0;
 	const bool scanm_general = cf.scanm_general;
 	const uint32_t scanm_minnt = cf.scanm_minnt, scanm_maxnt = cf.scanm_maxnt;
 	/* k_scanm if the densest list holds at most this fraction of the docs */
@@ -149,7 +152,10 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 			}
 		}
 	}
-	const uint64_t per_wave = std::max<uint64_t>(min_post, total / std::max<uint64_t>(target, 1) + 1);
+	/* (limits > 64: a range's own threshold needs well over k matches to form, and
+	 * every range that starts cold emits k candidates before it has one) */
+	const uint64_t per_wave = std::max<uint64_t>(std::max<uint64_t>(min_post, (uint64_t)big_k * cf.big_minpost),
+	    total / std::max<uint64_t>(target, 1) + 1);
 	/* launch order of the classes: the mask path first -- a class's heap replay
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
@@ -282,9 +288,13 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
  */
 static void
 launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
-    const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL)
+    const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL,
+    bool replays_aside = false)
 {
 	bool forked = false, forked3 = false;
+	/* where the replay's heap lives: across the lanes (k <= 64) or in LDS (MODE_BIG) */
+	const int heap = a0.k <= WAVE ? HEAP_REG : HEAP_LDS;
+	const size_t heap_lds = heap == HEAP_LDS ? (size_t)a0.k * 8 : 0;
 	const launch_t *last_launch = NULL;
 	size_t n_launches = 0;
 
@@ -354,18 +364,18 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		if (ra && l.q_count) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
-			if (&l == last_launch) {
+			if (&l == last_launch && !replays_aside) {
 				/* nothing left to run beside it: same stream, no event
 				 * round trip (a single query has only this one) */
 				if (scans_done) {
 					(void)hipEventRecord(scans_done, ix->stream);
 					scans_done = NULL;
 				}
-				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream, r);
+				nxs_launch_replay(heap, l.q_count, heap_lds, ix->stream, r);
 			} else {
 				(void)hipEventRecord(ix->ev_cls, ix->stream);
 				(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
-				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream2, r);
+				nxs_launch_replay(heap, l.q_count, heap_lds, ix->stream2, r);
 				forked = true;
 			}
 		}
@@ -373,7 +383,13 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	if (scans_done) {
 		(void)hipEventRecord(scans_done, ix->stream);
 	}
-	if (forked) {
+	/*
+	 * replays_aside (MODE_BIG batches: a replay is thousands of heap insertions on one
+	 * lane, milliseconds): every replay runs on the second stream and the scan
+	 * stream does NOT wait for them -- the next batch's scans run beside this
+	 * batch's replays; the caller takes the batch's end from stream2.
+	 */
+	if (forked && !replays_aside) {
 		(void)hipEventRecord(ix->ev_join, ix->stream2);
 		(void)hipStreamWaitEvent(ix->stream, ix->ev_join, 0);
 	}
@@ -501,8 +517,11 @@ static int
 search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, nxsgpu_results_t *res, cand_log_t *cl = NULL)
 {
-	const bool fast = limit <= NXSGPU_FAST_K;
-	const uint32_t seg_cap = ix->cfg.seg_cap;
+	/* the candidate filter pass: limits up to NXSGPU_BIG_K (MODE_BIG beyond 64) */
+	const bool fast = limit <= NXSGPU_BIG_K;
+	const bool big = fast && limit > NXSGPU_FAST_K;
+	const uint32_t seg_cap = !big ? ix->cfg.seg_cap : ix->cfg.seg_cap_big ? ix->cfg.seg_cap_big :
+	    (uint32_t)((6 * limit + 1023) & ~1023ull);
 	std::vector<dev_query_t> hq(nq);
 	std::vector<uint32_t> h_ovf, h_cnt;
 	worklist_t wl;
@@ -562,7 +581,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	if (fill_dev_queries(ix, algo, queries, nq, hq.data(), total_post, false) != 0) {
 		return -1;
 	}
-	build_worklist(ix, hq.data(), nq, wl);
+	build_worklist(ix, hq.data(), nq, wl, false, big ? (uint32_t)limit : 0);
 	const uint64_t nseg = wl.n_segs;
 
 	/* workspace: queries | meta | items | seg_count | overflow | candidates | outputs */
@@ -664,13 +683,13 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			ra.log_cap = cl->cap;
 		}
 		if (ix->cfg.one_replay) {
-			launch_scan(MODE_TOPK, ix, sa, wl);
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(ix->ev[1], ix->stream);
-			nxs_launch_replay(HEAP_REG, nq, 0, ix->stream, ra);
+			nxs_launch_replay(big ? HEAP_LDS : HEAP_REG, nq, big ? (size_t)limit * 8 : 0, ix->stream, ra);
 		} else {
 			/* (profile: "replay" is then only what the last class's replay
 			 * adds after the last scan) */
-			launch_scan(MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? ix->ev[1] : NULL);
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? ix->ev[1] : NULL);
 		}
 		if (ix->profiling) (void)hipEventRecord(ix->ev[2], ix->stream);
 		if (hipGetLastError() != hipSuccess) {
@@ -1045,15 +1064,19 @@ static int
 batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, const batch_out_t &o)
 {
-	const uint32_t seg_cap = ix->cfg.seg_cap;
+	/* limits > 64 (the API's default is 1000, nxs_impl.h:39): the same pipeline with
+	 * the histogram threshold (MODE_BIG), the heap in LDS, larger candidate segments */
+	const bool big = limit > NXSGPU_FAST_K;
+	const uint32_t seg_cap = !big ? ix->cfg.seg_cap : ix->cfg.seg_cap_big ? ix->cfg.seg_cap_big :
+	    (uint32_t)((6 * (uint64_t)limit + 1023) & ~1023ull);
 	nxsgpu_index::dev_slot_t *sl = NULL;
 	uint64_t total_post = 0;
 	const bool gather = o.records && o.gather && ix->comm;
 	const uint32_t world = gather ? (uint32_t)nxsgpu_comm_world(ix->comm) : 1u;
 	const int my_rank = gather ? nxsgpu_comm_rank(ix->comm) : 0;
 
-	if (limit == 0 || limit > NXSGPU_FAST_K) {
-		set_error("device batches take limit 1..%d", NXSGPU_FAST_K);
+	if (limit == 0 || limit > (o.records ? NXSGPU_BIG_K : NXSGPU_FAST_K)) {
+		set_error("device batches take limit 1..%d", o.records ? NXSGPU_BIG_K : NXSGPU_FAST_K);
 		return -1;
 	}
 	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
@@ -1171,10 +1194,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	uint8_t *hp = sl->h_stage;
 	dev_query_t *h_q = carve<dev_query_t>(hp, nq);
-	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post) != 0) {
+	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post, !big) != 0) {
 		return -1;
 	}
-	build_worklist(ix, h_q, nq, wl, solo);
+	build_worklist(ix, h_q, nq, wl, solo, big ? limit : 0);
 	tb1 = now_us();
 	const uint64_t nseg = wl.n_segs;
 	if (nseg > seg_bound) {
@@ -1217,7 +1240,15 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		}
 		if (block_on_host) {
 			/* (the slot's previous batch was collected: nothing reads it any more) */
-			memset(sl->h_blocks, 0, recs_len);
+			if (sl->rec_bytes <= 1024) {
+				memset(sl->h_blocks, 0, recs_len);
+			} else {
+				/* large records (12 KB at the default limit): count and flags only --
+				 * nothing reads ids or scores beyond `count` */
+				for (uint32_t i = 0; i < o.n_slots; i++) {
+					*(uint64_t *)(sl->h_blocks + (size_t)i * sl->rec_bytes) = 0;
+				}
+			}
 			h_status = (uint32_t *)(sl->h_blocks + recs_len);
 		}
 		if (o.status) {
@@ -1325,21 +1356,29 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		return begin_fail(ix);
 	}
 	tc[2] = now_us();
+	/*
+	 * MODE_BIG, one rank: the replays (milliseconds: thousands of heap insertions
+	 * per query on one lane) all run on the second stream and the scan stream does
+	 * not wait for them, so the NEXT batch's scans run beside them; the batch ends
+	 * when stream2 has.  With a collective behind the replays the usual join stays.
+	 */
+	const bool aside = big && nq && !gather && !solo && !ix->cfg.one_replay;
+	hipStream_t s_end = aside ? ix->stream2 : ix->stream;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	if (nq) {
 		if (ix->cfg.one_replay) {
-			launch_scan(MODE_TOPK, ix, sa, wl);
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl);
 			if (ix->profiling) (void)hipEventRecord(sl->ev_t[1], ix->stream);
-			nxs_launch_replay(HEAP_REG, nq, 0, ix->stream, ra);
+			nxs_launch_replay(big ? HEAP_LDS : HEAP_REG, nq, big ? (size_t)limit * 8 : 0, ix->stream, ra);
 		} else {
 			/* (profile: "replay" is then only what the last class's replay adds
 			 * after the last scan) */
-			launch_scan(MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL);
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside);
 		}
 	} else if (ix->profiling) {
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);
 	}
-	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], ix->stream);
+	if (ix->profiling) (void)hipEventRecord(sl->ev_t[2], s_end);
 	tc[3] = now_us();
 	if (hipGetLastError() != hipSuccess) {
 		set_error("kernel launch failed");
@@ -1376,7 +1415,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			set_error("copy failed");
 			return begin_fail(ix);
 		}
-		if (hipEventRecord(sl->ev_done, s_down) != hipSuccess) {
+		if (hipEventRecord(sl->ev_done, aside ? s_end : s_down) != hipSuccess) {
 			set_error("event failed");
 			return begin_fail(ix);
 		}

@@ -731,6 +731,58 @@ def test_default_limit_batch_on_a_larger_corpus(nxs, tmp_path):
     gidx.close()
 
 
+@pytest.mark.parametrize("env", [{},
+                                 # many short ranges: cold starts, thresholds handed down between ranges
+                                 {"NXS_GPU_BIG_MINPOST": "0", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "1"},
+                                 # candidate segments too small: the overflowed queries take the exact passes
+                                 {"NXS_GPU_SEGCAP_BIG": "96", "NXS_GPU_BIG_MINPOST": "1"},
+                                 {"NXS_GPU_NOSCANR": "1", "NXS_GPU_NOSCAN1": "1"}, {"NXS_GPU_OLDSCAN": "1"},
+                                 {"NXS_GPU_ONEREPLAY": "1"}])
+def test_limits_above_64_ride_the_candidate_filter(nxs, tmp_path, monkeypatch, env):
+    """64 < limit <= 8000 (the API's default is 1000, nxs_impl.h:39): the scan
+    kernels filter on a histogram lower bound of the k-th best score (MODE_BIG) and
+    the heap is replayed in LDS -- the same ids, order and float bits as the
+    reference's heap (heap.c:58-221), on a tie-heavy corpus and a Zipf one, blocking
+    and pipelined (two batches in flight, different limits)."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    # (a) tiny vocabulary: massive score ties, thousands of matches per query
+    vocab = ["t%d" % i for i in range(14)]
+    rng = random.Random(77)
+    docs = [(d + 1, [rng.choice(vocab) for _ in range(rng.randint(1, 6))]) for d in range(9000)]
+    gidx, oidx, _ = open_pair(nxs, tmp_path, docs)
+    qs = ["t0", "t1 OR t2", "t3 AND t4", "t5 OR t6 OR t7 OR t8 OR t9", "t1 AND NOT t2", "(t1 AND t2) OR t10",
+          "t11 AND t12 AND t13", " OR ".join(vocab[:12])]
+    for limit in (65, 100, 1000, 4000, 8000):
+        for algo, name in ((1, "BM25"), (0, "TF-IDF")):
+            got = gidx.search_batch(qs, limit=limit, algo=name, fuzzymatch=False)
+            for q, g in zip(qs, got):
+                assert_same(g, oidx.search(q, algo=algo, limit=limit, fuzzymatch=False), (env, q, limit, name))
+    gidx.search_batch_begin(qs, limit=300, fuzzymatch=False)
+    gidx.search_batch_begin(qs[::-1], limit=10, fuzzymatch=False)
+    for batch, limit in ((qs, 300), (qs[::-1], 10)):
+        for q, g in zip(batch, gidx.search_batch_end()):
+            assert_same(g, oidx.search(q, limit=limit, fuzzymatch=False), (env, q, limit))
+    gidx.close()
+    # (b) Zipf corpus: five-term AND / OR shapes, single terms, sparse and dense lists
+    sub = tmp_path / "z"
+    sub.mkdir()
+    c = corpus.write_corpus(str(sub), 200_000, 8000, seed=41)
+    terms = corpus.term_strings(8000, seed=41)
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    qs = corpus.queries_bool5(terms, 40, seed=5, lo=1, hi=800)
+    qs += corpus.queries_single(terms, 8, seed=6, lo=1, hi=200)
+    qs += corpus.queries_bool5(terms, 8, seed=7, lo=1, hi=60, k=3)
+    for limit in (100, 1000):
+        got = gidx.search_batch(qs, limit=limit, fuzzymatch=False)
+        for q, g in zip(qs, got):
+            assert_same(g, oidx.search(q, limit=limit, fuzzymatch=False), (env, q, limit))
+    assert any(len(g) == 1000 for g in got)
+    for q in qs[:3] + qs[40:42]:
+        assert_same(gidx.search(q), oidx.search(q), q)             # params == NULL: limit 1000
+    gidx.close()
+
+
 def test_search_resyncs_appended_and_removed_docs(nxs, tmp_path):
     """search.c:309-312: every search first picks up what other processes
     appended.  The files are rewritten IN PLACE (same inode, MAP_SHARED), body

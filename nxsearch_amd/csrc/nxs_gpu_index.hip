@@ -97,6 +97,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
 	c.down_inline = on("NXS_GPU_DOWN_INLINE");
+	c.old_replay = on("NXS_GPU_OLDREPLAY");
 }
 
 /* ------------------------------------------------------------------ */
@@ -586,6 +587,11 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream2) {
 		(void)hipStreamDestroy(ix->stream2);
 	}
+	for (int i = 0; i < 2; i++) {
+		if (ix->stream_rp[i]) {
+			(void)hipStreamDestroy(ix->stream_rp[i]);
+		}
+	}
 	if (ix->stream3) {
 		(void)hipStreamDestroy(ix->stream3);
 	}
@@ -786,6 +792,8 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[i], hipStreamNonBlocking));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[0], hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[1], hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
@@ -1381,7 +1389,7 @@ void
 warm_streams(nxsgpu_index_t *ix)
 {
 	hipStream_t st[] = { ix->stream, ix->stream2, ix->stream3, ix->stream_up, ix->stream_down, ix->stream_fz,
-	    ix->xstream[0], ix->xstream[1], ix->xstream[2] };
+	    ix->xstream[0], ix->xstream[1], ix->xstream[2], ix->stream_rp[0], ix->stream_rp[1] };
 	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 512ull << 20) & ~(uint64_t)15;
 	const size_t cb = 4u << 20;
 	uint32_t *d_sink = NULL;

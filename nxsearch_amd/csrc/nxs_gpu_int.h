@@ -120,6 +120,7 @@ struct gpu_cfg_t {
 	uint64_t	drop_workmul;	/* NXS_GPU_DROP_WORKMUL: range count multiplier of that class */
 	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
 	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */
+	bool		old_replay;	/* NXS_GPU_OLDREPLAY: the LDS heap on one lane (k_replay<HEAP_LDS>) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
 };
 
@@ -140,6 +141,8 @@ struct nxsgpu_index {
 					 * while batches are in flight: beside them, not queued behind
 					 * their scans */
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
+	hipStream_t	stream_rp[2];	/* MODE_BIG batches (limit > 64): the replays of batch slot i -- milliseconds
+					 * of heap insertions -- run here, beside the other slot's scans AND replays */
 	hipStream_t	stream3;	/* the sparse + dense OR class (k_scanm<.., DROP>): few, latency-bound
 					 * wavefronts that run BESIDE the other classes, not in front of them */
 	hipEvent_t	ev_cls, ev_join, ev_fork3, ev_join3;
@@ -323,6 +326,7 @@ struct replay_args_t {
 	uint32_t *		log_cnt;
 	uint32_t		log_cap;
 	const uint32_t *	log_slot;	/* [Q] row of the log per query (NULL: q) */
+	uint32_t		flags;		/* bit 0: 64 < k <= REPLAY_LDS_K on the one-lane kernel (NXS_GPU_OLDREPLAY) */
 };
 
 /* where the heap lives: global memory (any k), across the lanes (k <= 64), or in

@@ -375,6 +375,7 @@ k_replay(const replay_args_t A)
 					const int L = __ffsll((long long)pend) - 1;
 					const float v = __shfl(sc, L);
 					const uint32_t dv = (uint32_t)__shfl((int)dc, L);
+					RSTAT(n_ins++;)
 					if (lane == 0) {
 						uint32_t cnt = s_n;
 						if constexpr (HEAP == HEAP_LDS) {
@@ -521,6 +522,7 @@ k_replay(const replay_args_t A)
 		}
 		return;
 	}
+	RSTAT(const unsigned long long rt_heap = __builtin_amdgcn_s_memrealtime();)
 	/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
 	const uint32_t cnt = s_n;
 	if constexpr (HEAP == HEAP_LDS) {
@@ -534,6 +536,19 @@ k_replay(const replay_args_t A)
 			}
 		}
 		__syncthreads();
+#ifdef NXS_STATS
+		if (lane == 0) {
+			const unsigned long long rt4 = __builtin_amdgcn_s_memrealtime();
+			atomicAdd(&g_rstats[0], 1ull);
+			atomicAdd(&g_rstats[1], rt1 - rt0);
+			atomicAdd(&g_rstats[2], rt_heap - rt1);
+			atomicAdd(&g_rstats[3], rt4 - rt_heap);
+			atomicMax(&g_rstats[4], rt4 - rt0);
+			atomicAdd(&g_rstats[5], n_cand);
+			atomicAdd(&g_rstats[6], n_ins);
+			atomicMax(&g_rstats[7], n_ins * 1000000ull + n_cand / 16);
+		}
+#endif
 		if (A.rec_base) {
 			uint8_t *rec = A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes;
 			uint64_t *r_ids = (uint64_t *)(rec + 8);
@@ -592,6 +607,326 @@ k_replay(const replay_args_t A)
 	}
 }
 
+/* ------------------------------------------------------------------ */
+/* k_replay_coop: the same heap for 64 < k <= REPLAY_LDS_K, all 64 lanes  */
+/* ------------------------------------------------------------------ */
+
+/*
+ * The API's default limit is 1000 (nxs_impl.h:39): a five-term OR over 10M docs
+ * puts 3 600 items through the 1000-entry heap on average, 10 000 for the
+ * heaviest query of a C3 batch -- one after the other (every heap_add sees the
+ * array the previous one left: heap.c:58-124, and the final order among equal
+ * scores is whatever those arrays make it, Q12).  On one lane an insertion is a
+ * chain of ~13 dependent LDS round trips, or -- with the top of the heap in
+ * registers -- ~25 scalar instructions per level at one instruction per four
+ * cycles (a single wavefront's issue rate): 1.3-1.5 us either way, and the
+ * heaviest query's replay (17-19 ms) set the pace of the whole batch.
+ *
+ * Same array (in LDS, (score, doc) pairs), same comparisons, same stores -- but
+ * the wavefront works on one insertion TOGETHER, six levels at a time:
+ *  - a sift-down looks at the 63-node subtree under its hole: lane b stands for
+ *    descendant b (breadth-first) and loads that node's two children; each lane
+ *    picks its smaller child (left on ties, heap.c:162-171) and says whether the
+ *    sinking element would move on from it (child < element).  Those two wave
+ *    masks fix the element's whole way through the six levels: lane b lies on it
+ *    iff every ancestor sinks and points towards b -- two 64-bit constants per
+ *    lane, a handful of vector instructions, no level-by-level walk.  The lanes on
+ *    the way store their child's pair into their own node (one LDS instruction for
+ *    all of them); the deepest one either holds the element's final place or
+ *    names the root of the next six levels.  k = 1000 is ten levels: two rounds;
+ *  - a sift-up loads all ancestors of the new leaf at once (lane t: t + 1 levels
+ *    up); the first one that is <= the item (heap.c:103) ends the rise, the ones
+ *    below it move down one level with one store;
+ *  - every branch is wave-uniform; nothing is handed through LDS flags, no barrier.
+ * About 0.4 us per insertion instead of 1.3-1.5.
+ */
+struct chp_lane_t {
+	uint32_t	lvl;	/* depth of local node `lane` in a 63-node block (lane 63: unused) */
+	uint64_t	anc;	/* its proper ancestors (local indices), as a bit mask */
+	uint64_t	dir;	/* ... and at which of them the way to it goes RIGHT */
+	bool		act;
+};
+
+__device__ __forceinline__ chp_lane_t
+chp_lane_init(void)
+{
+	const uint32_t lane = threadIdx.x;
+	chp_lane_t K;
+	uint32_t a = lane;
+
+	K.act = lane < 63;
+	K.lvl = 31u - (uint32_t)__clz((int)(lane + 1));
+	K.anc = K.dir = 0;
+	while (a) {
+		const uint32_t p = (a - 1) >> 1;
+		K.anc |= 1ull << p;
+		if (a == 2 * p + 2) {
+			K.dir |= 1ull << p;
+		}
+		a = p;
+	}
+	if (!K.act) {
+		K.anc = K.dir = 0;
+	}
+	return K;
+}
+
+/*
+ * Six levels of heap_remove_min's sinking loop (heap.c:149-187) at once: the
+ * element (score es) has its hole at node g; n = items in the heap.  The nodes it
+ * passes take their smaller child's pair.  Returns true if it leaves the block
+ * (g_out = the child it moves into: the next block's root), false if it comes to
+ * rest (g_out = its place; the caller stores it).  top_s = what node g holds now
+ * if the element moved on from it (the caller tracks the heap's minimum with it).
+ */
+__device__ __forceinline__ bool
+chp_block(uint2 *h, const chp_lane_t &K, uint32_t g, uint32_t n, float es, uint32_t &g_out, float &top_s)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t G = (g << K.lvl) + lane;		/* this lane's node */
+	const uint32_t cl = 2 * G + 1;
+	float ls = INFINITY, rs = INFINITY;		/* a missing child never is the smaller one */
+	uint32_t ld = 0, rd = 0;
+
+	if (K.act && cl < n) {
+		const uint2 a = h[cl];
+		ls = __uint_as_float(a.x);
+		ld = a.y;
+		if (cl + 1 < n) {
+			const uint2 b = h[cl + 1];
+			rs = __uint_as_float(b.x);
+			rd = b.y;
+		}
+	}
+	const bool right = rs < ls;			/* heap.c:162-171: left unless the right child is strictly smaller */
+	const float mcs = right ? rs : ls;
+	const uint32_t mcd = right ? rd : ld;
+	const uint64_t sink = ballot64(mcs < es);	/* the element would move on from these nodes */
+	const uint64_t rmask = ballot64(right);
+	/* on the element's way: every ancestor sinks and points here */
+	const uint64_t bad = (~sink | (rmask ^ K.dir)) & K.anc;
+	const uint64_t path = ballot64(K.act && bad == 0);	/* (never empty: the block's root has no ancestors) */
+	const uint32_t c = 63u - (uint32_t)__builtin_clzll(path);	/* the deepest node on it */
+
+	if (lane_of(path & sink)) {
+		h[G] = make_uint2(__float_as_uint(mcs), mcd);
+	}
+	top_s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mcs), 0));
+	if ((sink >> c) & 1) {
+		g_out = (uint32_t)__builtin_amdgcn_readlane((int)(cl + (right ? 1u : 0u)), (int)c);
+		return true;
+	}
+	g_out = (uint32_t)__builtin_amdgcn_readlane((int)G, (int)c);
+	return false;
+}
+
+/* heap_remove_min (heap.c:133-189) without the removed item (the caller has it:
+ * the root); root_s = the new root's score */
+__device__ __forceinline__ void
+chp_remove_min(uint2 *h, const chp_lane_t &K, uint32_t &n, float &root_s)
+{
+	if (--n == 0) {
+		return;
+	}
+	const uint2 e = h[n];				/* heap.c:146-147: the last item goes to the root ... */
+	const float es = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.x));
+	const uint32_t ed = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+	uint32_t g = 0, g_out;
+	float top_s, dummy;
+	bool more = chp_block(h, K, 0, n, es, g_out, top_s);	/* ... and sinks (heap.c:149-187) */
+	root_s = (more || g_out != 0) ? top_s : es;
+	while (more) {
+		g = g_out;
+		more = chp_block(h, K, g, n, es, g_out, dummy);
+	}
+	h[g_out] = make_uint2(__float_as_uint(es), ed);	/* (every lane: same address, same value) */
+	asm volatile("" ::: "memory");
+}
+
+/* the rising loop of heap_add (heap.c:96-122): item (s, d) enters at index i */
+__device__ __forceinline__ void
+chp_sift_up(uint2 *h, uint32_t i, float s, uint32_t d, float &root_s)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t ip1 = i + 1;
+	const uint32_t depth = 31u - (uint32_t)__clz((int)ip1);	/* proper ancestors of i */
+	const bool has = lane < depth;				/* lane t: the ancestor t + 1 levels up */
+	uint2 av = make_uint2(0, 0);
+
+	if (has) {
+		av = h[(ip1 >> (lane + 1)) - 1];
+	}
+	/* heap.c:103: the first ancestor that is <= the item ends the rise */
+	const uint64_t rise = ballot64(has && s < __uint_as_float(av.x));
+	const uint32_t u = (uint32_t)__builtin_ctzll(~rise);
+	if (lane < u) {
+		h[(ip1 >> lane) - 1] = av;			/* the ancestors below it move down one level */
+	}
+	const uint32_t pos = (ip1 >> u) - 1;
+	h[pos] = make_uint2(__float_as_uint(s), d);
+	if (pos == 0) {
+		root_s = s;
+	}
+	asm volatile("" ::: "memory");
+}
+
+/* heap_add (heap.c:58-124); the caller has checked acceptance (heap.c:68-74) */
+__device__ __forceinline__ void
+chp_add(uint2 *h, const chp_lane_t &K, uint32_t &n, uint32_t cap, float s, uint32_t d, float &root_s)
+{
+	if (n == cap) {
+		chp_remove_min(h, K, n, root_s);
+	}
+	chp_sift_up(h, n++, s, d, root_s);
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_replay_coop(const replay_args_t A)
+{
+	extern __shared__ uint2 coop_heap[];	/* [k] */
+	const unsigned lane = threadIdx.x;
+#ifdef NXS_STATS
+	const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+	unsigned long long rt1 = rt0, n_ins = 0, n_cand = 0;
+#endif
+	const uint32_t q = A.qlist ? A.qlist[blockIdx.x] : blockIdx.x;
+	uint2 *h = coop_heap;
+	const chp_lane_t K = chp_lane_init();
+	uint32_t n = 0;
+	float rmin = 0.0f;	/* the root's score */
+
+	if (A.skip && A.skip[q]) {
+		if (A.rec_base && lane == 0) {
+			((uint32_t *)(A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes))[1] = NXSGPU_REC_INEXACT;
+		}
+		return;
+	}
+	/* (no heap_off: the filter pass of a limit > 64, every heap has room for k) */
+	const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)(A.heap_off ?
+	    (uint32_t)min((uint64_t)A.k, A.heap_off[q + 1] - A.heap_off[q]) : A.k));
+	const qmeta_t qm = A.qmeta[q];
+	const uint32_t log_row = A.log_cnt ? (A.log_slot ? A.log_slot[q] : q) : 0;
+
+	/* candidates: ranges in descending doc order, each already descending; segment
+	 * by segment, plain coalesced loads, RU x 64 in flight */
+	for (int g0 = (int)qm.n_groups; g0 > 0 && cap; g0 -= WAVE) {
+		const int gi = g0 - 1 - (int)lane;
+		uint32_t cnt_l = 0;
+		uint64_t sb_l = 0;
+		if (gi >= 0) {
+			const uint64_t seg_l = (uint64_t)qm.seg_first + gi;
+			if (A.seg_cap) {
+				cnt_l = A.seg_count[seg_l];
+				sb_l = seg_l * A.seg_cap;
+			} else {
+				sb_l = A.seg_off[seg_l];
+				cnt_l = (uint32_t)(A.seg_off[seg_l + 1] - sb_l);
+			}
+		}
+		RSTAT(if (rt1 == rt0) rt1 = __builtin_amdgcn_s_memrealtime();)
+		constexpr int RU = 4;
+		uint64_t nonempty = ballot64(cnt_l != 0);
+		while (nonempty) {
+			const int sl = __builtin_ctzll(nonempty);
+			nonempty &= nonempty - 1;
+			const uint32_t scnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, sl);
+			const uint64_t ssb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(sb_l >> 32), sl) << 32) |
+			    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sb_l, sl);
+			RSTAT(n_cand += scnt;)
+			for (uint32_t c0 = 0; c0 < scnt; c0 += WAVE * RU) {
+				float scv[RU];
+				uint32_t dcv[RU];
+#pragma unroll
+				for (int u = 0; u < RU; u++) {
+					const uint32_t j = c0 + u * WAVE + lane;
+					scv[u] = 0.0f;
+					dcv[u] = 0;
+					if (j < scnt) {
+						const uint64_t at = ssb + j;
+						scv[u] = A.cand_sc[at];
+						dcv[u] = A.cand_doc ? A.cand_doc[at] : (uint32_t)at;
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < RU; u++) {
+					const bool valid = c0 + u * WAVE + lane < scnt;
+					const float sc = scv[u];
+					/* heap.c:68-74: when full, an item <= the root is dropped
+					 * without touching the heap */
+					uint64_t pend = ballot64(valid && (n < cap || sc > rmin));
+					while (pend) {
+						const int L = __builtin_ctzll(pend);
+						const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sc), L));
+						const uint32_t dv = (uint32_t)__builtin_amdgcn_readlane((int)dcv[u], L);
+						chp_add(h, K, n, cap, v, dv, rmin);
+						RSTAT(n_ins++;)
+						if (A.log_cnt && lane == 0) {
+							const uint32_t nl = A.log_cnt[log_row];
+							if (nl < A.log_cap) {
+								A.log_ids[(uint64_t)log_row * A.log_cap + nl] = A.doc_ids[dv];
+								A.log_sc[(uint64_t)log_row * A.log_cap + nl] = v;
+							}
+							A.log_cnt[log_row] = nl + 1;
+						}
+						pend &= pend - 1;
+						pend &= ballot64(valid && (n < cap || sc > rmin));
+					}
+				}
+			}
+		}
+	}
+	RSTAT(const unsigned long long rt_heap = __builtin_amdgcn_s_memrealtime();)
+
+	/* heap_sort (heap.c:197-221): repeated remove-min, placed from the back */
+	const uint32_t cnt = n;
+	while (n) {
+		const uint32_t last = n - 1;
+		const uint2 m = h[0];
+		const uint32_t mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);
+		const uint32_t my = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.y);
+		chp_remove_min(h, K, n, rmin);
+		h[last] = make_uint2(mx, my);
+		asm volatile("" ::: "memory");
+	}
+#ifdef NXS_STATS
+	if (lane == 0) {
+		const unsigned long long rt4 = __builtin_amdgcn_s_memrealtime();
+		atomicAdd(&g_rstats[0], 1ull);
+		atomicAdd(&g_rstats[1], rt1 - rt0);
+		atomicAdd(&g_rstats[2], rt_heap - rt1);
+		atomicAdd(&g_rstats[3], rt4 - rt_heap);
+		atomicMax(&g_rstats[4], rt4 - rt0);
+		atomicAdd(&g_rstats[5], n_cand);
+		atomicAdd(&g_rstats[6], n_ins);
+		atomicMax(&g_rstats[7], n_ins * 1000000ull + n_cand / 16);
+	}
+#endif
+	/* result i: node i of the sorted array */
+	uint64_t *o_ids;
+	float *o_sc;
+	if (A.rec_base) {
+		/* u32 count | u32 flags | u64 ids[k] | f32 scores[k]  (nxs_gpu.h) */
+		uint8_t *rec = A.rec_base + (size_t)A.rec_slot[q] * A.rec_bytes;
+		o_ids = (uint64_t *)(rec + 8);
+		o_sc = (float *)(rec + 8 + 8 * (size_t)A.k);
+		if (lane == 0) {
+			((uint32_t *)rec)[0] = cnt;
+		}
+	} else {
+		const uint64_t ob = A.out_off ? A.out_off[q] : (uint64_t)q * A.k;
+		o_ids = A.out_ids + ob;
+		o_sc = A.out_sc + ob;
+		if (lane == 0) {
+			A.out_count[q] = cnt;
+		}
+	}
+	for (uint32_t i = lane; i < cnt; i += WAVE) {
+		const uint2 e = h[i];
+		o_ids[i] = A.doc_ids[e.y];
+		o_sc[i] = __uint_as_float(e.x);
+	}
+}
+
 /* ---- launcher ------------------------------------------------------- */
 
 void
@@ -599,7 +934,13 @@ nxs_launch_replay(int heap, unsigned grid, size_t dyn_lds, hipStream_t st, const
 {
 	switch (heap) {
 	case HEAP_REG: hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(grid), dim3(WAVE), 0, st, r); break;
-	case HEAP_LDS: hipLaunchKernelGGL(k_replay<HEAP_LDS>, dim3(grid), dim3(WAVE), dyn_lds, st, r); break;
+	case HEAP_LDS:
+		if (r.flags & 1) {	/* NXS_GPU_OLDREPLAY: the one-lane form, for A/B runs */
+			hipLaunchKernelGGL(k_replay<HEAP_LDS>, dim3(grid), dim3(WAVE), dyn_lds, st, r);
+		} else {
+			hipLaunchKernelGGL(k_replay_coop, dim3(grid), dim3(WAVE), dyn_lds, st, r);
+		}
+		break;
 	default: hipLaunchKernelGGL(k_replay<HEAP_GLOBAL>, dim3(grid), dim3(WAVE), 0, st, r); break;
 	}
 }

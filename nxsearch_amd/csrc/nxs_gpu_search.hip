@@ -289,8 +289,9 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
 static void
 launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL,
-    bool replays_aside = false)
+    bool replays_aside = false, hipStream_t replay_stream = NULL)
 {
+	const hipStream_t st_rp = replay_stream ? replay_stream : ix->stream2;
 	bool forked = false, forked3 = false;
 	/* where the replay's heap lives: across the lanes (k <= 64) or in LDS (MODE_BIG) */
 	const int heap = a0.k <= WAVE ? HEAP_REG : HEAP_LDS;
@@ -374,8 +375,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				nxs_launch_replay(heap, l.q_count, heap_lds, ix->stream, r);
 			} else {
 				(void)hipEventRecord(ix->ev_cls, ix->stream);
-				(void)hipStreamWaitEvent(ix->stream2, ix->ev_cls, 0);
-				nxs_launch_replay(heap, l.q_count, heap_lds, ix->stream2, r);
+				(void)hipStreamWaitEvent(st_rp, ix->ev_cls, 0);
+				nxs_launch_replay(heap, l.q_count, heap_lds, st_rp, r);
 				forked = true;
 			}
 		}
@@ -387,10 +388,10 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	 * replays_aside (MODE_BIG batches: a replay is thousands of heap insertions on one
 	 * lane, milliseconds): every replay runs on the second stream and the scan
 	 * stream does NOT wait for them -- the next batch's scans run beside this
-	 * batch's replays; the caller takes the batch's end from stream2.
+	 * batch's replays; the caller takes the batch's end from the replay stream.
 	 */
 	if (forked && !replays_aside) {
-		(void)hipEventRecord(ix->ev_join, ix->stream2);
+		(void)hipEventRecord(ix->ev_join, st_rp);
 		(void)hipStreamWaitEvent(ix->stream, ix->ev_join, 0);
 	}
 	if (forked3) {
@@ -665,6 +666,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		if (ix->profiling) (void)hipEventRecord(ix->ev[0], ix->stream);
 		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq));
 		memset(&ra, 0, sizeof(ra));
+		ra.flags = ix->cfg.old_replay ? 1u : 0u;
 		ra.qmeta = d_qmeta;
 		ra.seg_cap = seg_cap;
 		ra.seg_count = d_seg_count;
@@ -849,6 +851,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 			sb.cand_sc = dx_csc;
 			launch_scan(MODE_ALL, ix, sb, xwl);
 			memset(&ra, 0, sizeof(ra));
+			ra.flags = ix->cfg.old_replay ? 1u : 0u;
 			ra.qmeta = dx_qmeta;
 			ra.seg_cap = 0;
 			ra.seg_off = dx_seg_off;
@@ -1054,6 +1057,8 @@ begin_fail(nxsgpu_index_t *ix)
 	(void)hipStreamSynchronize(ix->stream);
 	(void)hipStreamSynchronize(ix->stream2);
 	(void)hipStreamSynchronize(ix->stream3);
+	(void)hipStreamSynchronize(ix->stream_rp[0]);
+	(void)hipStreamSynchronize(ix->stream_rp[1]);
 	(void)hipStreamSynchronize(ix->stream_down);
 	(void)hipGetLastError();
 	return -1;
@@ -1324,6 +1329,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.cold_state = d_cold_state;
 	sa.cold_top = d_cold_top;
 	memset(&ra, 0, sizeof(ra));
+	ra.flags = ix->cfg.old_replay ? 1u : 0u;
 	ra.qmeta = d_qmeta;
 	ra.seg_cap = seg_cap;
 	ra.seg_count = d_seg_count;
@@ -1359,11 +1365,11 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	/*
 	 * MODE_BIG, one rank: the replays (milliseconds: thousands of heap insertions
 	 * per query on one lane) all run on the second stream and the scan stream does
-	 * not wait for them, so the NEXT batch's scans run beside them; the batch ends
-	 * when stream2 has.  With a collective behind the replays the usual join stays.
+	 * not wait for them, so the NEXT batch's scans AND replays run beside them (a
+	 * replay stream per batch slot); the batch ends when its replay stream has.  With a collective behind the replays the usual join stays.
 	 */
 	const bool aside = big && nq && !gather && !solo && !ix->cfg.one_replay;
-	hipStream_t s_end = aside ? ix->stream2 : ix->stream;
+	hipStream_t s_end = aside ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	if (nq) {
 		if (ix->cfg.one_replay) {
@@ -1373,7 +1379,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		} else {
 			/* (profile: "replay" is then only what the last class's replay adds
 			 * after the last scan) */
-			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside);
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL);
 		}
 	} else if (ix->profiling) {
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);

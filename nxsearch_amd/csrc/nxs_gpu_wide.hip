@@ -384,6 +384,7 @@ nxsgpu_search_wide(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_wi
 		hipLaunchKernelGGL(k_scanw<MODE_ALL>, dim3(nseg), dim3(WAVE), lds, ix->stream, wa);
 		replay_args_t ra;
 		memset(&ra, 0, sizeof(ra));
+		ra.flags = ix->cfg.old_replay ? 1u : 0u;
 		ra.qmeta = d_qmeta;
 		ra.seg_cap = 0;
 		ra.seg_off = d_seg_off;

@@ -79,7 +79,11 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--np", type=int, default=0,
-                    help="worker processes of the CPU-NP baseline (0 = host share, at most 16)")
+                    help="worker processes of the CPU-NP baseline (0 = every core of the host share)")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="seed-distinct batches rotated through the timed loop")
+    ap.add_argument("--sparse-ids", action="store_true",
+                    help="corpus with sparse random u64 doc ids (SURVEY 8d: exercises the ordinal map)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the latency / fuzzy / device-resident side measurements")
     ap.add_argument("--workdir", default=None)
@@ -100,23 +104,25 @@ def pick_workdir(args, need_bytes):
         try:
             st = os.statvfs(base)
             if st.f_bavail * st.f_frsize > need_bytes * 1.3:
-                return os.path.join(base, "nxs_bench_%d_%d_%d_%d" % (
-                    os.getuid(), args.docs, args.terms, args.seed))
+                return os.path.join(base, "nxs_bench_%d_%d_%d_%d%s" % (
+                    os.getuid(), args.docs, args.terms, args.seed, "_sp" if args.sparse_ids else ""))
         except OSError:
             pass
     return os.path.join(tempfile.gettempdir(), "nxs_bench_%d" % os.getuid())
 
 
-def make_queries(args, terms, n, corpus):
-    """The batch of workload `args.workload`, seed-stable."""
+def make_queries(args, terms, n, corpus, variant=0):
+    """The batch of workload `args.workload`, seed-stable.
+    variant 0 is THE batch (parity sample, CPU baseline); variants 1.. are the
+    same distribution from other seeds, rotated through the timed loop."""
     w = args.workload
     if w == "C2":
-        return corpus.queries_single(terms, n, seed=3)
+        return corpus.queries_single(terms, n, seed=3 + 100 * variant)
     if w == "C3":
-        return corpus.queries_bool5(terms, n, seed=3, hi=1000)
+        return corpus.queries_bool5(terms, n, seed=3 + 100 * variant, hi=1000)
     if w == "C4":
-        return corpus.queries_fuzzy(terms, n, seed=4)
-    return corpus.queries_mixed(terms, n, seed=6, hi=1000)
+        return corpus.queries_fuzzy(terms, n, seed=4 + 100 * variant)
+    return corpus.queries_mixed(terms, n, seed=6 + 100 * variant, hi=1000)
 
 
 def c_strings(qs):
@@ -159,7 +165,7 @@ def main():
     marker = os.path.join(work, "done")
     if rank == 0 and not os.path.exists(marker):
         os.makedirs(work, exist_ok=True)
-        info = corpus.write_corpus(work, args.docs, args.terms, seed=args.seed)
+        info = corpus.write_corpus(work, args.docs, args.terms, seed=args.seed, sparse_ids=args.sparse_ids)
         with open(marker, "w") as f:
             json.dump(info, f)
     barrier()
@@ -179,6 +185,9 @@ def main():
     B.nxs_bench_batches.restype = C.c_int
     B.nxs_bench_batches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
                                     C.c_uint, C.c_int, C.POINTER(BenchOut)]
+    B.nxs_bench_batches_rot.restype = C.c_int
+    B.nxs_bench_batches_rot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint,
+                                        C.c_uint, C.c_int, C.POINTER(BenchOut)]
     B.nxs_bench_singles.restype = C.c_int
     B.nxs_bench_singles.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
                                     C.POINTER(C.c_double), C.POINTER(BenchOut)]
@@ -190,6 +199,10 @@ def main():
     strong = args.workload == "C5"
     n_total = args.batch if strong else args.batch * world
     queries = make_queries(args, terms, n_total, corpus)
+    # the timed loop rotates `--rotate` seed-distinct batches (step s takes batch s mod R):
+    # no step re-reads exactly what the previous one warmed up
+    n_sets = max(1, args.rotate)
+    batches = [queries] + [make_queries(args, terms, n_total, corpus, variant=v) for v in range(1, n_sets)]
     fuzzy_on = args.workload in ("C4", "C5")
     sharded, shard_err = False, None
     if world > 1 or os.environ.get("NXS_BENCH_FORCE_SHARD"):
@@ -220,12 +233,14 @@ def main():
                 pass
             lo, hi = multi.shard_slice(n_total, rank, world)
             queries = queries[lo:hi]
+            batches = [b[lo:hi] for b in batches]
     qarr = c_strings(queries)
+    qarr_all = c_strings([q for b in batches for q in b])
     params = N._make_params(args.limit, "BM25", fuzzy_on)
 
     def run(steps):
         out = BenchOut()
-        if B.nxs_bench_batches(idx._h, params, qarr, len(queries), steps, 2, C.byref(out)) != 0:
+        if B.nxs_bench_batches_rot(idx._h, params, qarr_all, len(queries), n_sets, steps, 2, C.byref(out)) != 0:
             raise N.NxsError(*nxs.error())
         return out
 
@@ -276,7 +291,8 @@ def main():
     # one scan launch per query class and step; on C3: k_scanm<5,false,false> (pure OR of
     # sparse terms), k_cold<5> + k_scanm<5,false,true> (pure OR with a dense term, on
     # its own stream) and k_scanr<0,5> (required terms); kernel_ms spans them all
-    roofline = {"bound": "hbm", "kernel": "k_scanm+k_cold+k_scanr" if args.workload in ("C3", "C5") else "k_scan1",
+    roofline = {"bound": "hbm", "kernel": ("k_scan1" if args.workload not in ("C3", "C5") else
+                                           "k_scanm+k_cold+k_scanr" if args.limit <= 64 else "k_scan8<MODE_BIG>+k_scanr<MODE_BIG>"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "peak_measured": round(measured, 1),
@@ -301,6 +317,7 @@ def main():
                    "postings": info["postings"],
                    "boundary": "nxs_index_search_batch_begin/_end: query strings in, nxs_resp_t out, "
                                "two batches in flight",
+                   "batches_rotated": n_sets, "doc_ids": "sparse random u64" if args.sparse_ids else "1..D",
                    "parallelism": ("query-sharded x%d, index replicated, one RCCL all-gather of "
                                    "record blocks per step" % world) if (world > 1 and sharded) else
                                   ("query-sharded x%d, index replicated, NO collective (the RCCL communicator "
@@ -429,17 +446,32 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
                     "exact_requeries_per_step": idx.host_profile()["exact_requeries"] / 10.0}
     L.nxs_params_release(pt)
 
-    # (5) default limit (1000): what nxs_index_search(idx, NULL, ...) takes -- the
-    #     exact two-pass path with the heap in global memory; 64 queries, once
-    pd = N._make_params(None, "BM25", fuzzy_on) if fuzzy_on else N._make_params(None, "BM25", False)
-    sub = c_strings(queries[:64])
-    B.nxs_bench_batches(idx._h, pd, sub, 64, 1, 1, C.byref(o))
-    B.nxs_bench_batches(idx._h, pd, sub, 64, 2, 1, C.byref(o))
-    res["default_limit"] = {"queries_per_s": round(64 * 2 / o.seconds, 1), "limit": 1000,
-                            "results_per_query": round(o.results / 128.0, 1),
-                            "what": "first 64 queries of the batch, nxs_index_search_batch(), limit 1000"}
-    L.nxs_params_release(pd)
+    # (5) default limit: params == NULL, what the reference's own callers pass
+    #     (src/utils/benchmark.c:204) => limit 1000 (nxs_impl.h:39).  The WHOLE batch,
+    #     pipelined like the headline (candidate filter on a histogram threshold,
+    #     MODE_BIG; heap replayed in LDS by the whole wavefront), then the blocking call
+    idx.host_profile()
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 2, 2, C.byref(o))
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 8, 2, C.byref(o))
+    hp = idx.host_profile()
+    res["default_limit"] = {"queries_per_s": round(nq * 8 / o.seconds, 1), "limit": 1000,
+                            "ms_per_step": round(1e3 * o.seconds / 8, 3),
+                            "results_per_query": round(o.results / (8.0 * nq), 1),
+                            "exact_requeries_per_step": hp["exact_requeries"] / 10.0,
+                            "what": "the whole batch (%d queries), params == NULL, "
+                                    "nxs_index_search_batch_begin/_end, two batches in flight" % nq}
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 4, 1, C.byref(o))
+    res["default_limit"]["blocking_queries_per_s"] = round(nq * 4 / o.seconds, 1)
     L.nxs_params_release(p)
+    # ... and the latency of the reference CLI's actual call: nxs_index_search(idx, NULL, ...)
+    B.nxs_bench_singles(idx._h, None, sarr, 100, lat, C.byref(o))
+    B.nxs_bench_singles(idx._h, None, sarr, len(singles), lat, C.byref(o))
+    ls = sorted(lat[100:])
+    res["latency_default"] = {"p50_ms": round(1e-3 * ls[len(ls) // 2], 4),
+                              "p95_ms": round(1e-3 * ls[int(len(ls) * 0.95)], 4),
+                              "p99_ms": round(1e-3 * ls[int(len(ls) * 0.99)], 4),
+                              "results_per_query": round(o.results / float(len(singles)), 1),
+                              "what": "nxs_index_search(idx, NULL, ...): single-term, default limit 1000, n=%d" % len(ls)}
 
     # (6) fuzzy: C4 = 1024 tokens, Levenshtein d<=2 over the BK-tree of all terms
     toks = corpus.queries_fuzzy(terms, 1024, seed=4)
@@ -464,26 +496,40 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
     # search finds the same winners with far fewer distance evaluations (`levels`: pairs
     # screened, survivors of the screen, d = 2 matches walked to the root).
     ref_vis = float(sum(vis))
-    fz_bytes = ref_vis * (16 + mean_len)
-    res["fuzzy"] = {"candidates_per_s": round(ref_vis / (ms * 1e-3), 1) if ms > 0 else None,
-                    "tokens_per_s": round(len(toks) / best_dt, 1),
+    f_ms, d_ms, c_ms = pr["fuzzy_filter_ms"] / 3.0, pr["fuzzy_dist_ms"] / 3.0, pr["fuzzy_chain_ms"] / 3.0
+    checked = pr["fuzzy_checked"] / 3.0
+    # Bounds in WORK DONE (round 2's object divided the reference's visits by this time: frac > 1).
+    # k_fz_filter: 6 vector instructions per compared (token, term) pair, one pair per lane:
+    #   wave-instructions = pairs x 6 / 64 against the chip's VALU issue rate
+    #   (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction, MI355X_MICROARCH.md);
+    # k_fz_dist / k_fz_chain: dependent gathers out of L2 (node record + Peq words per
+    #   evaluation; parent / slot + node per ancestor): a rate, no streaming peak applies.
+    valu_peak = 256 * 4 * 2.4e9 / 2
+    filt_rate = checked * 6 / 64 / (f_ms * 1e-3) if f_ms > 0 else 0.0
+    res["fuzzy"] = {"tokens_per_s": round(len(toks) / best_dt, 1),
+                    "reference_visits_equiv_per_s": round(ref_vis / (ms * 1e-3), 1) if ms > 0 else None,
+                    "distance_evaluations_per_s": round(evals / (ms * 1e-3), 1) if ms > 0 else None,
                     "reference_visits": int(ref_vis),
                     "distance_evaluations": int(evals), "queue_items": int(pairs),
                     "device_ms": round(ms, 3), "resolved": sum(1 for i in ids if i),
                     "same_as_unpruned": ids == ids_ref,
                     "levels": [int(x / 3) for x in pr["fuzzy_level"] if x],
-                    "roofline": {"bound": "hbm", "kernel": "k_fz_filter+k_fz_dist+k_fz_chain",
-                                 "achieved": round(fz_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(fz_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
-                                 "alg_bytes": int(fz_bytes),
-                                 "cells_per_s": round(ref_vis * mean_len * tok_len / (ms * 1e-3), 1) if ms > 0 else None,
-                                 # what the three kernels really touch (mostly L2): 8 B per candidate term and token
-                                 # slice, 16 B per queue item written + read, 104 B per distance evaluation
-                                 "moved_bytes_estimate": int(len(terms) * 8 * 8 + pairs * 16 + evals * 104),
-                                 "note": "work done in the reference's unit (its visits), not bytes moved: the "
-                                         "40 MB tree and the 8 MB of signatures sit in L2 / Infinity Cache and "
-                                         "most visits are never made; HBM peak is the nominal denominator only"},
+                    "bounds": {
+                        "k_fz_filter": {"bound": "valu_issue", "ms": round(f_ms, 4), "pairs_compared": int(checked),
+                                        "valu_instr_per_pair": 6, "achieved": round(filt_rate / 1e9, 2),
+                                        "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instr/s",
+                                        "frac": round(filt_rate / valu_peak, 4)},
+                        "k_fz_dist": {"bound": "l2_gather_latency", "ms": round(d_ms, 4), "gathers": int(evals),
+                                      "bytes_per_gather": 104,
+                                      "achieved": round(evals / (d_ms * 1e-3) / 1e9, 3) if d_ms > 0 else None,
+                                      "unit": "G gathers/s",
+                                      "gb_per_s_from_l2": round(evals * 104 / (d_ms * 1e-3) / 1e9, 1) if d_ms > 0 else None},
+                        "k_fz_chain": {"bound": "l2_gather_latency (dependent)", "ms": round(c_ms, 4),
+                                       "matches_walked": int(pr["fuzzy_level"][2] / 3)}},
+                    "moved_bytes_estimate": int(len(terms) * 8 * 8 + pairs * 16 + evals * 104),
+                    "note": "tokens_per_s is the headline; reference_visits_equiv_per_s restates it in the "
+                            "reference's unit (nodes ITS bktree_search would visit for these tokens) -- work the "
+                            "match-first search does not do, so not a rate of this device",
                     "what": "C4: %d tokens, d<=2 over a %d-term BK-tree" % (len(toks), args.terms)}
     return res
 
@@ -633,7 +679,9 @@ def cpu_baseline(args, info, queries, idx, fuzzy_on, work):
             share = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             share = os.cpu_count() or 1
-        np_ = args.np or min(share, 16)
+        # one worker per core of the host share (the reference's deployment model);
+        # the workers fork after the index is loaded, so they share its pages
+        np_ = args.np or share
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-np-worker", "--workload", args.workload,
                "--docs", str(args.docs), "--terms", str(args.terms), "--batch", str(args.batch),
                "--limit", str(args.limit), "--seed", str(args.seed), "--np", str(np_),

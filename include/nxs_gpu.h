@@ -115,6 +115,11 @@ typedef struct {
 	uint64_t	fuzzy_visits;	/* Levenshtein distance evaluations    */
 	uint64_t	fuzzy_pairs;	/* (token, node) pairs dequeued        */
 	uint64_t	fuzzy_level[40];/* ... per BFS level                   */
+	/* match-first search, per kernel (HIP events on the fuzzy stream) */
+	double		fuzzy_filter_ms;/* k_bk_peq + k_bk_seed + k_fz_filter   */
+	double		fuzzy_dist_ms;	/* k_fz_dist                           */
+	double		fuzzy_chain_ms;	/* k_fz_chain + k_bk_finish            */
+	uint64_t	fuzzy_checked;	/* (token, term) pairs k_fz_filter compared */
 } nxsgpu_profile_t;
 
 int		nxsgpu_device_count(void);

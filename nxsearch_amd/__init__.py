@@ -68,7 +68,9 @@ class GpuProfile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("scan_ms", C.c_double),
                 ("replay_ms", C.c_double), ("fuzzy_ms", C.c_double),
                 ("postings", C.c_uint64), ("fuzzy_visits", C.c_uint64),
-                ("fuzzy_pairs", C.c_uint64), ("fuzzy_level", C.c_uint64 * 40)]
+                ("fuzzy_pairs", C.c_uint64), ("fuzzy_level", C.c_uint64 * 40),
+                ("fuzzy_filter_ms", C.c_double), ("fuzzy_dist_ms", C.c_double),
+                ("fuzzy_chain_ms", C.c_double), ("fuzzy_checked", C.c_uint64)]
 
 
 # every symbol include/nxs.h and include/nxs_gpu.h declare

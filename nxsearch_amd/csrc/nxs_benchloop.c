@@ -52,14 +52,16 @@ consume(nxs_resp_t **resps, size_t n, nxs_bench_out_t *o)
 }
 
 /*
- * `steps` batches of the same n query strings.  depth 1: the blocking
- * nxs_index_search_batch(); depth 2: nxs_index_search_batch_begin/_end with
- * two batches in flight (the host plans batch i+1 while the GPU runs batch i).
- * All steps have completed and all responses are consumed on return.
+ * `steps` batches of n query strings; step s takes batch s mod n_sets of the
+ * n_sets * n strings (distinct batches: nothing a step warms up -- term hash
+ * lines, cursor searches, dense columns -- is what the next one reads).  depth 1:
+ * the blocking nxs_index_search_batch(); depth 2: nxs_index_search_batch_begin /
+ * _end with two batches in flight (the host plans batch i+1 while the GPU runs
+ * batch i).  All steps have completed and all responses are consumed on return.
  */
 int
-nxs_bench_batches(nxs_index_t *idx, nxs_params_t *params, const char *const *queries,
-    size_t n, unsigned steps, int depth, nxs_bench_out_t *out)
+nxs_bench_batches_rot(nxs_index_t *idx, nxs_params_t *params, const char *const *all_queries,
+    size_t n, unsigned n_sets, unsigned steps, int depth, nxs_bench_out_t *out)
 {
 	nxs_resp_t **resps = calloc(n ? n : 1, sizeof(*resps));
 	nxs_err_t *errs = calloc(n ? n : 1, sizeof(*errs));
@@ -67,12 +69,13 @@ nxs_bench_batches(nxs_index_t *idx, nxs_params_t *params, const char *const *que
 	double t0;
 
 	memset(out, 0, sizeof(*out));
-	if (!resps || !errs) {
+	if (!resps || !errs || n_sets == 0) {
 		goto out;
 	}
 	t0 = now_s();
 	if (depth <= 1) {
 		for (unsigned s = 0; s < steps; s++) {
+			const char *const *queries = all_queries + (size_t)(s % n_sets) * n;
 			if (nxs_index_search_batch(idx, params, queries, n, resps, errs) < 0) {
 				goto out;
 			}
@@ -80,6 +83,7 @@ nxs_bench_batches(nxs_index_t *idx, nxs_params_t *params, const char *const *que
 		}
 	} else {
 		for (unsigned s = 0; s < steps; s++) {
+			const char *const *queries = all_queries + (size_t)(s % n_sets) * n;
 			if (nxs_index_search_batch_begin(idx, params, queries, n) != 0) {
 				goto out;
 			}
@@ -103,6 +107,13 @@ out:
 	free(resps);
 	free(errs);
 	return ret;
+}
+
+int
+nxs_bench_batches(nxs_index_t *idx, nxs_params_t *params, const char *const *queries,
+    size_t n, unsigned steps, int depth, nxs_bench_out_t *out)
+{
+	return nxs_bench_batches_rot(idx, params, queries, n, 1, steps, depth, out);
 }
 
 /* one nxs_index_search() per query string; per-call wall time in microseconds */

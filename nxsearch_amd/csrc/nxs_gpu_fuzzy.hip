@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256)
 k_fz_filter(const uint32_t *__restrict__ sig, const uint32_t *__restrict__ cand_node,
     const uint8_t *__restrict__ len8, uint32_t n_c, const uint2 *__restrict__ tokf,
     const uint32_t *__restrict__ tok_len_off, fz_item_t *out, uint32_t *out_count, uint32_t qcap,
-    uint32_t *overflow)
+    uint32_t *overflow, unsigned long long *checked)
 {
 	__shared__ fz_item_t s_buf[4][FZF_BUF];
 	/* this workgroup's sub-queue: [sq * qcap, (sq + 1) * qcap) */
@@ -383,6 +383,10 @@ k_fz_filter(const uint32_t *__restrict__ sig, const uint32_t *__restrict__ cand_
 	const uint32_t per = (tb - ta + gridDim.y - 1) / gridDim.y;
 	const uint32_t t0 = ta + blockIdx.y * per, t1 = min(tb, t0 + per);
 	uint32_t nb = 0;
+
+	if (checked && lane == 0 && t1 > t0) {	/* (profiling) the pairs this wavefront compares */
+		atomicAdd(checked, (unsigned long long)__popcll(vmask) * (t1 - t0));
+	}
 
 	auto flush = [&]() {
 		uint32_t base = 0;
@@ -675,7 +679,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	    ((size_t)n_tok + 1) * 4 + (NXS_MYERS_MAXPAT + 4) * 4 + 16 * 256;
 	uint32_t h_cnt[4] = { 0, 0, 0, 0 };
 	std::vector<uint32_t> h_qcnt(FZ_NQ * FZ_CSTRIDE);
-	unsigned long long h_evals = 0;
+	unsigned long long h_evals[2] = { 0, 0 };
 	/* one upload: token offsets, rank of every token in the length-sorted order,
 	 * first rank of every length */
 	std::vector<uint32_t> up((size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2);
@@ -698,7 +702,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	fz_item_t *d_match = carve<fz_item_t>(p, mcap);
 	uint32_t *d_cnt = carve<uint32_t>(p, 4);		/* -, matches, overflow, (seed's count) */
 	uint32_t *d_qcnt = carve<uint32_t>(p, FZ_NQ * FZ_CSTRIDE);	/* survivors per sub-queue */
-	unsigned long long *d_evals = carve<unsigned long long>(p, 1);
+	unsigned long long *d_evals = carve<unsigned long long>(p, 2);	/* distance evaluations, pairs compared */
 	uint64_t *d_peq = carve<uint64_t>(p, (size_t)n_tok * 256);
 	uint2 *d_tokf = carve<uint2>(p, (size_t)n_tok + 4);
 	uint32_t *d_best = carve<uint32_t>(p, n_tok);
@@ -732,7 +736,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	    hipMemcpyAsync(d_up, up.data(), up.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
 	    hipMemsetAsync(d_cnt, 0, 16, st) != hipSuccess ||
 	    hipMemsetAsync(d_qcnt, 0, FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
-	    hipMemsetAsync(d_evals, 0, 8, st) != hipSuccess ||
+	    hipMemsetAsync(d_evals, 0, 16, st) != hipSuccess ||
 	    hipMemsetAsync(d_tokf + n_tok, 0xff, 4 * sizeof(uint2), st) != hipSuccess) {
 		set_error("fuzzy upload failed");
 		return -1;
@@ -744,8 +748,9 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	if (n_c) {
 		hipLaunchKernelGGL(k_fz_filter, dim3((n_c + 255) / 256, gy), dim3(256), 0, st,
 		    ix->d_fz_sig, ix->d_fz_node, ix->d_fz_len, n_c, d_tokf, d_len_off, d_cand, d_qcnt,
-		    (uint32_t)qcap, d_cnt + 2);
+		    (uint32_t)qcap, d_cnt + 2, ix->profiling ? d_evals + 1 : (unsigned long long *)NULL);
 	}
+	if (ix->profiling) (void)hipEventRecord(ix->ev[2], st);
 	memset(&fa, 0, sizeof(fa));
 	fa.bk = ix->d_bk;
 	fa.bk_bytes = ix->d_bk_bytes;
@@ -759,6 +764,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	fa.evals = ix->profiling ? d_evals : NULL;
 	hipLaunchKernelGGL(k_fz_dist, dim3(8, FZ_NQ), dim3(1024), 0, st, fa, d_cand, d_qcnt, (uint32_t)qcap, d_match, d_cnt + 1,
 	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
+	if (ix->profiling) (void)hipEventRecord(ix->ev[3], st);
 	hipLaunchKernelGGL(k_fz_chain, dim3(1024), dim3(256), 0, st, fa, ix->d_bk_parent, ix->d_bk_slot, d_match, d_cnt + 1,
 	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
 	hipLaunchKernelGGL(k_bk_finish, dim3((n_tok + 255) / 256), dim3(256), 0, st, ix->d_bk, d_best, n_tok, d_tids);
@@ -770,7 +776,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	if (hipMemcpyAsync(term_ids, d_tids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
 	    hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
 	    (ix->profiling && hipMemcpyAsync(h_qcnt.data(), d_qcnt, h_qcnt.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-	    hipMemcpyAsync(&h_evals, d_evals, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipMemcpyAsync(h_evals, d_evals, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
 	    hipStreamSynchronize(st) != hipSuccess) {
 		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
 		return -1;
@@ -779,6 +785,12 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
 		ix->prof.fuzzy_ms += ms;
+		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[2]);
+		ix->prof.fuzzy_filter_ms += ms;
+		(void)hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]);
+		ix->prof.fuzzy_dist_ms += ms;
+		(void)hipEventElapsedTime(&ms, ix->ev[3], ix->ev[1]);
+		ix->prof.fuzzy_chain_ms += ms;
 	}
 	if (h_cnt[2]) {
 		return 1;
@@ -790,7 +802,8 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 		for (uint32_t q = 0; q < FZ_NQ; q++) {
 			surv += h_qcnt[q * FZ_CSTRIDE];
 		}
-		ix->prof.fuzzy_visits += h_evals;
+		ix->prof.fuzzy_visits += h_evals[0];
+		ix->prof.fuzzy_checked += h_evals[1];
 		ix->prof.fuzzy_pairs += surv + h_cnt[1];
 		ix->prof.fuzzy_level[0] += (uint64_t)n_tok * n_c;
 		ix->prof.fuzzy_level[1] += surv;

@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256)
 k_fz_filter(const uint32_t *__restrict__ sig, const uint32_t *__restrict__ cand_node,
     const uint8_t *__restrict__ len8, uint32_t n_c, const uint2 *__restrict__ tokf,
     const uint32_t *__restrict__ tok_len_off, fz_item_t *out, uint32_t *out_count, uint32_t qcap,
-    uint32_t *overflow, unsigned long long *checked)
+    uint32_t *overflow)
 {
 	__shared__ fz_item_t s_buf[4][FZF_BUF];
 	/* this workgroup's sub-queue: [sq * qcap, (sq + 1) * qcap) */
@@ -383,10 +383,6 @@ k_fz_filter(const uint32_t *__restrict__ sig, const uint32_t *__restrict__ cand_
 	const uint32_t per = (tb - ta + gridDim.y - 1) / gridDim.y;
 	const uint32_t t0 = ta + blockIdx.y * per, t1 = min(tb, t0 + per);
 	uint32_t nb = 0;
-
-	if (checked && lane == 0 && t1 > t0) {	/* (profiling) the pairs this wavefront compares */
-		atomicAdd(checked, (unsigned long long)__popcll(vmask) * (t1 - t0));
-	}
 
 	auto flush = [&]() {
 		uint32_t base = 0;
@@ -622,6 +618,7 @@ bk_aux_build(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n)
 	for (uint32_t l = 0; l <= FZ_MAXLEN; l++) {
 		start[l + 1] += start[l];
 	}
+	ix->fz_len_start.assign(start.begin(), start.end());	/* first candidate of every length */
 	perm.resize(std::max<uint32_t>(n_c, 1));
 	for (uint32_t i = 0; i < n; i++) {
 		if (is_cand(i)) {
@@ -748,7 +745,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	if (n_c) {
 		hipLaunchKernelGGL(k_fz_filter, dim3((n_c + 255) / 256, gy), dim3(256), 0, st,
 		    ix->d_fz_sig, ix->d_fz_node, ix->d_fz_len, n_c, d_tokf, d_len_off, d_cand, d_qcnt,
-		    (uint32_t)qcap, d_cnt + 2, ix->profiling ? d_evals + 1 : (unsigned long long *)NULL);
+		    (uint32_t)qcap, d_cnt + 2);
 	}
 	if (ix->profiling) (void)hipEventRecord(ix->ev[2], st);
 	memset(&fa, 0, sizeof(fa));
@@ -803,7 +800,22 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 			surv += h_qcnt[q * FZ_CSTRIDE];
 		}
 		ix->prof.fuzzy_visits += h_evals[0];
-		ix->prof.fuzzy_checked += h_evals[1];
+		/* the (token, term) pairs k_fz_filter compared: per workgroup of 256 candidates
+		 * (sorted by length) the tokens of compatible length -- the kernel's own bounds */
+		if (ix->fz_len_start.size() == FZ_MAXLEN + 2) {
+			uint64_t checked = 0;
+			uint32_t l_lo = 0, l_hi = 0;
+			for (uint32_t first = 0; first < n_c; first += 256) {
+				const uint32_t last = std::min(first + 255, n_c - 1);
+				while (ix->fz_len_start[l_lo + 1] <= first) l_lo++;
+				l_hi = std::max(l_hi, l_lo);
+				while (ix->fz_len_start[l_hi + 1] <= last) l_hi++;
+				const uint32_t ta = len_off[l_lo > 2 ? l_lo - 2 : 0];
+				const uint32_t tb = len_off[std::min<uint32_t>(l_hi + 2, NXS_MYERS_MAXPAT) + 1];
+				checked += (uint64_t)(last - first + 1) * (tb > ta ? tb - ta : 0);
+			}
+			ix->prof.fuzzy_checked += checked;
+		}
 		ix->prof.fuzzy_pairs += surv + h_cnt[1];
 		ix->prof.fuzzy_level[0] += (uint64_t)n_tok * n_c;
 		ix->prof.fuzzy_level[1] += surv;

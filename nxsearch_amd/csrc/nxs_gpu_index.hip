@@ -587,10 +587,8 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream2) {
 		(void)hipStreamDestroy(ix->stream2);
 	}
-	for (int i = 0; i < 2; i++) {
-		if (ix->stream_rp[i]) {
-			(void)hipStreamDestroy(ix->stream_rp[i]);
-		}
+	if (ix->stream_rp[1]) {	/* ([0] is stream3) */
+		(void)hipStreamDestroy(ix->stream_rp[1]);
 	}
 	if (ix->stream3) {
 		(void)hipStreamDestroy(ix->stream3);
@@ -787,23 +785,36 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		goto fail;
 	}
 	HIP_TRY(hipSetDevice(device));
+	/*
+	 * HIP deals its hardware queues (four by default) out round-robin in stream
+	 * creation order, and work on streams that share a queue runs one after the
+	 * other.  Which streams must NOT share one (measured: a C3 step took 2.0 ms
+	 * instead of 1.2 when the dense-term class's stream sat on the upload stream's
+	 * queue; with 8 or 16 queues -- GPU_MAX_HW_QUEUES -- every stream has its own and
+	 * the step takes 1.7: some serialisation helps) decides the order here:
+	 *   queue A: stream (scans), stream2 (replays of a class: short), stream_fz
+	 *   queue B: stream3 (dense-term class; limits > 64: replays of batch slot 0),
+	 *            xstream[0], stream_down (record blocks: sharded runs only)
+	 *   queue C: stream_up (uploads + k_cursors of the NEXT batch), xstream[1]
+	 *   queue D: stream_rp[1] (limits > 64: replays of batch slot 1), xstream[2]
+	 */
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[1], hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
 	for (int i = 0; i < 3; i++) {
 		HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[i], hipStreamNonBlocking));
 	}
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[0], hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[1], hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
-	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
-	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
 	/* (at the highest stream priority the fuzzy passes finish sooner -- the host
 	 * waits 8-10 instead of 27-32 ms per C5 step for them -- but that wait is
 	 * hidden behind the device's 38 ms anyway, and the changed timing made one
 	 * query per step overflow its candidate lists: plain priority) */
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
+	ix->stream_rp[0] = ix->stream3;		/* (the dense-term class does not exist for limits > 64) */
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
@@ -1389,7 +1400,7 @@ void
 warm_streams(nxsgpu_index_t *ix)
 {
 	hipStream_t st[] = { ix->stream, ix->stream2, ix->stream3, ix->stream_up, ix->stream_down, ix->stream_fz,
-	    ix->xstream[0], ix->xstream[1], ix->xstream[2], ix->stream_rp[0], ix->stream_rp[1] };
+	    ix->xstream[0], ix->xstream[1], ix->xstream[2], ix->stream_rp[1] };
 	const uint64_t bytes = std::min<uint64_t>(ix->n_post * sizeof(posting_t), 512ull << 20) & ~(uint64_t)15;
 	const size_t cb = 4u << 20;
 	uint32_t *d_sink = NULL;

@@ -218,6 +218,7 @@ struct nxsgpu_index {
 	uint32_t *	d_fz_sig;	/* [n_fz] byte-set signature */
 	uint8_t *	d_fz_len;	/* [n_fz] */
 	uint32_t	n_fz;
+	std::vector<uint32_t> fz_len_start;	/* [FZ_MAXLEN + 2] first candidate of every term length (profiling) */
 
 	/* reusable query workspaces */
 	void *		ws;
@@ -279,7 +280,18 @@ struct scan_args_t {
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
 	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
-	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class) */
+	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class);
+						 * bit 1 (k_scan8): the work items are the retry list's */
+	/*
+	 * Ranges whose pending list overflowed on the mask path (k_scanm: a burst of docs
+	 * above a still-weak threshold -- it depends on when higher ranges publish theirs,
+	 * i.e. on timing) are not a reason to re-run the query: the range is queued here
+	 * and scanned once more on the accumulator tiles (k_scan8), which have no such
+	 * list, right behind the class's scan and in front of its heap replay.
+	 */
+	uint32_t *		retry_count;	/* entries queued (may exceed retry_cap: those flag the query instead) */
+	item_t *		retry_items;	/* [retry_cap] */
+	uint32_t		retry_cap;
 	uint32_t *		cold_state;	/* [segments][16]: what k_cold hands to k_scanm<.., DROP> */
 	float *			cold_top;	/* [segments][64]: its running top-k scores */
 	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
@@ -363,6 +375,10 @@ carve(uint8_t *&p, size_t n)
 #ifndef SCANR_HASH
 #define	SCANR_HASH	1		/* a round = a whole driver window, its docs in an LDS hash table */
 #endif
+
+/* retry lists of the mask path (scan_args_t::retry_items): one per scan launch */
+#define	RETRY_LISTS	64
+#define	RETRY_CAP	64
 
 /* ---- nxs_gpu_index.hip ---- */
 #define	X_KEEP_MAX	(4ull << 30)

@@ -679,7 +679,14 @@ k_scanm(const scan_args_t A)
 	if (lane == 0) {
 		A.seg_count[seg] = ovf ? 0 : n_out;
 		if (ovf) {
-			A.overflow[q] = 1;
+			/* once more on the accumulator tiles (scan_args_t::retry_items); a full
+			 * retry list sends the query to the exact passes */
+			const uint32_t ri = A.retry_items ? atomicAdd(A.retry_count, 1u) : 0xffffffffu;
+			if (ri < A.retry_cap) {
+				A.retry_items[ri] = item;
+			} else {
+				A.overflow[q] = 1;
+			}
 		}
 	}
 }

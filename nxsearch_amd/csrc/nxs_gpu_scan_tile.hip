@@ -329,7 +329,16 @@ k_scan8(const scan_args_t A)
 	constexpr int SW = WAVE * K;
 
 	const unsigned lane = threadIdx.x;
-	const item_t item = A.items[A.item_base + blockIdx.x];
+	item_t item;
+	if (A.flags & 2) {
+		/* second chance of the ranges that overflowed on the mask path */
+		if (blockIdx.x >= min(*A.retry_count, A.retry_cap)) {
+			return;
+		}
+		item = A.retry_items[blockIdx.x];
+	} else {
+		item = A.items[A.item_base + blockIdx.x];
+	}
 	const uint32_t q = item.q, g = item.g;
 	const qmeta_t qm = A.qmeta[q];
 	const dev_query_t *Q = &A.queries[q];

@@ -321,6 +321,21 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			continue;
 		}
 		a.item_base = l.first;
+		/* this launch's retry list (mask path only) */
+		const size_t li = (size_t)(&l - wl.launches.data());
+		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5);
+		a.retry_count = retry ? a0.retry_count + li : NULL;
+		a.retry_items = retry ? a0.retry_items + li * RETRY_CAP : NULL;
+		a.retry_cap = retry ? RETRY_CAP : 0;
+		/* the ranges whose pending list overflowed, once more on the accumulator
+		 * tiles: a fixed, small grid whose wavefronts beyond the list's end return */
+		auto launch_retry = [&](hipStream_t st) {
+			if (retry) {
+				scan_args_t a2 = a;
+				a2.flags |= 2;
+				nxs_launch_scan8(MODE_TOPK, l.nt_bucket, (l.kind == 5 || l.nomask == 1) ? 1u : 0u, RETRY_CAP, st, a2);
+			}
+		};
 		if (side3 && l.kind == 5) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
@@ -331,6 +346,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			}
 			a.flags = ix->cfg.drop_prio ? 1u : 0u;
 			nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
+			launch_retry(ix->stream3);
 			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
 			continue;
 		}
@@ -347,6 +363,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		} else if (l.kind == 4) {
 			if (topk64) {
 				nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
+				launch_retry(ix->stream);
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, l.nomask == 1 ? 1u : 0u, grid, ix->stream, a);
 			}
@@ -354,6 +371,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			/* sparse + dense pure OR: top-k pass with the dense lists dropped */
 			if (topk64) {
 				nxs_launch_drop_class(l.nt_bucket, grid, ix->stream, a);
+				launch_retry(ix->stream);
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, 1u, grid, ix->stream, a);
 			}
@@ -591,7 +609,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
 		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256
-		    + nseg * (16 * 4 + 64 * 4) + 1024;
+		    + nseg * (16 * 4 + 64 * 4) + 1024 + RETRY_LISTS * (4 + RETRY_CAP * sizeof(item_t)) + 1024;
 		if (!ensure_ws(ix, need)) {
 			return -1;
 		}
@@ -611,6 +629,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	uint32_t *d_bnd_q = carve<uint32_t>(p, nseg + nq);
 	uint32_t *d_qorder = carve<uint32_t>(p, nq);
 	float *d_pub = carve<float>(p, nseg);
+	uint32_t *d_retry_cnt = carve<uint32_t>(p, RETRY_LISTS);
 	d_ovf = carve<uint32_t>(p, nq);
 	const size_t up_len = (size_t)(p - up0);
 	uint8_t *const down0 = (uint8_t *)d_ovf;
@@ -624,6 +643,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	d_cand_sc = carve<float>(p, nseg * seg_cap);
 	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
 	float *d_cold_top = carve<float>(p, nseg * 64);
+	item_t *d_retry_items = carve<item_t>(p, RETRY_LISTS * RETRY_CAP);
 
 	if (!ensure_pin(ix, up_len + down_len + 512)) {
 		return -1;
@@ -660,6 +680,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.pub = d_pub;
 	sa.cold_state = d_cold_state;
 	sa.cold_top = d_cold_top;
+	sa.retry_count = d_retry_cnt;
+	sa.retry_items = d_retry_items;
 
 	h_ovf.assign(nq, 0);
 	if (fast) {
@@ -1057,7 +1079,6 @@ begin_fail(nxsgpu_index_t *ix)
 	(void)hipStreamSynchronize(ix->stream);
 	(void)hipStreamSynchronize(ix->stream2);
 	(void)hipStreamSynchronize(ix->stream3);
-	(void)hipStreamSynchronize(ix->stream_rp[0]);
 	(void)hipStreamSynchronize(ix->stream_rp[1]);
 	(void)hipStreamSynchronize(ix->stream_down);
 	(void)hipGetLastError();
@@ -1192,7 +1213,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * <= target + nq ranges, see build_worklist) */
 	const uint64_t wave_target = ix->cfg.wave_target;
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
-	const size_t stage_need = 32768 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
+	const size_t stage_need = 32768 + RETRY_LISTS * 4 + 256 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
 	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + sl->block_bytes;
 	if (slot_ensure(*sl, 0, stage_need) != 0) {
 		return -1;
@@ -1220,6 +1241,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *h_recslot = carve<uint32_t>(hp, nq);
 	uint32_t *h_ovf = carve<uint32_t>(hp, nq);
 	float *h_pub = carve<float>(hp, nseg);
+	uint32_t *h_retry_cnt = carve<uint32_t>(hp, RETRY_LISTS);
 	uint8_t *h_block = carve<uint8_t>(hp, block_in_ws ? sl->block_bytes : 0);
 	const size_t up_len = (size_t)(hp - sl->h_stage);
 	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, o.n_slots);
@@ -1231,6 +1253,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		memset(h_ovf, 0, nq * 4);
 		memset(h_pub, 0, nseg * 4);
 	}
+	memset(h_retry_cnt, 0, RETRY_LISTS * 4);
 	sl->h_ovf = h_ovf;
 	if (o.records) {
 		for (uint32_t i = 0; i < nq; i++) {
@@ -1266,7 +1289,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	/* device workspace: the uploaded block first (same carve sequence => same
 	 * offsets), then what only the kernels touch */
 	const size_t ws_need = 32768 + up_len + nseg * 4
-	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8 + nseg * (16 * 4 + 64 * 4);
+	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8 + nseg * (16 * 4 + 64 * 4)
+	    + RETRY_LISTS * RETRY_CAP * sizeof(item_t) + 1024;
 	if (slot_ensure(*sl, ws_need, 0) != 0) {
 		return -1;
 	}
@@ -1279,6 +1303,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *d_recslot = carve<uint32_t>(p, nq);
 	uint32_t *d_ovf = carve<uint32_t>(p, nq);
 	float *d_pub = carve<float>(p, nseg);
+	uint32_t *d_retry_cnt = carve<uint32_t>(p, RETRY_LISTS);
 	uint8_t *d_myblock = carve<uint8_t>(p, block_in_ws ? sl->block_bytes : 0);
 	uint32_t *d_seg_count = carve<uint32_t>(p, nseg);
 	uint32_t *d_cursors = carve<uint32_t>(p, (nseg + nq) * NXSGPU_MAX_TOKENS);
@@ -1286,6 +1311,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	float *d_cand_sc = carve<float>(p, nseg * (size_t)seg_cap);
 	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
 	float *d_cold_top = carve<float>(p, nseg * 64);
+	item_t *d_retry_items = carve<item_t>(p, RETRY_LISTS * RETRY_CAP);
 	if (block_on_host) {
 		d_myblock = sl->h_blocks_dev;
 	} else if (o.records && !block_in_ws) {
@@ -1328,6 +1354,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.pub = d_pub;
 	sa.cold_state = d_cold_state;
 	sa.cold_top = d_cold_top;
+	sa.retry_count = d_retry_cnt;
+	sa.retry_items = d_retry_items;
 	memset(&ra, 0, sizeof(ra));
 	ra.flags = ix->cfg.old_replay ? 1u : 0u;
 	ra.qmeta = d_qmeta;

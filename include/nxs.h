@@ -51,6 +51,10 @@ struct nxs_params;
 typedef struct nxs_params nxs_params_t;
 
 nxs_params_t *	nxs_params_create(void);
+/* params.c:201-208: a JSON object of string / unsigned / bool members (how the
+ * Lua binding passes limit, algo, fuzzymatch: lua.c:99-110); NULL + NXS_ERR_SYSTEM
+ * "params parsing failed: ..." on a syntax error */
+nxs_params_t *	nxs_params_fromjson(nxs_t *, const char *, size_t);
 int		nxs_params_set_str(nxs_params_t *, const char *, const char *);
 int		nxs_params_set_uint(nxs_params_t *, const char *, uint64_t);
 int		nxs_params_set_bool(nxs_params_t *, const char *, bool);

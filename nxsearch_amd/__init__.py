@@ -75,7 +75,7 @@ class GpuProfile(C.Structure):
 
 # every symbol include/nxs.h and include/nxs_gpu.h declare
 NXS_H_SYMBOLS = [
-    "nxs_open", "nxs_close", "nxs_get_error", "nxs_params_create",
+    "nxs_open", "nxs_close", "nxs_get_error", "nxs_params_create", "nxs_params_fromjson",
     "nxs_params_set_str", "nxs_params_set_uint", "nxs_params_set_bool",
     "nxs_params_release", "nxs_index_open", "nxs_index_close",
     "nxs_index_search", "nxs_resp_iter_reset", "nxs_resp_iter_result",
@@ -128,6 +128,12 @@ def lib():
     L.nxs_get_error.restype = C.c_int
     L.nxs_get_error.argtypes = [vp, C.POINTER(cp)]
     L.nxs_params_create.restype = vp
+    L.nxs_params_fromjson.restype = vp
+    L.nxs_params_fromjson.argtypes = [vp, cp, C.c_size_t]
+    L.nxs_params_get_str.restype = cp
+    L.nxs_params_get_str.argtypes = [vp, cp]
+    L.nxs_params_get_uint.argtypes = [vp, cp, C.POINTER(C.c_uint64)]
+    L.nxs_params_get_bool.argtypes = [vp, cp, C.POINTER(C.c_bool)]
     L.nxs_params_set_str.argtypes = [vp, cp, cp]
     L.nxs_params_set_uint.argtypes = [vp, cp, C.c_uint64]
     L.nxs_params_set_bool.argtypes = [vp, cp, C.c_bool]
@@ -361,10 +367,17 @@ class Index:
     def device(self):
         return lib().nxs_index_device(self._h)
 
-    def search(self, query, limit=None, algo=None, fuzzymatch=None, json=False):
-        """nxs_index_search(): -> [(doc_id, score), ...] (or the JSON text)."""
+    def search(self, query, limit=None, algo=None, fuzzymatch=None, json=False, params_json=None):
+        """nxs_index_search(): -> [(doc_id, score), ...] (or the JSON text).
+        params_json: the parameters as the Lua binding passes them (nxs_params_fromjson)."""
         L = lib()
-        p = _make_params(limit, algo, fuzzymatch)
+        if params_json is not None:
+            pj = _b(params_json)
+            p = L.nxs_params_fromjson(self.nxs._h, pj, len(pj))
+            if not p:
+                self.nxs._raise()
+        else:
+            p = _make_params(limit, algo, fuzzymatch)
         q = _b(query)
         try:
             resp = L.nxs_index_search(self._h, p, q, len(q))

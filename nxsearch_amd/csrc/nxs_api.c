@@ -353,6 +353,374 @@ nxs_params_get_bool(const nxs_params_t *p, const char *key, bool *val)
 	return 0;
 }
 
+/*
+ * nxs_params_fromjson (params.c:201-208): how the reference's Lua / HTTP tier
+ * hands `limit`, `algo` and `fuzzymatch` to nxs_index_search (lua.c:99-110).  The
+ * reference parses with yyjson into a mutable document and the getters look a key
+ * up in the ROOT OBJECT by type; here: a strict JSON scanner (RFC 8259, no
+ * trailing content -- yyjson's default flags) that keeps the root object's
+ * string / unsigned-integer / bool members and validates and skips everything
+ * else (negative or fractional numbers, null, arrays, nested objects: no getter of
+ * the query path reads those).  A syntax error is NXS_ERR_SYSTEM "params parsing
+ * failed: ... at <offset>", as there.
+ */
+typedef struct {
+	const char *	p;
+	const char *	end;
+	const char *	beg;
+	const char *	err;
+} jscan_t;
+
+static void
+js_ws(jscan_t *j)
+{
+	while (j->p < j->end && (*j->p == ' ' || *j->p == '\t' || *j->p == '\n' || *j->p == '\r')) {
+		j->p++;
+	}
+}
+
+static int
+js_fail(jscan_t *j, const char *msg)
+{
+	if (!j->err) {
+		j->err = msg;
+	}
+	return -1;
+}
+
+static int
+js_hex4(jscan_t *j, unsigned *out)
+{
+	unsigned v = 0;
+
+	if (j->end - j->p < 4) {
+		return js_fail(j, "invalid escaped sequence in string");
+	}
+	for (int i = 0; i < 4; i++) {
+		const char c = *j->p++;
+		v <<= 4;
+		if (c >= '0' && c <= '9') v |= (unsigned)(c - '0');
+		else if (c >= 'a' && c <= 'f') v |= (unsigned)(c - 'a' + 10);
+		else if (c >= 'A' && c <= 'F') v |= (unsigned)(c - 'A' + 10);
+		else return js_fail(j, "invalid escaped sequence in string");
+	}
+	*out = v;
+	return 0;
+}
+
+/* a string; *out (if wanted) = malloc'ed, unescaped, NUL-terminated copy */
+static int
+js_string(jscan_t *j, char **out)
+{
+	char *buf = NULL;
+	size_t n = 0;
+
+	if (j->p >= j->end || *j->p != '"') {
+		return js_fail(j, "unexpected character");
+	}
+	j->p++;
+	if (out && (buf = malloc((size_t)(j->end - j->p) + 1)) == NULL) {
+		return js_fail(j, "out of memory");
+	}
+	while (j->p < j->end && *j->p != '"') {
+		unsigned char c = (unsigned char)*j->p++;
+
+		if (c < 0x20) {
+			free(buf);
+			return js_fail(j, "unexpected control character in string");
+		}
+		if (c == '\\') {
+			unsigned cp;
+
+			if (j->p >= j->end) {
+				break;
+			}
+			c = (unsigned char)*j->p++;
+			switch (c) {
+			case '"': case '\\': case '/': cp = c; break;
+			case 'b': cp = '\b'; break;
+			case 'f': cp = '\f'; break;
+			case 'n': cp = '\n'; break;
+			case 'r': cp = '\r'; break;
+			case 't': cp = '\t'; break;
+			case 'u':
+				if (js_hex4(j, &cp) == -1) {
+					free(buf);
+					return -1;
+				}
+				if (cp >= 0xd800 && cp <= 0xdbff) {	/* surrogate pair */
+					unsigned lo;
+					if (j->end - j->p < 6 || j->p[0] != '\\' || j->p[1] != 'u') {
+						free(buf);
+						return js_fail(j, "no low surrogate in string");
+					}
+					j->p += 2;
+					if (js_hex4(j, &lo) == -1 || lo < 0xdc00 || lo > 0xdfff) {
+						free(buf);
+						return js_fail(j, "invalid low surrogate in string");
+					}
+					cp = 0x10000 + ((cp - 0xd800) << 10) + (lo - 0xdc00);
+				} else if (cp >= 0xdc00 && cp <= 0xdfff) {
+					free(buf);
+					return js_fail(j, "invalid high surrogate in string");
+				}
+				break;
+			default:
+				free(buf);
+				return js_fail(j, "invalid escaped character in string");
+			}
+			if (buf) {
+				if (cp < 0x80) {
+					buf[n++] = (char)cp;
+				} else if (cp < 0x800) {
+					buf[n++] = (char)(0xc0 | (cp >> 6));
+					buf[n++] = (char)(0x80 | (cp & 0x3f));
+				} else if (cp < 0x10000) {
+					buf[n++] = (char)(0xe0 | (cp >> 12));
+					buf[n++] = (char)(0x80 | ((cp >> 6) & 0x3f));
+					buf[n++] = (char)(0x80 | (cp & 0x3f));
+				} else {
+					buf[n++] = (char)(0xf0 | (cp >> 18));
+					buf[n++] = (char)(0x80 | ((cp >> 12) & 0x3f));
+					buf[n++] = (char)(0x80 | ((cp >> 6) & 0x3f));
+					buf[n++] = (char)(0x80 | (cp & 0x3f));
+				}
+			}
+			continue;
+		}
+		if (buf) {
+			buf[n++] = (char)c;
+		}
+	}
+	if (j->p >= j->end) {
+		free(buf);
+		return js_fail(j, "unclosed string");
+	}
+	j->p++;		/* the closing quote */
+	if (buf) {
+		buf[n] = '\0';
+		*out = buf;
+	}
+	return 0;
+}
+
+/* a number; *is_uint: a non-negative integer without fraction / exponent that fits u64 */
+static int
+js_number(jscan_t *j, bool *is_uint, uint64_t *u)
+{
+	const char *s = j->p;
+	bool neg = false, integral = true, fits = true;
+	uint64_t v = 0;
+
+	if (j->p < j->end && *j->p == '-') {
+		neg = true;
+		j->p++;
+	}
+	if (j->p >= j->end || *j->p < '0' || *j->p > '9') {
+		j->p = s;
+		return js_fail(j, "unexpected character");
+	}
+	if (*j->p == '0') {
+		j->p++;
+		if (j->p < j->end && *j->p >= '0' && *j->p <= '9') {
+			return js_fail(j, "number with leading zero is not allowed");
+		}
+	} else {
+		while (j->p < j->end && *j->p >= '0' && *j->p <= '9') {
+			const unsigned d = (unsigned)(*j->p++ - '0');
+			if (v > (UINT64_MAX - d) / 10) {
+				fits = false;
+			} else {
+				v = v * 10 + d;
+			}
+		}
+	}
+	if (j->p < j->end && *j->p == '.') {
+		integral = false;
+		j->p++;
+		if (j->p >= j->end || *j->p < '0' || *j->p > '9') {
+			return js_fail(j, "no digit after decimal point");
+		}
+		while (j->p < j->end && *j->p >= '0' && *j->p <= '9') {
+			j->p++;
+		}
+	}
+	if (j->p < j->end && (*j->p == 'e' || *j->p == 'E')) {
+		integral = false;
+		j->p++;
+		if (j->p < j->end && (*j->p == '+' || *j->p == '-')) {
+			j->p++;
+		}
+		if (j->p >= j->end || *j->p < '0' || *j->p > '9') {
+			return js_fail(j, "no digit after exponent sign");
+		}
+		while (j->p < j->end && *j->p >= '0' && *j->p <= '9') {
+			j->p++;
+		}
+	}
+	*is_uint = !neg && integral && fits;
+	*u = v;
+	return 0;
+}
+
+static int js_value(jscan_t *j, nxs_params_t *into, const char *key, unsigned depth);
+
+static int
+js_literal(jscan_t *j, const char *word)
+{
+	const size_t n = strlen(word);
+
+	if ((size_t)(j->end - j->p) < n || memcmp(j->p, word, n) != 0) {
+		return js_fail(j, "invalid literal");
+	}
+	j->p += n;
+	return 0;
+}
+
+/* one value; if `into` (the root object's member `key`), keep what the getters read */
+static int
+js_value(jscan_t *j, nxs_params_t *into, const char *key, unsigned depth)
+{
+	js_ws(j);
+	if (j->p >= j->end) {
+		return js_fail(j, "unexpected end of data");
+	}
+	if (depth > 512) {
+		return js_fail(j, "nesting too deep");
+	}
+	switch (*j->p) {
+	case '"': {
+		char *str = NULL;
+
+		if (js_string(j, into ? &str : NULL) == -1) {
+			return -1;
+		}
+		if (into) {
+			const int r = nxs_params_set_str(into, key, str);
+			free(str);
+			return r == 0 ? 0 : js_fail(j, "out of memory");
+		}
+		return 0;
+	}
+	case 't':
+		if (js_literal(j, "true") == -1) return -1;
+		return into && nxs_params_set_bool(into, key, true) != 0 ? js_fail(j, "out of memory") : 0;
+	case 'f':
+		if (js_literal(j, "false") == -1) return -1;
+		return into && nxs_params_set_bool(into, key, false) != 0 ? js_fail(j, "out of memory") : 0;
+	case 'n':
+		return js_literal(j, "null");
+	case '[':
+		j->p++;
+		js_ws(j);
+		if (j->p < j->end && *j->p == ']') {
+			j->p++;
+			return 0;
+		}
+		for (;;) {
+			if (js_value(j, NULL, NULL, depth + 1) == -1) {
+				return -1;
+			}
+			js_ws(j);
+			if (j->p < j->end && *j->p == ',') {
+				j->p++;
+				continue;
+			}
+			if (j->p < j->end && *j->p == ']') {
+				j->p++;
+				return 0;
+			}
+			return js_fail(j, j->p < j->end ? "unexpected character" : "unclosed array");
+		}
+	case '{': {
+		/* only the ROOT object's members are parameters */
+		nxs_params_t *const members = (depth == 0) ? into : NULL;
+
+		j->p++;
+		js_ws(j);
+		if (j->p < j->end && *j->p == '}') {
+			j->p++;
+			return 0;
+		}
+		for (;;) {
+			char *k = NULL;
+			int r;
+
+			js_ws(j);
+			if (js_string(j, &k) == -1) {
+				return -1;
+			}
+			js_ws(j);
+			if (j->p >= j->end || *j->p != ':') {
+				free(k);
+				return js_fail(j, "unexpected character");
+			}
+			j->p++;
+			/* (an embedded NUL would truncate the key: such a key is no parameter) */
+			r = js_value(j, members, k, depth + 1);
+			free(k);
+			if (r == -1) {
+				return -1;
+			}
+			js_ws(j);
+			if (j->p < j->end && *j->p == ',') {
+				j->p++;
+				continue;
+			}
+			if (j->p < j->end && *j->p == '}') {
+				j->p++;
+				return 0;
+			}
+			return js_fail(j, j->p < j->end ? "unexpected character" : "unclosed object");
+		}
+	}
+	default: {
+		bool is_uint = false;
+		uint64_t u = 0;
+
+		if (js_number(j, &is_uint, &u) == -1) {
+			return -1;
+		}
+		if (into && is_uint && nxs_params_set_uint(into, key, u) != 0) {
+			return js_fail(j, "out of memory");
+		}
+		return 0;
+	}
+	}
+}
+
+nxs_params_t *
+nxs_params_fromjson(nxs_t *nxs, const char *json, size_t len)
+{
+	nxs_params_t *params;
+	jscan_t j = { json, json + len, json, NULL };
+
+	if ((params = nxs_params_create()) == NULL) {
+		return NULL;
+	}
+	/* the root: its members if it is an object, nothing otherwise (the getters
+	 * look keys up in the root object) */
+	js_ws(&j);
+	if (j.p < j.end && *j.p == '{') {
+		if (js_value(&j, params, NULL, 0) == -1) {
+			goto fail;
+		}
+	} else if (js_value(&j, NULL, NULL, 1) == -1) {
+		goto fail;
+	}
+	js_ws(&j);
+	if (j.p < j.end) {
+		js_fail(&j, "unexpected content after document");
+		goto fail;
+	}
+	return params;
+fail:
+	nxs_params_release(params);
+	nxs_decl_err(nxs, NXS_ERR_SYSTEM, "params parsing failed: %s at %u",
+	    j.err ? j.err : "invalid JSON", (unsigned)(j.p - j.beg));
+	return NULL;
+}
+
 /* ranking.c:182-192 */
 static int
 get_ranking_func_id(const char *name)
@@ -1101,7 +1469,60 @@ pend_release(nxs_pend_t *p)
 		nxs_query_release(&p->prep[i]);
 	}
 	free(p->prep);
+	for (size_t i = 0; p->st_resps && i < p->n; i++) {
+		if (p->st_resps[i]) {		/* stashed and never collected */
+			nxs_resp_release(p->st_resps[i]);
+		}
+	}
+	free(p->st_resps);
+	free(p->st_errs);
+	free(p->st_errmsg);
 	memset(p, 0, sizeof(*p));
+}
+
+static int batch_end_core(nxs_index_t *, nxs_pend_t *, nxs_resp_t **, nxs_err_t *);
+
+/*
+ * search.c:309-312: the reference syncs with the index files before EVERY search.
+ * A refresh swaps device arrays the batches in flight read, so when the files
+ * have moved (nxs_index_changed: four loads) the batches in flight are finished
+ * here, oldest first, their responses kept for the caller's _end -- then the
+ * index is refreshed and the new batch sees the change.  In the steady state of
+ * a pipelined server (one batch always in flight) nothing else ever would.
+ */
+static int
+resync_before_batch(nxs_index_t *idx)
+{
+	/* (sharded: the ranks would have to agree on WHICH _begin finishes the batches in
+	 * flight -- their fix-up round is a collective --, so with a communicator attached
+	 * the files are re-read between batches only, as before) */
+	if (pend_oldest(idx) && !idx->comm && nxs_index_changed(idx)) {
+		for (;;) {
+			nxs_pend_t *pd = NULL;
+
+			for (int i = 0; i < 2; i++) {
+				nxs_pend_t *c = &idx->pend[i];
+				if (c->active && !c->stashed && (!pd || c->seq < pd->seq)) {
+					pd = c;
+				}
+			}
+			if (!pd) {
+				break;
+			}
+			pd->st_resps = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_resps));
+			pd->st_errs = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_errs));
+			if (!pd->st_resps || !pd->st_errs) {
+				nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
+				return -1;
+			}
+			pd->st_ret = batch_end_core(idx, pd, pd->st_resps, pd->st_errs);
+			pd->st_errcode = idx->nxs->errcode;
+			pd->st_errmsg = idx->nxs->errmsg ? strdup(idx->nxs->errmsg) : NULL;
+			pd->stashed = true;
+			nxs_clear_error(idx->nxs);
+		}
+	}
+	return nxs_index_refresh(idx);
 }
 
 /* batches never collected (the caller closes the index instead): wait, drop */
@@ -1113,7 +1534,7 @@ index_drain(nxs_index_t *idx)
 	while ((pd = pend_oldest(idx)) != NULL) {
 		nxsgpu_batch_view_t v;
 
-		if (pd->on_device && idx->dev) {
+		if (pd->on_device && !pd->stashed && idx->dev) {
 			(void)nxsgpu_batch_end(idx->dev, &v);
 		}
 		pend_release(pd);
@@ -1149,11 +1570,8 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		nxs_decl_err(nxs, NXS_ERR_INVALID, "two batches are already in flight");
 		return -1;
 	}
-	/*
-	 * search.c:309-312: pick up what other processes appended -- between
-	 * batches only: a refresh swaps device arrays the batch in flight reads.
-	 */
-	if (!pend_oldest(idx) && nxs_index_refresh(idx) == -1) {
+	/* search.c:309-312: pick up what other processes appended or removed */
+	if (resync_before_batch(idx) == -1) {
 		return -1;
 	}
 	if (n > UINT32_MAX / 2) {
@@ -1356,8 +1774,39 @@ resps_from_blocks(nxs_t *nxs, const nxs_pend_t *pd, size_t n, uint32_t world, ui
 int
 nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs)
 {
-	nxs_t *nxs = idx->nxs;
 	nxs_pend_t *pd = pend_oldest(idx);
+	int ret;
+
+	if (!pd) {
+		nxs_clear_error(idx->nxs);
+		nxs_decl_err(idx->nxs, NXS_ERR_INVALID, "no batch in flight");
+		return -1;
+	}
+	if (pd->stashed) {
+		/* finished early by a later _begin (resync_before_batch): hand over */
+		nxs_clear_error(idx->nxs);
+		for (size_t i = 0; i < pd->n; i++) {
+			resps[i] = pd->st_resps[i];
+			pd->st_resps[i] = NULL;
+			if (errs) {
+				errs[i] = pd->st_errs[i];
+			}
+		}
+		if (pd->st_errcode) {
+			nxs_decl_err(idx->nxs, pd->st_errcode, "%s", pd->st_errmsg ? pd->st_errmsg : "");
+		}
+		ret = pd->st_ret;
+	} else {
+		ret = batch_end_core(idx, pd, resps, errs);
+	}
+	pend_release(pd);
+	return ret;
+}
+
+static int
+batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_t *nxs = idx->nxs;
 	nxsgpu_results_t res, wres;
 	slab_builder_t sb = { 0 };
 	uint8_t *patched = NULL;
@@ -1370,10 +1819,6 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 	memset(&res, 0, sizeof(res));
 	memset(&wres, 0, sizeof(wres));
 	nxs_clear_error(nxs);
-	if (!pd) {
-		nxs_decl_err(nxs, NXS_ERR_INVALID, "no batch in flight");
-		return -1;
-	}
 	n = pd->n;
 	nl = pd->hi - pd->lo;
 	for (size_t i = 0; i < n; i++) {
@@ -1559,7 +2004,6 @@ out:
 	free(patched);
 	free(which);
 	free(pos);
-	pend_release(pd);
 	idx->hp_end += now_s() - t_in;
 	return ret;
 }

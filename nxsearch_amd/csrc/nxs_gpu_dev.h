@@ -360,9 +360,17 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
  * A workgroup here is ONE wavefront: its DS operations execute in issue order,
  * so cross-lane LDS hand-offs need no s_barrier -- and must not get one:
  * __syncthreads() also drains vmcnt(0), i.e. every posting prefetch in flight.
- * This only stops the compiler from moving memory operations across the point.
+ * This only stops the compiler from moving memory operations across the point:
+ * the wavefront-scope fence is what does that (it generates no instruction on
+ * gfx9 -- one wavefront's LDS operations are ordered anyway -- but the optimiser
+ * must treat it as a clobber of all memory: no store-to-load forwarding of a
+ * lane's own LDS store across it, no load hoisted above another lane's store);
+ * the wave barrier alone is declared IntrNoMem and promises nothing of the kind.
  */
-#define	WAVE_SYNC()	__builtin_amdgcn_wave_barrier()
+#define	WAVE_SYNC()	do {							\
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");			\
+	__builtin_amdgcn_wave_barrier();					\
+} while (0)
 
 #define	LIST_CAP	512
 #ifndef SCAN8_RING_MAX

@@ -80,6 +80,17 @@ typedef struct nxs_pend {
 	int		algo;
 	struct qprep *	prep;		/* [hi - lo] */
 	uint64_t	seq;
+	/*
+	 * Collected early: the index files changed while this batch was in flight and
+	 * a later _begin had to finish it to re-sync (search.c:309-312).  Its
+	 * responses wait here for the caller's _end.
+	 */
+	bool		stashed;
+	nxs_resp_t **	st_resps;	/* [n] */
+	nxs_err_t *	st_errs;	/* [n] */
+	int		st_ret;
+	nxs_err_t	st_errcode;
+	char *		st_errmsg;
 } nxs_pend_t;
 
 struct nxs_index {
@@ -143,6 +154,7 @@ struct nxs_index {
 int	nxs_index_load(nxs_index_t *, const char *terms_path, const char *dtmap_path);
 void	nxs_index_unload(nxs_index_t *);
 int	nxs_index_refresh(nxs_index_t *);
+bool	nxs_index_changed(const nxs_index_t *);
 int	nxs_index_bk_sync(nxs_index_t *);
 void	nxs_index_refresh_stats(const nxs_index_t *, uint64_t out[2]);
 uint32_t nxs_term_lookup(const nxs_index_t *, const uint8_t *val, size_t len);

@@ -959,6 +959,25 @@ ord_of(const nxs_index_t *idx, uint64_t doc_id)
  * every loaded one (what an indexer with growing ids produces); anything else --
  * a re-used or out-of-order id -- takes the full rebuild.  Returns 0 or -1.
  */
+/*
+ * Did another process publish anything since the last sync?  The four words
+ * idx_terms_sync / idx_dtmap_sync look at (terms.c:320-330, dtmap.c:440-470):
+ * both data_len fields (published last, with release semantics) and the header
+ * counters.  Cheap enough for every search.
+ */
+bool
+nxs_index_changed(const nxs_index_t *idx)
+{
+	if (!idx->tmap || !idx->dmap || idx->n_shards > 1) {
+		return false;
+	}
+	const uint64_t t_now = be32toh(__atomic_load_n((const uint32_t *)(idx->tmap + 8), __ATOMIC_ACQUIRE));
+	const uint64_t d_now = be64toh(__atomic_load_n((const uint64_t *)(idx->dmap + 8), __ATOMIC_ACQUIRE));
+
+	return t_now != idx->terms_consumed || d_now != idx->dt_consumed ||
+	    rd32(idx->dmap + 24) != idx->hdr_docs_seen || rd64(idx->dmap + 16) != idx->hdr_tokens_seen;
+}
+
 int
 nxs_index_refresh(nxs_index_t *idx)
 {

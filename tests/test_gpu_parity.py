@@ -112,6 +112,15 @@ def test_errors_match_reference_conventions(golden, nxs, tmp_path):
     assert [d for d, _ in gidx.search("cat")] == [3, 1]
     assert gidx.nxs.error()[0] == 0
     assert len(gidx.search("cat OR dog OR cow", limit=2)) == 2       # Q13
+    # the Lua binding's way in: nxs_params_fromjson (params.c:201-208, lua.c:99-110)
+    assert gidx.search("cat OR dog OR cow", params_json='{"limit": 2, "algo": "TF-IDF", "fuzzymatch": false}') == \
+        gidx.search("cat OR dog OR cow", limit=2, algo="TF-IDF", fuzzymatch=False)
+    with pytest.raises(N.NxsError) as e:
+        gidx.search("cat", params_json='{"limit": 0}')
+    assert e.value.code == 3 and "invalid limit" in e.value.msg
+    with pytest.raises(N.NxsError) as e:
+        gidx.search("cat", params_json='{"limit": 2')
+    assert e.value.code == 2 and e.value.msg.startswith("params parsing failed")
     gidx.close()
 
 
@@ -811,6 +820,52 @@ def test_search_resyncs_appended_and_removed_docs(nxs, tmp_path):
     oidx = O.Index(t, d)
     for q in ("cat", "emu", "cow"):
         assert_same(gidx.search(q), oidx.search(q), q)
+    gidx.close()
+
+
+def test_resync_in_a_pipelined_loop_that_never_drains(nxs, tmp_path):
+    """search.c:309-312 under pipelining: a server that keeps one batch in flight
+    at all times (_begin(i+1) before _end(i), forever) still sees what an indexer
+    appends and removes.  _begin notices the moved data_len words, finishes the
+    batch in flight internally (its responses wait for the caller's _end),
+    refreshes, and plans the new batch against the new snapshot."""
+    ev = [("add", i + 1, ["cat", "dog", "w%d" % (i % 7)]) for i in range(300)]
+    timg, dimg, _ = nxsfmt.build_images_log(ev)
+    t, d = str(tmp_path / "nxsterms"), str(tmp_path / "nxsdtmap")
+    open(t, "wb").write(timg + b"\0" * 262144)
+    open(d, "wb").write(dimg + b"\0" * 262144)
+    gidx = nxs.open_files(t, d)
+    qs = ["cat", "emu", "dog OR emu", "w3 AND cat", "emu AND cat", "gnu"]
+    oracles = [O.Index(t, d)]                 # snapshot 0
+    seen_by = []                              # snapshot each batch was planned against
+
+    def publish(events):
+        timg, dimg, _ = nxsfmt.build_images_log(events)
+        nxsfmt.publish_in_place(t, d, timg, dimg)
+        oracles.append(O.Index(t, d))
+
+    gidx.search_batch_begin(qs, limit=10)     # batch 0: snapshot 0
+    seen_by.append(0)
+    for step in range(1, 9):
+        if step == 2:
+            ev.append(("add", 1000, ["cat", "emu"]))
+            publish(ev)                       # between _begin(1) and _begin(2), batch 1 in flight
+        if step == 5:
+            ev.append(("rm", 1000))
+            ev.append(("add", 1001, ["gnu", "cat", "cat"]))
+            publish(ev)
+        gidx.search_batch_begin(qs, limit=10)             # never drains: batch step-1 is in flight
+        seen_by.append(len(oracles) - 1)
+        got = gidx.search_batch_end()                     # collects batch step-1
+        want = oracles[seen_by[step - 1]]
+        for q, g in zip(qs, got):
+            assert_same(g, want.search(q, limit=10), (step, q))
+    got = gidx.search_batch_end()
+    for q, g in zip(qs, got):
+        assert_same(g, oracles[seen_by[-1]].search(q, limit=10), ("last", q))
+    # the change published at step 2 was seen by batch 2 (not later), the one at step 5 by batch 5
+    assert seen_by[2] == 1 and seen_by[5] == 2
+    assert [x for x, _ in gidx.search("emu")] == [] and [x for x, _ in gidx.search("gnu")] == [1001]
     gidx.close()
 
 

@@ -29,6 +29,49 @@ def test_cabi_exports_every_declared_symbol():
         assert declared == set(names), (hdr, declared ^ set(names))
 
 
+def test_params_fromjson_is_what_the_lua_binding_needs(tmp_path):
+    """nxs_params_fromjson (reference params.c:201-208; caller lua.c:99-110): the
+    root object's string / unsigned / bool members, by type like the reference's
+    getters (params.c:125-155); a syntax error is NXS_ERR_SYSTEM "params parsing
+    failed: ..."."""
+    L = N.lib()
+    with N.Nxs(str(tmp_path)) as nxs:
+        def parse(js):
+            b = js.encode() if isinstance(js, str) else js
+            return L.nxs_params_fromjson(nxs._h, b, len(b))
+
+        def get(p, key):
+            u, b = C.c_uint64(), C.c_bool()
+            if L.nxs_params_get_uint(p, key, C.byref(u)) == 0:
+                return int(u.value)
+            if L.nxs_params_get_bool(p, key, C.byref(b)) == 0:
+                return bool(b.value)
+            v = L.nxs_params_get_str(p, key)
+            return v.decode() if v is not None else None
+
+        p = parse(' {"limit": 25, "algo" : "TF-IDF", "fuzzymatch": false, "lang":"en",\n'
+                  '  "filters": ["normalizer", "stemmer"], "neg": -3, "real": 1.5, "nil": null,\n'
+                  '  "nested": {"limit": 7}, "esc": "a\\"b\\u00e9\\ud83d\\ude00\\n", "big": 18446744073709551615,\n'
+                  '  "huge": 18446744073709551616, "t": true} ')
+        assert p
+        assert get(p, b"limit") == 25 and get(p, b"algo") == "TF-IDF" and get(p, b"fuzzymatch") is False
+        assert get(p, b"t") is True and get(p, b"lang") == "en"
+        assert get(p, b"esc") == 'a"b\u00e9\U0001f600\n'
+        assert get(p, b"big") == 2 ** 64 - 1
+        for k in (b"neg", b"real", b"nil", b"nested", b"filters", b"huge", b"missing"):
+            assert get(p, k) is None, k           # not a string / unsigned / bool member of the root
+        L.nxs_params_release(p)
+        for ok in ("{}", "[1, 2]", "3", '"x"', "  null  "):    # valid JSON, no parameters
+            p = parse(ok)
+            assert p and get(p, b"limit") is None
+            L.nxs_params_release(p)
+        for bad in ("", "{", '{"limit": 10,}', '{"limit" 10}', "{'limit': 10}", '{"a": 01}', '{"a": 1} x',
+                    '{"a": "unclosed}', '{"a": tru}', '{"a": "\\x"}', '{"a": 1.}', '[1, 2', '{"a": "\\ud800"}'):
+            assert not parse(bad), bad
+            code, msg = nxs.error()
+            assert code == 2 and msg.startswith("params parsing failed: "), (bad, code, msg)
+
+
 def test_no_gpu_means_loud_failure(tmp_path):
     if N.lib().nxsgpu_device_count() > 0:
         pytest.skip("a GPU is present")

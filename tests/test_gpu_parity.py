@@ -836,13 +836,22 @@ def test_resync_in_a_pipelined_loop_that_never_drains(nxs, tmp_path):
     open(d, "wb").write(dimg + b"\0" * 262144)
     gidx = nxs.open_files(t, d)
     qs = ["cat", "emu", "dog OR emu", "w3 AND cat", "emu AND cat", "gnu"]
-    oracles = [O.Index(t, d)]                 # snapshot 0
+    import shutil
+
+    def snapshot():                           # (a private copy: the oracle reads the header counters live)
+        k = len(oracles)
+        tt, dd = str(tmp_path / ("t%d" % k)), str(tmp_path / ("d%d" % k))
+        shutil.copy(t, tt)
+        shutil.copy(d, dd)
+        return O.Index(tt, dd)
+    oracles = []
+    oracles.append(snapshot())                # snapshot 0
     seen_by = []                              # snapshot each batch was planned against
 
     def publish(events):
         timg, dimg, _ = nxsfmt.build_images_log(events)
         nxsfmt.publish_in_place(t, d, timg, dimg)
-        oracles.append(O.Index(t, d))
+        oracles.append(snapshot())
 
     gidx.search_batch_begin(qs, limit=10)     # batch 0: snapshot 0
     seen_by.append(0)

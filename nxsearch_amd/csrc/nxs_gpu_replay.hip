@@ -184,6 +184,123 @@ rheap_add(float &hs, uint32_t &hd, uint32_t &nitems, uint32_t cap, float s, uint
 }
 
 /*
+ * The lane-resident heap, worked on by ALL lanes at once (the form k_replay_coop
+ * uses for the large heaps, below; there is a single 64-node block here and no
+ * LDS).  Walking the levels on the scalar unit costs ~30 instructions per level
+ * at one instruction per four cycles -- 0.5 us per heap_add measured, 30-50 us
+ * of a single-term query's ~90 us.  Here every lane fetches its two children
+ * with ds_bpermute, picks the smaller one (left on ties, heap.c:162-171) and says
+ * whether the sinking element would move on from it; the two wave masks fix the
+ * element's whole way down (lane b lies on it iff every ancestor sinks and points
+ * towards b).  A rise fetches every node's parent the same way: the nodes
+ * between the new leaf and the first ancestor that is <= the item (heap.c:103)
+ * take their parent's pair.  Same comparisons, same final array.
+ */
+struct lph_lane_t {
+	uint32_t	lvl;	/* depth of node `lane` */
+	uint64_t	anc;	/* its proper ancestors, as a bit mask */
+	uint64_t	dir;	/* ... and at which of them the way to it goes RIGHT */
+};
+
+__device__ __forceinline__ lph_lane_t
+lph_lane_init(void)
+{
+	const uint32_t lane = threadIdx.x;
+	lph_lane_t K;
+	uint32_t a = lane;
+
+	K.lvl = 31u - (uint32_t)__clz((int)(lane + 1));
+	K.anc = K.dir = 0;
+	while (a) {
+		const uint32_t p = (a - 1) >> 1;
+		K.anc |= 1ull << p;
+		if (a == 2 * p + 2) {
+			K.dir |= 1ull << p;
+		}
+		a = p;
+	}
+	return K;
+}
+
+/* the sinking loop of heap_remove_min (heap.c:149-187): element (es, ed) enters at
+ * the root of a heap of n items; root_s = the new root's score */
+__device__ __forceinline__ void
+lph_sift_down(const lph_lane_t &K, float &hs, uint32_t &hd, uint32_t n, float es, uint32_t ed, float &root_s)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t cl = 2 * lane + 1, cr = cl + 1;
+	/* (bpermute wraps the lane index: the loads of missing children are harmless) */
+	const float ls_ = __shfl(hs, (int)(cl & 63)), rs_ = __shfl(hs, (int)(cr & 63));
+	const uint32_t ld = (uint32_t)__shfl((int)hd, (int)(cl & 63)), rd = (uint32_t)__shfl((int)hd, (int)(cr & 63));
+	const float ls = cl < n ? ls_ : INFINITY, rs = cr < n ? rs_ : INFINITY;
+	const bool right = rs < ls;		/* heap.c:162-171: left unless the right child is strictly smaller */
+	const float mcs = right ? rs : ls;
+	const uint32_t mcd = right ? rd : ld;
+	const uint64_t sink = ballot64(mcs < es);
+	const uint64_t rmask = ballot64(right);
+	const uint64_t bad = (~sink | (rmask ^ K.dir)) & K.anc;
+	const uint64_t path = ballot64(bad == 0);
+	const uint32_t c = 63u - (uint32_t)__builtin_clzll(path);	/* where the element comes to rest */
+
+	if (lane_of(path & sink)) {
+		hs = mcs;
+		hd = mcd;
+	}
+	if (lane == c) {
+		hs = es;
+		hd = ed;
+	}
+	root_s = (sink & 1) ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mcs), 0)) : es;
+}
+
+/* heap_remove_min (heap.c:133-189); the caller has read the root */
+__device__ __forceinline__ void
+lph_remove_min(const lph_lane_t &K, float &hs, uint32_t &hd, uint32_t &n, float &root_s)
+{
+	if (--n == 0) {
+		return;
+	}
+	lph_sift_down(K, hs, hd, n, rh_gets(hs, n), rh_getd(hd, n), root_s);	/* heap.c:146-147 */
+}
+
+/* heap_add (heap.c:58-124); the caller has checked acceptance (heap.c:68-74) */
+__device__ __forceinline__ void
+lph_add(const lph_lane_t &K, float &hs, uint32_t &hd, uint32_t &n, uint32_t cap, float s, uint32_t d, float &root_s)
+{
+	const uint32_t lane = threadIdx.x;
+
+	if (n == cap) {
+		lph_remove_min(K, hs, hd, n, root_s);
+	}
+	/* heap.c:96-122: the item enters at node i = n and rises past every ancestor
+	 * that is larger, stopping at the first (from below) that is <= it */
+	const uint32_t i = n++;
+	const uint32_t par = (lane - 1) >> 1;		/* (lane 0: no parent; never used) */
+	const float ps = __shfl(hs, (int)(par & 63));
+	const uint32_t pd = (uint32_t)__shfl((int)hd, (int)(par & 63));
+	const uint32_t ilo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)K.anc, (int)i);
+	const uint32_t ihi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(K.anc >> 32), (int)i);
+	const uint64_t anc_i = ((uint64_t)ihi << 32) | ilo;		/* proper ancestors of i */
+	const uint64_t stop = anc_i & ~ballot64(s < hs);		/* ancestors that end the rise */
+	/* the item lands on the chain node just below the nearest such ancestor (the
+	 * root if there is none); the chain nodes below its place take their parent's pair */
+	const uint64_t chain = anc_i | (1ull << i);
+	const uint64_t below = stop ? chain & ~((2ull << (63 - __builtin_clzll(stop))) - 1) : chain;
+	const uint32_t q = (uint32_t)__builtin_ctzll(below);		/* the shallowest of them: the item's place */
+	if (lane_of(below)) {
+		hs = ps;
+		hd = pd;
+	}
+	if (lane == q) {
+		hs = s;
+		hd = d;
+	}
+	if (q == 0) {
+		root_s = s;
+	}
+}
+
+/*
  * The same heap once more for 64 < k <= REPLAY_LDS_K (the API's default limit is
  * 1000), in dynamic LDS as (score, doc) PAIRS: both children of a node come with
  * one read, and the element on the move stays in registers ("hole" form of the
@@ -276,6 +393,8 @@ k_replay(const replay_args_t A)
 	float rhs = 0.0f;
 	uint32_t rhd = 0, rn = 0;
 	float rmin = 0.0f;
+	const lph_lane_t KL = lph_lane_init();
+	(void)KL;
 
 	if (A.skip && A.skip[q]) {
 		/* the query overflowed its candidate segments: its record says so (the
@@ -350,7 +469,11 @@ k_replay(const replay_args_t A)
 						const int L = __builtin_ctzll(pend);
 						const float v = rh_gets(sc, (uint32_t)L);
 						const uint32_t dv = rh_getd(dc, (uint32_t)L);
+#ifdef NXS_OLD_REGHEAP
 						rheap_add(rhs, rhd, rn, cap, v, dv);
+#else
+						lph_add(KL, rhs, rhd, rn, cap, v, dv, rmin);
+#endif
 						RSTAT(n_ins++;)
 						rn = (uint32_t)__builtin_amdgcn_readfirstlane((int)rn);
 						if (A.log_cnt && lane == 0) {
@@ -362,7 +485,9 @@ k_replay(const replay_args_t A)
 							}
 							A.log_cnt[row] = nl + 1;
 						}
+#ifdef NXS_OLD_REGHEAP
 						rmin = rh_gets(rhs, 0);
+#endif
 						pend &= pend - 1;
 						pend &= ballot64(valid && (rn < cap || sc > rmin));
 					}
@@ -480,9 +605,19 @@ k_replay(const replay_args_t A)
 		while (n) {
 			const uint32_t last = n - 1;
 			float ms; uint32_t mdoc;
+#ifdef NXS_OLD_REGHEAP
 			rheap_remove_min(rhs, rhd, n, ms, mdoc);
 			n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
 			rh_set(rhs, rhd, last, ms, mdoc);
+#else
+			ms = rh_gets(rhs, 0);
+			mdoc = rh_getd(rhd, 0);
+			lph_remove_min(KL, rhs, rhd, n, rmin);
+			if (lane == last) {
+				rhs = ms;
+				rhd = mdoc;
+			}
+#endif
 		}
 		/* lane i holds result i */
 		if (A.rec_base) {

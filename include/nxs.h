@@ -150,13 +150,25 @@ nxs_index_t *	nxs_index_open_files(nxs_t *, const char *terms_path,
  * runs a batch on every shard (each on its own device, `device` < 0 = the
  * NXS_GPU_DEVICE default) and merges the shards' candidates through one more
  * exact heap replay: the responses equal those of the unsharded index, ties
- * included.  limit <= 64; a shard is a static snapshot (no re-sync).
+ * included.  limit <= 64; a shard is a static snapshot (no re-sync).  The
+ * shards' passes run concurrently (every shard has its own device / streams).
+ *
+ * One process per shard (one GPU each): rank r opens shard r of W, attaches a
+ * communicator of W ranks (nxs_index_shard), joins the collection
+ * (nxs_docshard_attach: all-gather + sum of the shards' df, collective) and
+ * then every rank calls nxs_docshard_search_batch_rank() with the SAME batch:
+ * each runs its shard, ONE all-gather of the ranks' candidate blocks, every
+ * rank merges and holds all responses.
  */
 nxs_index_t *	nxs_index_open_shard(nxs_t *, const char *terms_path,
 		    const char *dtmap_path, const char *algo, bool lowercase,
 		    unsigned shard, unsigned n_shards, int device);
 int		nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards,
 		    nxs_params_t *, const char *const *queries, size_t n,
+		    nxs_resp_t **resps, nxs_err_t *errs);
+int		nxs_docshard_attach(nxs_index_t *shard);
+int		nxs_docshard_search_batch_rank(nxs_index_t *shard, nxs_params_t *,
+		    const char *const *queries, size_t n,
 		    nxs_resp_t **resps, nxs_err_t *errs);
 
 /*

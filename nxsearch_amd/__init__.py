@@ -84,6 +84,7 @@ NXS_H_SYMBOLS = [
     "nxs_index_plan_batch", "nxs_index_search_batch_begin",
     "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
     "nxs_index_host_profile", "nxs_index_open_shard", "nxs_docshard_search_batch",
+    "nxs_docshard_attach", "nxs_docshard_search_batch_rank",
 ]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -311,6 +312,80 @@ class Nxs:
             else:
                 out.append(NxsError(errs[i], "query %d failed" % i))
         return out
+
+    def _collect(self, r, n, resps, errs):
+        L = lib()
+        if r < 0:
+            self._raise()
+        out = []
+        for i in range(n):
+            if resps[i]:
+                out.append(_drain(resps[i]))
+                L.nxs_resp_release(resps[i])
+            else:
+                out.append(NxsError(errs[i], "query %d failed" % i))
+        return out
+
+    def docshard_search_batch_rank(self, shard, queries, limit=None, algo=None, fuzzymatch=None):
+        """nxs_docshard_search_batch_rank(): this rank's shard + one all-gather + merge."""
+        L = lib()
+        L.nxs_docshard_search_batch_rank.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
+                                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        n = len(queries)
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        resps, errs = (C.c_void_p * max(n, 1))(), (C.c_int * max(n, 1))()
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            r = L.nxs_docshard_search_batch_rank(shard._h, p, qs, n, resps, errs)
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        return self._collect(r, n, resps, errs)
+
+    def docshard_attach(self, shard):
+        """nxs_docshard_attach(): collective; collection-wide df for this rank's shard."""
+        L = lib()
+        L.nxs_docshard_attach.argtypes = [C.c_void_p]
+        if L.nxs_docshard_attach(shard._h) != 0:
+            self._raise()
+
+    def docshard_emulated_ranks(self, shards, queries, cap=512, limit=None, algo=None, fuzzymatch=None):
+        """tests: the one-process-per-shard form with the ranks played one after the
+        other on this GPU -- every rank's candidate block (nxs_test_docshard_block),
+        the blocks concatenated as the all-gather would, then every rank's merge
+        (nxs_test_docshard_finish).  -> one result list per rank."""
+        L = lib()
+        vp = C.c_void_p
+        L.nxs_test_docshard_set_df.argtypes = [C.POINTER(vp), C.c_uint]
+        L.nxs_test_docshard_block.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32,
+                                              C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.nxs_test_docshard_finish.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32,
+                                               C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        hs = (vp * len(shards))(*[s._h for s in shards])
+        if L.nxs_test_docshard_set_df(hs, len(shards)) != 0:
+            self._raise()
+        n = len(queries)
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        p = _make_params(limit, algo, fuzzymatch)
+        try:
+            gathered = b""
+            for sh in shards:
+                blk, ln = C.POINTER(C.c_uint8)(), C.c_size_t()
+                if L.nxs_test_docshard_block(sh._h, p, qs, n, cap, C.byref(blk), C.byref(ln)) != 0:
+                    self._raise()
+                gathered += C.string_at(blk, ln.value)
+                libc.free(blk)
+            outs = []
+            for sh in shards:
+                resps, errs = (vp * max(n, 1))(), (C.c_int * max(n, 1))()
+                r = L.nxs_test_docshard_finish(sh._h, p, qs, n, cap, gathered, resps, errs)
+                outs.append(self._collect(r, n, resps, errs))
+        finally:
+            if p:
+                L.nxs_params_release(p)
+        return outs
 
     def shard_unique_id(self):
         """nxs_shard_unique_id(): the bytes rank 0 hands to the other ranks."""

@@ -1448,6 +1448,30 @@ nxs_index_host_profile(nxs_index_t *idx, double out[8])
 
 /* status word of a record slot: 0, an nxs_err_t, or ... */
 #define	STATUS_HOSTPATH	0x100u	/* the owner evaluates it on the exact path (fix-up round) */
+/*
+ * A rank that cannot do its share of a sharded batch (planning failed, out of
+ * memory, its exact fix-up failed) must not leave its peers waiting in the
+ * all-gather: it still contributes a block, every status word of which carries
+ * STATUS_ABORT | its error code.  All ranks see all blocks, so all fail the batch
+ * together -- the collectives of every rank stay in step.
+ */
+#define	STATUS_ABORT	0x200u
+
+/* the first rank whose block says "aborted" (and its error code), or -1 */
+static int
+blocks_aborted(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k, nxs_err_t *code)
+{
+	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
+
+	for (uint32_t r = 0; n_slots && r < world; r++) {
+		const uint32_t *st = (const uint32_t *)(blocks + (size_t)r * block_bytes + (size_t)n_slots * rec_bytes);
+		if (st[0] & STATUS_ABORT) {
+			*code = (nxs_err_t)(st[0] & 0xff);
+			return (int)r;
+		}
+	}
+	return -1;
+}
 
 static nxs_pend_t *
 pend_oldest(nxs_index_t *idx)
@@ -1605,7 +1629,14 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		goto out;
 	}
 	t0 = now_s();
-	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1) {
+	/* (a rank of a real communicator: its peers queue an all-gather for this batch) */
+	const bool collective = idx->comm != NULL && !idx->emu_world && sp.limit <= NXSGPU_BIG_K;
+	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1 ||
+	    (idx->test_fail_begin && idx->test_fail_begin-- == 1 &&
+	    (nxs_decl_err(nxs, NXS_ERR_SYSTEM, "injected failure (test)"), true))) {
+		if (collective) {
+			goto abort_collective;
+		}
 		goto out;
 	}
 	t1 = now_s();
@@ -1616,6 +1647,9 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
 		if (!plans || !slot_of || !status) {
 			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+			if (collective) {
+				goto abort_collective;
+			}
 			goto out;
 		}
 		for (size_t i = 0; i < nl; i++) {
@@ -1653,6 +1687,31 @@ out:
 		pend_release(pd);
 	}
 	return ret;
+
+abort_collective:
+	/*
+	 * This rank cannot do its share, but its peers have queued (or will queue) the
+	 * batch's all-gather: contribute a block that says so and wait for the
+	 * collective, so that every rank fails this batch and the next one starts in
+	 * step.  The error of this rank stays in its slot.
+	 */
+	{
+		const nxs_err_t code = nxs->errcode ? nxs->errcode : NXS_ERR_FATAL;
+		char *msg = nxs->errmsg ? strdup(nxs->errmsg) : NULL;
+		nxsgpu_batch_view_t v;
+
+		free(status);
+		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
+		for (uint32_t i = 0; status && i < pd->cap; i++) {
+			status[i] = STATUS_ABORT | (uint32_t)code;
+		}
+		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, NULL, 0, NULL, status, pd->cap, 1) == 0) {
+			(void)nxsgpu_batch_end(idx->dev, &v);
+		}
+		nxs_decl_err(nxs, code, "%s", msg ? msg : "this rank aborted the sharded batch");
+		free(msg);
+	}
+	goto out;
 }
 
 /* exact path (nxsgpu_search / nxsgpu_search_wide) for the given local queries */
@@ -1856,6 +1915,15 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			    v.world, W);
 			goto out;
 		}
+		if (all) {
+			nxs_err_t acode;
+			const int ar = blocks_aborted(blocks, W, v.n_slots, v.k, &acode);
+			if (ar >= 0) {
+				/* every rank sees it: all of them fail here, none enters a fix-up round */
+				nxs_decl_err(nxs, acode ? acode : NXS_ERR_FATAL, "rank %d aborted the sharded batch", ar);
+				goto out;
+			}
+		}
 		/* records that need the exact path: every rank sees the same flags, so
 		 * every rank takes (or skips) the fix-up round together */
 		for (uint32_t r = 0; r < W; r++) {
@@ -1881,17 +1949,43 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			const size_t len = (all ? (size_t)W : 1) * v.block_bytes;
 			uint8_t *mine;
 
+			bool fix_failed = false;
+			char *fix_msg = NULL;
+			nxs_err_t fix_code = NXS_ERR_SUCCESS;
+
 			if ((patched = malloc(len ? len : 1)) == NULL) {
 				nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
-				goto out;
+				if (!(all && W > 1)) {
+					goto out;
+				}
+				/* (the peers are on their way into the fix-up all-gather: send the
+				 * unpatched block -- records still marked inexact fail the batch on
+				 * every rank, below) */
+				fix_failed = true;
+				fix_code = NXS_ERR_SYSTEM;
+			} else {
+				memcpy(patched, blocks, len);
 			}
-			memcpy(patched, blocks, len);
-			mine = patched + (all ? (size_t)pd->rank * v.block_bytes : 0);
-			if (run_exact(idx, pd, which, nw, &res, &wres, pos) != 0) {
-				goto out;
+			mine = patched ? patched + (all ? (size_t)pd->rank * v.block_bytes : 0) :
+			    (uint8_t *)(uintptr_t)(blocks + (size_t)pd->rank * v.block_bytes);
+			if (!fix_failed && (run_exact(idx, pd, which, nw, &res, &wres, pos) != 0 ||
+			    (idx->test_fail_fixup && idx->test_fail_fixup-- == 1 &&
+			    (nxs_decl_err(nxs, NXS_ERR_SYSTEM, "injected failure (test)"), true)))) {
+				if (!(all && W > 1)) {
+					goto out;
+				}
+				/* this rank's exact pass failed: say so in its block and still take
+				 * part in the collective */
+				uint32_t *st = (uint32_t *)(mine + (size_t)v.n_slots * v.rec_bytes);
+				fix_failed = true;
+				fix_code = nxs->errcode ? nxs->errcode : NXS_ERR_FATAL;
+				fix_msg = nxs->errmsg ? strdup(nxs->errmsg) : NULL;
+				for (uint32_t i = 0; i < v.n_slots; i++) {
+					st[i] = STATUS_ABORT | (uint32_t)fix_code;
+				}
 			}
 			idx->hp_inexact += nw;
-			for (size_t j = 0; j < nw; j++) {
+			for (size_t j = 0; !fix_failed && j < nw; j++) {
 				uint8_t *rec = mine + (size_t)which[j] * v.rec_bytes;
 				uint32_t *st = (uint32_t *)(mine + (size_t)v.n_slots * v.rec_bytes);
 				uint32_t at;
@@ -1907,15 +2001,47 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			if (all && W > 1) {
 				uint8_t *gathered = malloc(len);
 
+				/* (no buffer to receive into: a rank that cannot even allocate that
+				 * cannot be saved -- but it is the only case left that strands peers) */
 				if (!gathered || nxsgpu_comm_allgather(idx->comm, mine, gathered, v.block_bytes) != 0) {
 					nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather failed: %s",
 					    gathered ? nxsgpu_last_error() : "out of memory");
 					free(gathered);
+					free(fix_msg);
 					goto out;
 				}
 				free(patched);
 				patched = gathered;
+				{
+					nxs_err_t acode;
+					int ar = blocks_aborted(patched, W, v.n_slots, v.k, &acode);
+					/* ... or a record a rank could not patch (it is still marked) */
+					for (uint32_t r = 0; ar < 0 && r < W; r++) {
+						const uint8_t *blk = patched + (size_t)r * v.block_bytes;
+						const uint32_t *st = (const uint32_t *)(blk + (size_t)v.n_slots * v.rec_bytes);
+						uint64_t rlo, rhi;
+						nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
+						for (uint64_t i = 0; i < rhi - rlo; i++) {
+							if (((const uint32_t *)(blk + i * v.rec_bytes))[1] == NXSGPU_REC_INEXACT ||
+							    st[i] == STATUS_HOSTPATH) {
+								ar = (int)r;
+								acode = NXS_ERR_FATAL;
+							}
+						}
+					}
+					if (ar >= 0) {
+						if (ar == pd->rank && fix_code) {
+							nxs_decl_err(nxs, fix_code, "%s", fix_msg ? fix_msg : "exact pass failed");
+						} else {
+							nxs_decl_err(nxs, acode ? acode : NXS_ERR_FATAL,
+							    "rank %d aborted the sharded batch (exact fix-up round)", ar);
+						}
+						free(fix_msg);
+						goto out;
+					}
+				}
 			}
+			free(fix_msg);
 			blocks = patched;
 		}
 		if (!all) {
@@ -2094,21 +2220,80 @@ out:
 	return ret;
 }
 
-int
-nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_params_t *params,
-    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+/*
+ * One shard's pass: the candidates its heap accepts for every plan of the batch
+ * (nxsgpu_search_candidates), on the shard's own device and streams.  Shards of
+ * one process run these side by side, one host thread each (the HIP side keeps
+ * its error text per thread).
+ */
+typedef struct {
+	nxs_index_t *	shard;
+	int		algo;
+	uint64_t	limit;
+	const nxsgpu_query_t *plans;
+	uint32_t	np, cap;
+	uint64_t *	ids;	/* [np][cap] */
+	float *		sc;
+	uint32_t *	cnt;	/* [np] */
+	int		ret;
+	char		err[256];
+} ds_job_t;
+
+static void *
+ds_job_run(void *arg)
 {
-	nxs_index_t *idx0 = shards[0];
+	ds_job_t *j = arg;
+
+	j->ret = nxsgpu_search_candidates(j->shard->dev, j->algo, j->limit, j->plans, j->np, j->cap,
+	    j->ids, j->sc, j->cnt);
+	if (j->ret != 0) {
+		snprintf(j->err, sizeof(j->err), "%s", nxsgpu_last_error());
+	}
+	return NULL;
+}
+
+/*
+ * The doc-sharded search (N4).  Two forms share everything but where the other
+ * shards' candidates come from:
+ *  - in-process (nxs_docshard_search_batch): `local` holds ALL n_shards shard
+ *    indexes, each on its own device / streams; their passes run concurrently
+ *    (one host thread per shard), then the merge;
+ *  - one process per shard (nxs_docshard_search_batch_rank): `local` is this
+ *    rank's shard; the ranks all-gather their candidate blocks
+ *    (u32 abort | u32 cnt[np] | u64 ids[np][cap] | f32 sc[np][cap]) through the
+ *    communicator attached with nxs_index_shard() and EVERY rank merges -- the
+ *    query-sharded mode's rule: one collective per step, all ranks hold all
+ *    responses.  `gathered` (tests): the blocks of all ranks, instead of a
+ *    communicator; `my_block` (tests): hand out this rank's block and stop.
+ * The merge feeds the shards' accepted-candidate logs, highest doc ids first,
+ * through the reference's heap once more (nxsgpu_merge_candidates).
+ */
+static size_t
+ds_block_bytes(size_t np, uint32_t cap)
+{
+	return 8 + ((np * 4 + 7) & ~(size_t)7) + np * cap * 8 + np * cap * 4;
+}
+
+static int
+docshard_search(nxs_index_t *const *local, unsigned n_local, unsigned n_shards, unsigned my_shard,
+    nxs_params_t *params, const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs,
+    uint32_t cap0, const uint8_t *gathered, uint8_t **my_block, size_t *my_block_len)
+{
+	nxs_index_t *idx0 = local[0];
 	nxs_t *nxs = idx0->nxs;
+	const bool ranks = n_local == 1 && n_shards > 1;	/* one process per shard */
 	search_params_t sp;
 	qprep_t *prep = NULL;
 	nxsgpu_query_t *plans = NULL;
-	uint32_t *plan_of = NULL, *cnt_s = NULL, *cnt_all = NULL, *o_cnt = NULL;
-	uint64_t *ids_s = NULL, *ids_all = NULL, *o_ids = NULL;
-	float *sc_s = NULL, *sc_all = NULL, *o_sc = NULL;
+	uint32_t *plan_of = NULL, *cnt_all = NULL, *o_cnt = NULL;
+	uint64_t *ids_all = NULL, *o_ids = NULL;
+	float *sc_all = NULL, *o_sc = NULL;
+	ds_job_t *jobs = NULL;
+	pthread_t *thr = NULL;
+	uint8_t *sendb = NULL, *recvb = NULL;
 	slab_builder_t sb = { 0 };
 	size_t np = 0, total = 0;
-	uint32_t cap = 512;
+	uint32_t cap = cap0 ? cap0 : 512;
 	int failed = 0, ret = -1;
 
 	nxs_clear_error(nxs);
@@ -2125,8 +2310,14 @@ nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_par
 		nxs_decl_err(nxs, NXS_ERR_LIMIT, "doc-sharded search takes limit <= %d", NXSGPU_FAST_K);
 		return -1;
 	}
-	if (!idx0->global_df_set && docshard_set_global_df(shards, n_shards) == -1) {
-		return -1;
+	if (!idx0->global_df_set) {
+		if (!ranks && docshard_set_global_df(local, n_shards) == -1) {
+			return -1;
+		}
+		if (ranks) {
+			nxs_decl_err(nxs, NXS_ERR_INVALID, "nxs_docshard_attach() the shard first (collection-wide df)");
+			return -1;
+		}
 	}
 	if (n == 0) {
 		return 0;
@@ -2134,7 +2325,9 @@ nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_par
 	prep = calloc(n, sizeof(qprep_t));
 	plans = calloc(n, sizeof(nxsgpu_query_t));
 	plan_of = calloc(n, sizeof(uint32_t));
-	if (!prep || !plans || !plan_of) {
+	jobs = calloc(n_local, sizeof(ds_job_t));
+	thr = calloc(n_local, sizeof(pthread_t));
+	if (!prep || !plans || !plan_of || !jobs || !thr) {
 		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 		goto out;
 	}
@@ -2157,42 +2350,125 @@ nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_par
 	o_cnt = calloc(np ? np : 1, sizeof(uint32_t));
 	for (;;) {
 		bool overflow = false;
+		const size_t per = (np ? np : 1) * (size_t)cap;
+		const size_t bb = ds_block_bytes(np, cap);
 
-		free(ids_s); free(sc_s); free(cnt_s); free(ids_all); free(sc_all); free(cnt_all);
-		ids_s = malloc((np ? np : 1) * (size_t)cap * sizeof(uint64_t));
-		sc_s = malloc((np ? np : 1) * (size_t)cap * sizeof(float));
-		cnt_s = calloc(np ? np : 1, sizeof(uint32_t));
-		ids_all = malloc((np ? np : 1) * (size_t)n_shards * cap * sizeof(uint64_t));
-		sc_all = malloc((np ? np : 1) * (size_t)n_shards * cap * sizeof(float));
+		free(ids_all); free(sc_all); free(cnt_all);
+		ids_all = malloc(per * n_shards * sizeof(uint64_t));
+		sc_all = malloc(per * n_shards * sizeof(float));
 		cnt_all = calloc((np ? np : 1) * (size_t)n_shards, sizeof(uint32_t));
-		if (!o_ids || !o_sc || !o_cnt || !ids_s || !sc_s || !cnt_s || !ids_all || !sc_all || !cnt_all) {
+		for (unsigned s = 0; s < n_local; s++) {
+			free(jobs[s].ids); free(jobs[s].sc); free(jobs[s].cnt);
+			jobs[s].ids = malloc(per * sizeof(uint64_t));
+			jobs[s].sc = malloc(per * sizeof(float));
+			jobs[s].cnt = calloc(np ? np : 1, sizeof(uint32_t));
+			if (!jobs[s].ids || !jobs[s].sc || !jobs[s].cnt) {
+				o_cnt = (free(o_cnt), NULL);
+			}
+			jobs[s].shard = local[s];
+			jobs[s].algo = sp.algo;
+			jobs[s].limit = sp.limit;
+			jobs[s].plans = plans;
+			jobs[s].np = (uint32_t)np;
+			jobs[s].cap = cap;
+			jobs[s].ret = 0;
+		}
+		if (!o_ids || !o_sc || !o_cnt || !ids_all || !sc_all || !cnt_all) {
 			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 			goto out;
 		}
-		for (unsigned s = 0; s < n_shards && np; s++) {
-			if (nxsgpu_search_candidates(shards[s]->dev, sp.algo, sp.limit, plans, (uint32_t)np, cap,
-			    ids_s, sc_s, cnt_s) != 0) {
-				nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+		/* every local shard's pass is queued before any is waited for */
+		if (np) {
+			unsigned started = 0;
+			for (unsigned s = 1; s < n_local; s++) {
+				if (pthread_create(&thr[s], NULL, ds_job_run, &jobs[s]) != 0) {
+					break;
+				}
+				started = s;
+			}
+			ds_job_run(&jobs[0]);
+			for (unsigned s = 1; s <= started; s++) {
+				(void)pthread_join(thr[s], NULL);
+			}
+			for (unsigned s = started + 1; s < n_local; s++) {
+				ds_job_run(&jobs[s]);	/* (no thread: in line) */
+			}
+		}
+		for (unsigned s = 0; s < n_local; s++) {
+			if (jobs[s].ret != 0) {
+				nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", jobs[s].err);
+				if (!ranks) {
+					goto out;
+				}
+			}
+		}
+		if (!ranks) {
+			/* [query][shard][cap]: what the merge works on */
+			for (unsigned s = 0; s < n_local; s++) {
+				for (size_t q = 0; q < np; q++) {
+					const size_t at = (q * n_shards + s) * cap;
+					overflow = overflow || jobs[s].cnt[q] > cap;
+					cnt_all[q * n_shards + s] = jobs[s].cnt[q];
+					memcpy(ids_all + at, jobs[s].ids + q * cap, (size_t)cap * sizeof(uint64_t));
+					memcpy(sc_all + at, jobs[s].sc + q * cap, (size_t)cap * sizeof(float));
+				}
+			}
+		} else {
+			/* this rank's block; a rank whose pass failed says so in the first word
+			 * and still takes part in the collective */
+			free(sendb); free(recvb);
+			sendb = calloc(1, bb);
+			recvb = malloc(bb * n_shards);
+			if (!sendb || !recvb) {
+				nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 				goto out;
 			}
-			/* [query][shard][cap]: what the merge (and an all-gather of the
-			 * shards' blocks, in a multi-process deployment) works on */
-			for (size_t q = 0; q < np; q++) {
-				const size_t at = (q * n_shards + s) * cap;
-				overflow = overflow || cnt_s[q] > cap;
-				cnt_all[q * n_shards + s] = cnt_s[q];
-				memcpy(ids_all + at, ids_s + q * cap, (size_t)cap * sizeof(uint64_t));
-				memcpy(sc_all + at, sc_s + q * cap, (size_t)cap * sizeof(float));
+			const size_t cnt_len = (np * 4 + 7) & ~(size_t)7;
+			((uint32_t *)sendb)[0] = jobs[0].ret != 0 ? (uint32_t)NXS_ERR_FATAL : 0u;
+			memcpy(sendb + 8, jobs[0].cnt, np * 4);
+			memcpy(sendb + 8 + cnt_len, jobs[0].ids, np * (size_t)cap * 8);
+			memcpy(sendb + 8 + cnt_len + np * (size_t)cap * 8, jobs[0].sc, np * (size_t)cap * 4);
+			if (my_block) {			/* tests: one rank at a time, no collective */
+				*my_block = sendb;
+				*my_block_len = bb;
+				sendb = NULL;
+				ret = 0;
+				goto out;
+			}
+			if (gathered) {
+				memcpy(recvb, gathered, bb * n_shards);
+			} else if (nxsgpu_comm_allgather(idx0->comm, sendb, recvb, bb) != 0) {
+				nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather failed: %s", nxsgpu_last_error());
+				goto out;
+			}
+			for (unsigned s = 0; s < n_shards; s++) {
+				const uint8_t *blk = recvb + (size_t)s * bb;
+				const uint32_t *bc = (const uint32_t *)(blk + 8);
+
+				if (((const uint32_t *)blk)[0]) {
+					if (s != my_shard || !nxs->errcode) {
+						nxs_decl_err(nxs, NXS_ERR_FATAL, "shard %u failed its pass of the batch", s);
+					}
+					goto out;	/* every rank sees it: all fail together */
+				}
+				for (size_t q = 0; q < np; q++) {
+					const size_t at = (q * n_shards + s) * cap;
+					overflow = overflow || bc[q] > cap;
+					cnt_all[q * n_shards + s] = bc[q];
+					memcpy(ids_all + at, blk + 8 + cnt_len + q * (size_t)cap * 8, (size_t)cap * 8);
+					memcpy(sc_all + at, blk + 8 + cnt_len + np * (size_t)cap * 8 + q * (size_t)cap * 4, (size_t)cap * 4);
+				}
 			}
 		}
 		if (!overflow) {
 			break;
 		}
-		if (cap >= (1u << 16)) {
+		if (cap >= (1u << 16) || gathered || my_block) {
 			nxs_decl_err(nxs, NXS_ERR_LIMIT, "candidate log overflow");
 			goto out;
 		}
-		cap *= 8;	/* rare: adversarial score orders; try again with room */
+		cap *= 8;	/* rare: adversarial score orders; try again with room (every rank
+				 * sees every count: all ranks retry together) */
 	}
 	if (np && nxsgpu_merge_candidates(idx0->device, (uint32_t)sp.limit, (uint32_t)np, n_shards, cap,
 	    ids_all, sc_all, cnt_all, o_ids, o_sc, o_cnt) != 0) {
@@ -2235,10 +2511,129 @@ out:
 	for (size_t i = 0; prep && i < n; i++) {
 		nxs_query_release(&prep[i]);
 	}
+	for (unsigned s = 0; jobs && s < n_local; s++) {
+		free(jobs[s].ids); free(jobs[s].sc); free(jobs[s].cnt);
+	}
+	free(jobs); free(thr); free(sendb); free(recvb);
 	free(prep); free(plans); free(plan_of);
-	free(ids_s); free(sc_s); free(cnt_s); free(ids_all); free(sc_all); free(cnt_all);
+	free(ids_all); free(sc_all); free(cnt_all);
 	free(o_ids); free(o_sc); free(o_cnt);
 	return ret;
+}
+
+int
+nxs_docshard_search_batch(nxs_index_t *const *shards, unsigned n_shards, nxs_params_t *params,
+    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	return docshard_search(shards, n_shards, n_shards, 0, params, queries, n, resps, errs, 0, NULL, NULL, NULL);
+}
+
+/*
+ * One process per shard: make this rank's shard part of the collection.  The
+ * communicator is the one nxs_index_shard() attached (rank r holds shard r of
+ * `world`); collection-wide df = the all-gathered shards' df arrays, summed, and
+ * every impact of the shard is recomputed with it.  Collective.
+ */
+int
+nxs_docshard_attach(nxs_index_t *shard)
+{
+	nxs_t *nxs = shard->nxs;
+	const uint32_t T = shard->last_id;
+	const unsigned W = shard->n_shards;
+	uint32_t *df = NULL, *all = NULL;
+	int ret = -1;
+
+	nxs_clear_error(nxs);
+	if (W > 1 && (!shard->comm || nxsgpu_comm_world(shard->comm) != (int)W ||
+	    nxsgpu_comm_rank(shard->comm) != (int)shard->shard)) {
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "shard %u of %u needs a communicator of %u ranks with itself as "
+		    "rank %u (nxs_index_shard)", shard->shard, W, W, shard->shard);
+		return -1;
+	}
+	df = calloc((size_t)T + 2, sizeof(uint32_t));
+	all = calloc(((size_t)T + 2) * W, sizeof(uint32_t));
+	if (!df || !all) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	(void)nxsgpu_index_df(shard->dev, df);
+	if (W > 1) {
+		if (nxsgpu_comm_allgather(shard->comm, df, all, ((size_t)T + 2) * 4) != 0) {
+			nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather of the shards' df failed: %s", nxsgpu_last_error());
+			goto out;
+		}
+		memset(df, 0, ((size_t)T + 2) * 4);
+		for (unsigned r = 0; r < W; r++) {
+			for (uint32_t t = 1; t <= T; t++) {
+				df[t] += all[(size_t)r * (T + 2) + t];
+			}
+		}
+	}
+	if (nxsgpu_index_set_global_df(shard->dev, df, T) != 0) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "%s", nxsgpu_last_error());
+		goto out;
+	}
+	shard->global_df_set = true;
+	ret = 0;
+out:
+	free(df);
+	free(all);
+	return ret;
+}
+
+int
+nxs_docshard_search_batch_rank(nxs_index_t *shard, nxs_params_t *params,
+    const char *const *queries, size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_index_t *local[1] = { shard };
+
+	if (shard->n_shards > 1 && !shard->comm) {
+		nxs_clear_error(shard->nxs);
+		nxs_decl_err(shard->nxs, NXS_ERR_INVALID, "no communicator attached (nxs_index_shard)");
+		return -1;
+	}
+	return docshard_search(local, 1, shard->n_shards, shard->shard, params, queries, n, resps, errs, 0, NULL, NULL, NULL);
+}
+
+/*
+ * Tests (one GPU, no second rank to talk to): the two halves of the rank form.
+ * nxs_test_docshard_block() = this rank's candidate block (malloc'ed);
+ * nxs_test_docshard_finish() = what every rank does once it holds all blocks.
+ * nxs_test_docshard_set_df() stands in for nxs_docshard_attach()'s collective.
+ */
+int
+nxs_test_docshard_block(nxs_index_t *shard, nxs_params_t *params, const char *const *queries, size_t n,
+    uint32_t cap, uint8_t **block, size_t *len)
+{
+	nxs_index_t *local[1] = { shard };
+	nxs_resp_t **resps = calloc(n ? n : 1, sizeof(*resps));
+	int r;
+
+	if (!resps) {
+		return -1;
+	}
+	*block = NULL;
+	*len = 0;
+	r = docshard_search(local, 1, shard->n_shards, shard->shard, params, queries, n,
+	    resps, NULL, cap, NULL, block, len);
+	free(resps);
+	return r;
+}
+
+int
+nxs_test_docshard_finish(nxs_index_t *shard, nxs_params_t *params, const char *const *queries, size_t n,
+    uint32_t cap, const uint8_t *gathered, nxs_resp_t **resps, nxs_err_t *errs)
+{
+	nxs_index_t *local[1] = { shard };
+
+	return docshard_search(local, 1, shard->n_shards, shard->shard, params, queries, n, resps, errs, cap,
+	    gathered, NULL, NULL);
+}
+
+int
+nxs_test_docshard_set_df(nxs_index_t *const *shards, unsigned n_shards)
+{
+	return docshard_set_global_df(shards, n_shards);
 }
 
 /* ---- query sharding over the GPUs of a node ---------------------------------------- */
@@ -2413,18 +2808,50 @@ nxs_test_pack_record(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot
 	st[slot] = status;
 }
 
+/* what a rank that cannot do its share contributes instead (STATUS_ABORT) */
+void
+nxs_test_pack_abort(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t code)
+{
+	uint32_t *st = (uint32_t *)(block + (size_t)n_slots * NXSGPU_REC_BYTES(k));
+
+	memset(block, 0, NXSGPU_BLOCK_BYTES(n_slots, k));
+	for (uint32_t i = 0; i < n_slots; i++) {
+		st[i] = STATUS_ABORT | code;
+	}
+}
+
+/* the n-th next _begin (which = 0) / exact fix-up round (1) of the index fails */
+void
+nxs_test_inject_failure(nxs_index_t *idx, int which, unsigned nth)
+{
+	if (which == 0) {
+		idx->test_fail_begin = nth;
+	} else {
+		idx->test_fail_fixup = nth;
+	}
+}
+
+/* >= 0: failed queries; -1: error; <= -2: rank (-2 - ret) aborted the batch --
+ * every rank sees that and fails the batch, none is left in a collective */
 int
 nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k,
     size_t n, nxs_resp_t **resps, nxs_err_t *errs)
 {
 	nxs_t fake;
 	slab_builder_t sb = { 0 };
-	int failed = 0;
+	int failed = 0, ar;
+	nxs_err_t acode;
 
 	memset(&fake, 0, sizeof(fake));
 	for (size_t i = 0; i < n; i++) {
 		resps[i] = NULL;
 		errs[i] = NXS_ERR_SUCCESS;
+	}
+	if ((ar = blocks_aborted(blocks, world, n_slots, k, &acode)) >= 0) {
+		for (size_t i = 0; i < n; i++) {
+			errs[i] = acode;
+		}
+		return -2 - ar;
 	}
 	if (resps_from_blocks(&fake, NULL, n, world, n_slots, k, blocks, resps, errs, &sb, &failed) == -1) {
 		free(fake.errmsg);

@@ -89,6 +89,30 @@ def pack_block(results, n_slots, k):
     return buf.raw[:block_bytes(n_slots, k)]
 
 
+def pack_abort(n_slots, k, code):
+    """The block of a rank that cannot do its share of the batch: every status
+    word says STATUS_ABORT | code.  The rank still takes part in the all-gather."""
+    L = lib()
+    L.nxs_test_pack_abort.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    buf = C.create_string_buffer(max(block_bytes(n_slots, k), 1))
+    L.nxs_test_pack_abort(buf, n_slots, k, code)
+    return buf.raw[:block_bytes(n_slots, k)]
+
+
+class ShardAborted(NxsError):
+    """A rank aborted the sharded batch; every rank raises this for the batch."""
+    def __init__(self, rank, code):
+        NxsError.__init__(self, code, "rank %d aborted the sharded batch" % rank)
+        self.rank = rank
+
+
+def inject_failure(index, which, nth=1):
+    """tests: the nth next _begin ("begin") / exact fix-up round ("fixup") fails."""
+    L = lib()
+    L.nxs_test_inject_failure.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+    L.nxs_test_inject_failure(index._h, 0 if which == "begin" else 1, nth)
+
+
 def assemble(blocks, world, n_slots, k, n):
     """What every rank does with the gathered blocks (resps_from_blocks):
     -> list of result lists; a failed query is an NxsError in its slot."""
@@ -99,7 +123,10 @@ def assemble(blocks, world, n_slots, k, n):
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     resps = (C.c_void_p * max(n, 1))()
     errs = (C.c_int * max(n, 1))()
-    if L.nxs_test_assemble(blocks, world, n_slots, k, n, resps, errs) < 0:
+    r = L.nxs_test_assemble(blocks, world, n_slots, k, n, resps, errs)
+    if r <= -2:
+        raise ShardAborted(-2 - r, errs[0] if n else 1)
+    if r < 0:
         raise NxsError(1, "assemble failed")
     out = []
     for i in range(n):

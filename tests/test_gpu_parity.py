@@ -667,6 +667,17 @@ def test_sharded_single_rank_through_rccl(nxs, tmp_path):
     for q, g in zip(qs, got):
         assert_same(g, oidx.search(q, limit=10), q)
     assert_same(gidx.search(qs[0], limit=10), oidx.search(qs[0], limit=10))    # never sharded
+    # limits above 64 shard too (fixed-size records up to NXSGPU_BIG_K)
+    for q, g in zip(qs[:24], gidx.search_batch(qs[:24], limit=300)):
+        assert_same(g, oidx.search(q, limit=300), (q, 300))
+    # a rank that cannot do its share still feeds the all-gather (STATUS_ABORT block):
+    # the batch fails with this rank's own error, the next batch is in step again
+    multi.inject_failure(gidx, "begin")
+    with pytest.raises(N.NxsError) as e:
+        gidx.search_batch(qs, limit=10)
+    assert e.value.code == 2 and "injected failure" in e.value.msg
+    for q, g in zip(qs, gidx.search_batch(qs, limit=10)):
+        assert_same(g, oidx.search(q, limit=10), q)
     gidx.shard(0, 1, None)                            # detach
     got = gidx.search_batch(qs[:16], limit=10)
     for q, g in zip(qs, got):
@@ -1016,8 +1027,39 @@ def test_doc_sharded_collection_equals_the_whole_index(nxs, tmp_path, n_shards):
     with pytest.raises(N.NxsError) as e:
         nxs.docshard_search_batch(sh2, qs[:2], limit=100)
     assert e.value.code == 6
+    # one process per shard, the ranks played one after the other on this GPU: every
+    # rank's candidate block, the blocks laid out as the all-gather would, every rank's
+    # merge -- all ranks hold the whole batch's responses
+    for per_rank in nxs.docshard_emulated_ranks(sh2, qs, limit=10, fuzzymatch=False):
+        for q, g in zip(qs, per_rank):
+            assert_same(g, o2.search(q, limit=10, fuzzymatch=False), ("rank form", q))
+    for per_rank in nxs.docshard_emulated_ranks(shards, queries[:40], cap=4096, limit=64):
+        for q, g in zip(queries[:40], per_rank):
+            try:
+                want = oidx.search(q, limit=64)
+            except O.SearchError as e:
+                assert isinstance(g, N.NxsError) and g.code == e.code
+                continue
+            assert_same(g, want, ("rank form", n_shards, q))
     for s_ in shards + sh2:
         s_.close()
+
+
+def test_doc_sharded_rank_form_through_rccl(nxs, tmp_path):
+    """The one-process-per-shard entry points end to end on ONE rank: a real RCCL
+    communicator (world 1), nxs_docshard_attach (all-gather of the df arrays) and
+    nxs_docshard_search_batch_rank (all-gather of the candidate blocks, merge)."""
+    from nxsearch_amd import multi
+    c = corpus.write_corpus(str(tmp_path), 60_000, 3000, seed=73)
+    terms = corpus.term_strings(3000, seed=73)
+    oidx = O.Index(c["terms"], c["dtmap"])
+    sh = nxs.open_shard(c["terms"], c["dtmap"], 0, 1)
+    multi.attach(nxs, sh, 0, 1)
+    nxs.docshard_attach(sh)
+    qs = corpus.queries_bool5(terms, 40, seed=5, hi=400) + corpus.queries_single(terms, 8, seed=6, lo=1, hi=200)
+    for q, g in zip(qs, nxs.docshard_search_batch_rank(sh, qs, limit=10, fuzzymatch=False)):
+        assert_same(g, oidx.search(q, limit=10, fuzzymatch=False), q)
+    sh.close()
 
 
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},

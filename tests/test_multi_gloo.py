@@ -104,3 +104,47 @@ def test_two_rank_sharded_search_reassembles_the_batch(tmp_path, n, k):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, tdir, n, k, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_abort(rank, world, port, tdir, n, k, ret):
+    """Rank 1 cannot do its share (planning failed, out of memory ...): it still
+    contributes a block -- all status words STATUS_ABORT | code -- so the ONE
+    collective completes on every rank, and every rank fails the batch together."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oidx = O.Index(os.path.join(tdir, "nxsterms"), os.path.join(tdir, "nxsdtmap"))
+    lo, hi = multi.shard_slice(n, rank, world)
+    cap = multi.shard_capacity(n, world)
+    if rank == 1:
+        block = multi.pack_abort(cap, k, 2)                  # NXS_ERR_SYSTEM
+    else:
+        block = multi.pack_block([_answer(oidx, q, k) for q in QUERIES[lo:hi]], cap, k)
+    send = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    recv = torch.empty(world * len(block), dtype=torch.uint8)
+    dist.all_gather_into_tensor(recv, send)                  # nobody is left waiting here
+    try:
+        multi.assemble(recv.numpy().tobytes(), world, cap, k, n)
+        ret[rank] = "no error"
+    except multi.ShardAborted as e:
+        ret[rank] = (e.rank, e.code)
+    # the next batch is in step again
+    block = multi.pack_block([_answer(oidx, q, k) for q in QUERIES[lo:hi]], cap, k)
+    send = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    dist.all_gather_into_tensor(recv, send)
+    got = multi.assemble(recv.numpy().tobytes(), world, cap, k, n)
+    assert len(got) == n
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_cannot_strand_its_peers(tmp_path):
+    world, n, k = 2, 9, 10
+    nxsfmt.write_index(str(tmp_path), "idx", [(d, t.split()) for d, t in DOCS.items()])
+    tdir = str(tmp_path)
+    if not os.path.exists(os.path.join(tdir, "nxsterms")):
+        tdir = os.path.join(tdir, "data", "idx")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_abort, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: (1, 2), 1: (1, 2)}

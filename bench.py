@@ -82,6 +82,9 @@ def parse_args():
                     help="worker processes of the CPU-NP baseline (0 = every core of the host share)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="seed-distinct batches rotated through the timed loop")
+    ap.add_argument("--docshard", type=int, default=0,
+                    help="N4: cut the collection into S doc shards (all on this GPU, a stream set each) and "
+                         "run the batch doc-sharded (nxs_docshard_search_batch)")
     ap.add_argument("--sparse-ids", action="store_true",
                     help="corpus with sparse random u64 doc ids (SURVEY 8d: exercises the ordinal map)")
     ap.add_argument("--no-extras", action="store_true",
@@ -174,8 +177,11 @@ def main():
     t_gen = time.time() - t0
     terms = corpus.term_strings(args.terms, seed=args.seed)
 
-    # ---- index resident in HBM (one replica per GPU) ------------------------
     os.environ["NXS_GPU_DEVICE"] = str(local_rank)
+    if args.docshard > 0:
+        return docshard_bench(args, info, terms, corpus, work, t_gen)
+
+    # ---- index resident in HBM (one replica per GPU) ------------------------
     t0 = time.time()
     nxs = N.Nxs(work)
     idx = nxs.open_files(info["terms"], info["dtmap"], algo="BM25")
@@ -355,6 +361,66 @@ def main():
             shutil.rmtree(work, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def docshard_bench(args, info, terms, corpus, work, t_gen):
+    """N4: the collection cut into S doc shards, every shard a device index of its own
+    (here all on one GPU, each with its own streams), a batch runs on all of them at once
+    and the shards' accepted candidates are merged by one more exact heap replay."""
+    import nxsearch_amd as N
+    S = args.docshard
+    t0 = time.time()
+    nxs = N.Nxs(work)
+    shards = [nxs.open_shard(info["terms"], info["dtmap"], s, S) for s in range(S)]
+    t_load = time.time() - t0
+    B = C.CDLL(os.path.join(N.CSRC, "libnxsbench.so"))
+    B.nxs_bench_docshard.restype = C.c_int
+    B.nxs_bench_docshard.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t,
+                                     C.c_uint, C.c_uint, C.POINTER(BenchOut)]
+    n_sets = max(1, args.rotate)
+    batches = [make_queries(args, terms, args.batch, corpus, variant=v) for v in range(n_sets)]
+    qarr_all = c_strings([q for b in batches for q in b])
+    fuzzy_on = args.workload in ("C4", "C5")
+    params = N._make_params(args.limit, "BM25", fuzzy_on)
+    hs = (C.c_void_p * S)(*[s._h for s in shards])
+    out = BenchOut()
+
+    def run(steps):
+        if B.nxs_bench_docshard(hs, S, params, qarr_all, args.batch, n_sets, steps, C.byref(out)) != 0:
+            raise N.NxsError(*nxs.error())
+    run(args.warmup)
+    t0 = time.perf_counter()
+    run(args.steps)
+    elapsed = time.perf_counter() - t0
+    # parity sample against the whole-index oracle
+    mism = None
+    if args.cpu_seconds > 0:
+        import oracle_lib as O
+        oidx = O.Index(info["terms"], info["dtmap"])
+        sample = batches[0][:max(4, min(24, int(args.cpu_seconds)))]
+        got = nxs.docshard_search_batch(shards, sample, limit=args.limit, fuzzymatch=fuzzy_on)
+        mism = sum(1 for q, g in zip(sample, got) if g != oidx.search(q, algo=O.BM25, limit=args.limit, fuzzymatch=fuzzy_on))
+        oidx.close()
+    what = WORKLOADS[args.workload][3] % args.limit
+    res = {"metric": "queries/sec (%s), doc-sharded x%d" % (what, S),
+           "value": round(args.batch * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s: %d docs / %d terms Zipf, %s, batch %d, %d doc shards on one GPU" % (
+                          args.workload, args.docs, args.terms, what, args.batch, S),
+                      "boundary": "nxs_docshard_search_batch: query strings in, nxs_resp_t out (blocking)",
+                      "parallelism": "doc-sharded x%d (N4): shards scanned concurrently, candidates merged by an "
+                                     "exact heap replay; one process" % S},
+           "roofline": None, "results_per_step": int(out.results // max(args.steps, 1)),
+           "failed_queries": int(out.failed), "parity_mismatches_vs_whole_index_oracle": mism,
+           "setup_s": {"corpus": round(t_gen, 1), "index_load": round(t_load, 1)}}
+    N.lib().nxs_params_release(params)
+    for s in shards:
+        s.close()
+    nxs.close()
+    print(json.dumps(res), flush=True)
+    if not args.keep and not args.workdir:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def pmc_traffic(args, world):

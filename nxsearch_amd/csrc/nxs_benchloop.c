@@ -131,3 +131,33 @@ nxs_bench_singles(nxs_index_t *idx, nxs_params_t *params, const char *const *que
 	}
 	return 0;
 }
+
+/* `steps` doc-sharded batches (N4): every shard's pass concurrently, one merge */
+int
+nxs_bench_docshard(nxs_index_t *const *shards, unsigned n_shards, nxs_params_t *params,
+    const char *const *all_queries, size_t n, unsigned n_sets, unsigned steps, nxs_bench_out_t *out)
+{
+	nxs_resp_t **resps = calloc(n ? n : 1, sizeof(*resps));
+	nxs_err_t *errs = calloc(n ? n : 1, sizeof(*errs));
+	int ret = -1;
+	double t0;
+
+	memset(out, 0, sizeof(*out));
+	if (!resps || !errs || n_sets == 0) {
+		goto out;
+	}
+	t0 = now_s();
+	for (unsigned s = 0; s < steps; s++) {
+		const char *const *queries = all_queries + (size_t)(s % n_sets) * n;
+		if (nxs_docshard_search_batch(shards, n_shards, params, queries, n, resps, errs) < 0) {
+			goto out;
+		}
+		consume(resps, n, out);
+	}
+	out->seconds = now_s() - t0;
+	ret = 0;
+out:
+	free(resps);
+	free(errs);
+	return ret;
+}

@@ -73,6 +73,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.scanm_maxnt = (uint32_t)u64("NXS_GPU_SCANM_MAXNT", 8, 2, 8);
 	c.rmin = on("NXS_GPU_NOSCANR2") ? 3u : 2u;
 	c.seg_cap = (uint32_t)u64("NXS_GPU_SEGCAP", SEG_CAP_DEFAULT, 1, 1u << 16);
+	c.scan1_split = (uint32_t)u64("NXS_GPU_SCAN1_SPLIT", 64, 1, 1u << 30);
 	c.seg_cap_big = (uint32_t)u64("NXS_GPU_SEGCAP_BIG", 0, 0, 1u << 20);
 	c.big_minpost = u64("NXS_GPU_BIG_MINPOST", 32, 0, 1u << 20);
 	c.fuzzy_items = u64("NXS_GPU_FUZZY_ITEMS", 256ull << 20, 1, 1ull << 32);

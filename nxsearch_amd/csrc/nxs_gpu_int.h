@@ -108,6 +108,8 @@ struct gpu_cfg_t {
 	uint32_t	scanm_minnt, scanm_maxnt;
 	uint32_t	rmin;		/* fewest tokens for k_scanr (NXS_GPU_NOSCANR2 => 3) */
 	uint32_t	seg_cap;	/* NXS_GPU_SEGCAP */
+	uint32_t	scan1_split;	/* NXS_GPU_SCAN1_SPLIT: single-token classes with a query of this many ranges
+					 * send every query's top range ahead in a launch of its own */
 	uint32_t	seg_cap_big;	/* NXS_GPU_SEGCAP_BIG: the same for limits > 64 (0: 6 x limit) */
 	uint64_t	big_minpost;	/* NXS_GPU_BIG_MINPOST: postings per range and unit of limit, limits > 64 */
 	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */

@@ -199,6 +199,13 @@ k_scanm(const scan_args_t A)
 	const uint32_t cs_nout = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cs[1]) : 0u;
 	const float cs_thr = DROP ? __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)cs[2])) : 0.0f;
 	const bool cs_ovf = DROP && __builtin_amdgcn_readfirstlane((int)cs[3]) != 0;
+	/*
+	 * Set-up in three steps, each ONE memory round trip for all terms together
+	 * (term by term -- plan words, wait, windows, wait, next term -- a wavefront spent
+	 * ten dependent round trips before its first tile, a fifth of its life):
+	 * the terms' plan words; then every term's two register windows and its ring;
+	 * then the scalars that need the windows (highest / lowest doc).
+	 */
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		pt[t] = A.post;
@@ -219,6 +226,9 @@ k_scanm(const scan_args_t A)
 			hi[t] = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
 			tmx[t] = Q->tmax[t];
 		}
+	});
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
 		if (DROP) {
 			if (((dmask >> t) & 1) || cs_left == 0) {
 				hi[t] = lo[t];		/* no postings as far as the windows are concerned */
@@ -245,13 +255,19 @@ k_scanm(const scan_args_t A)
 				bpair_request<t * RING + r>(&pt[t][min(ir, hi[t] - 1)]);
 				rst[t].st[r] = vseq++;
 			});
+		}
+	});
+	/* (the published thresholds of the higher ranges: in flight with the windows) */
+	const float hint = range_hint(A, qm, g);	/* 0 = nothing published yet */
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		if (hi[t] > lo[t]) {
 			refresh_pdoc(tc);
 			refresh_ldoc(tc);
 		}
 	});
 
 	float top = DROP ? A.cold_top[seg * 64 + lane] : -INFINITY;
-	const float hint = range_hint(A, qm, g);	/* 0 = nothing published yet */
 	float thr = DROP ? fmaxf(hint, cs_thr) : hint;	/* scores are > 0: 0 passes everything */
 	const uint32_t kidx = A.k - 1;			/* 1 <= k <= 64 (host) */
 	uint32_t n_out = cs_nout;

@@ -253,6 +253,24 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 						wl.items.push_back(it);
 					}
 				}
+				/*
+				 * Single-token queries (k_scan1: a wavefront is ~20 us of streaming):
+				 * a dense term is thousands of ranges that would all start at once,
+				 * cold, each handing its ~10 (1 + ln(postings / 10)) early maxima to
+				 * the one wavefront that replays the query -- 150 000 candidates for a
+				 * term holding 90 % of 10M docs, 0.3 ms of replay behind 0.05 ms of
+				 * scanning.  The TOP range of every query goes first, in a launch of
+				 * its own: when the others start it has published the 10th best of its
+				 * 4096 postings, and they emit a seventh of that.
+				 */
+				if (lev == 0 && l.kind == 1 && l.nt_bucket == 1 && max_g >= cf.scan1_split && !big_k && !solo) {
+					launch_t l0 = l;
+					l0.count = (uint32_t)wl.items.size() - l0.first;
+					l0.q_first = o0;
+					l0.q_count = 0;			/* (no replay behind this one) */
+					wl.launches.push_back(l0);
+					l.first = (uint32_t)wl.items.size();
+				}
 			}
 		} else {
 			for (uint32_t oi = o0; oi < o1; oi++) {

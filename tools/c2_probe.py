@@ -13,7 +13,7 @@ info = corpus.write_corpus(work, docs, docs // 10, seed=0)
 terms = corpus.term_strings(docs // 10, 0)
 nxs = N.Nxs(work)
 idx = nxs.open_files(info["terms"], info["dtmap"])
-qs = corpus.queries_single(terms, 1024, seed=3)
+qs = corpus.queries_single(terms, 1024, seed=3, lo=int(os.environ.get("LO", "10")), hi=int(os.environ.get("HI", "10000")))
 for _ in range(3):
     idx.search_batch(qs, limit=10, fuzzymatch=False)
 idx.set_profiling(True); idx.profile(reset=True)

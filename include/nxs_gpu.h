@@ -83,6 +83,9 @@ typedef struct {
 	uint32_t	bk_depth;	/* number of BFS levels */
 	const uint8_t *	bk_bytes;
 	uint64_t	bk_bytes_len;
+	/* the index's ranking function (params.db "algo"): its impacts are built with
+	 * the index, the other function's on the first search that asks for it; -1: both */
+	int		default_algo;
 } nxsgpu_index_src_t;
 
 /* one resolved query */

@@ -209,8 +209,12 @@ k_impacts(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
 		pb.imp = (float)(tf_bm25 * idf_bm25[t]);
 		pt.doc = doc;
 		pt.imp = (float)tf * idf_tfidf[t];
-		out_bm25[i] = pb;
-		out_tfidf[i] = pt;
+		if (out_bm25) {
+			out_bm25[i] = pb;
+		}
+		if (out_tfidf) {
+			out_tfidf[i] = pt;
+		}
 		/*
 		 * Largest impact of the term (k_scanm's score bounds).  Impacts are
 		 * >= +0, where unsigned order of the bit pattern is float order.  The
@@ -322,10 +326,14 @@ k_impacts_csr(const uint64_t *__restrict__ off, uint32_t n_terms, const uint64_t
 				pb.imp = (float)(tf_bm25 * idf_bm25[t]);
 				pt.doc = doc;
 				pt.imp = (float)tf * idf_tfidf[t];
-				out_bm25[i] = pb;
-				out_tfidf[i] = pt;
-				bb_ = pb.imp > 0.0f ? __float_as_uint(pb.imp) : 0u;
-				bt_ = pt.imp > 0.0f ? __float_as_uint(pt.imp) : 0u;
+				if (out_bm25) {
+					out_bm25[i] = pb;
+				}
+				if (out_tfidf) {
+					out_tfidf[i] = pt;
+				}
+				bb_ = (out_bm25 && pb.imp > 0.0f) ? __float_as_uint(pb.imp) : 0u;
+				bt_ = (out_tfidf && pt.imp > 0.0f) ? __float_as_uint(pt.imp) : 0u;
 			}
 			/* largest impact per term (k_scanm's bounds): one atomic per
 			 * wavefront when all its postings belong to one term */
@@ -341,10 +349,10 @@ k_impacts_csr(const uint64_t *__restrict__ off, uint32_t n_terms, const uint64_t
 				}
 			}
 			if (valid) {
-				if (bb_ > max_bm25[t]) {
+				if (bb_ && bb_ > max_bm25[t]) {
 					atomicMax(&max_bm25[t], bb_);
 				}
-				if (bt_ > max_tfidf[t]) {
+				if (bt_ && bt_ > max_tfidf[t]) {
 					atomicMax(&max_tfidf[t], bt_);
 				}
 			}
@@ -620,8 +628,11 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
  * the first build and by every refresh (N, adl and df move every idf).
  */
 int
-rebuild_impacts(nxsgpu_index_t *ix)
+rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 {
+	/* the ranking functions to (re)compute: materialised ones only */
+	const bool do_b = (only & (1u << NXSGPU_BM25)) && ix->algo_on[NXSGPU_BM25];
+	const bool do_t = (only & (1u << NXSGPU_TF_IDF)) && ix->algo_on[NXSGPU_TF_IDF];
 	const uint32_t T = ix->n_terms;
 	const uint64_t P = ix->n_post;
 	const unsigned long N = ix->hdr_doc_count;
@@ -671,9 +682,13 @@ rebuild_impacts(nxsgpu_index_t *ix)
 		adl = (double)(ix->hdr_token_count / N);	/* ranking.c:163 */
 		ix->bm25_valid = !(adl < 1);
 	}
-	ix->h_maximp[NXSGPU_BM25].assign((size_t)T + 2, 0.0f);
-	ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
-	if (P == 0) {
+	if (do_b || !ix->algo_on[NXSGPU_BM25]) {
+		ix->h_maximp[NXSGPU_BM25].assign((size_t)T + 2, 0.0f);
+	}
+	if (do_t || !ix->algo_on[NXSGPU_TF_IDF]) {
+		ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
+	}
+	if (P == 0 || (!do_b && !do_t)) {
 		return 0;
 	}
 	HIP_TRY(hipMalloc(&d_logtf, logtf.size() * 8));
@@ -687,16 +702,21 @@ rebuild_impacts(nxsgpu_index_t *ix)
 	hipLaunchKernelGGL(k_impacts_csr, dim3(4096), dim3(256), 0, ix->stream,
 	    ix->d_post_off, T, ix->d_post_dt, P, ix->d_doc_len, d_logtf, d_idf_bm25,
 	    d_idf_tfidf, adl >= 1 ? adl : 1.0, kk, bb,
-	    ix->d_post[NXSGPU_BM25], ix->d_post[NXSGPU_TF_IDF],
+	    do_b ? ix->d_post[NXSGPU_BM25] : (posting_t *)NULL, do_t ? ix->d_post[NXSGPU_TF_IDF] : (posting_t *)NULL,
 	    d_maximp, d_maximp + (size_t)T + 2);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_BM25].data(), d_maximp, ((size_t)T + 2) * 4,
-	    hipMemcpyDeviceToHost, ix->stream));
-	HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
-	    hipMemcpyDeviceToHost, ix->stream));
+	if (do_b) {
+		HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_BM25].data(), d_maximp, ((size_t)T + 2) * 4,
+		    hipMemcpyDeviceToHost, ix->stream));
+	}
+	if (do_t) {
+		HIP_TRY(hipMemcpyAsync(ix->h_maximp[NXSGPU_TF_IDF].data(), d_maximp + (size_t)T + 2, ((size_t)T + 2) * 4,
+		    hipMemcpyDeviceToHost, ix->stream));
+	}
 	HIP_TRY(hipStreamSynchronize(ix->stream));
-	/* impact columns of the dense terms (at most 64, densest first) */
-	{
+	/* impact columns of the dense terms (at most 64, densest first): BM25 only -- the
+	 * class that reads them is (k_scanm<.., DROP>, fill_dev_queries) */
+	if (do_b) {
 		std::vector<std::pair<uint64_t, uint32_t>> dn;
 		for (uint32_t t = 1; t <= T; t++) {
 			const uint64_t df = ix->h_post_off[t + 1] - ix->h_post_off[t];
@@ -717,19 +737,17 @@ rebuild_impacts(nxsgpu_index_t *ix)
 		std::sort(ix->dense_terms.begin(), ix->dense_terms.end());
 		const uint64_t words = (uint64_t)ix->dense_terms.size() * ix->n_docs;
 		if (words > ix->dense_cap || (!words && ix->dense_cap)) {
-			(void)hipFree(ix->d_dense_col[0]);
-			(void)hipFree(ix->d_dense_col[1]);
-			ix->d_dense_col[0] = ix->d_dense_col[1] = NULL;
+			(void)hipFree(ix->d_dense_col[NXSGPU_BM25]);
+			ix->d_dense_col[NXSGPU_BM25] = NULL;
 			ix->dense_cap = 0;
 			if (words) {
 				const uint64_t cap = words + words / 16 + 1024;
-				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[0], cap * 4));
-				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[1], cap * 4));
+				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[NXSGPU_BM25], cap * 4));
 				ix->dense_cap = cap;
 			}
 		}
 		if (words) {
-			for (int a = 0; a < 2; a++) {
+			for (int a = NXSGPU_BM25; a == NXSGPU_BM25; a = -1) {
 				HIP_TRY(hipMemsetAsync(ix->d_dense_col[a], 0xff, words * 4, ix->stream));
 				for (size_t c = 0; c < ix->dense_terms.size(); c++) {
 					const uint32_t t = ix->dense_terms[c];
@@ -751,6 +769,43 @@ fail:
 	return rc;
 }
 
+
+/*
+ * An index has ONE default ranking function (params.db "algo"); the other one's
+ * impacts (8 B per posting: 2.6 GB at 10M docs) are computed on the first search
+ * that names it: one k_impacts_csr pass into a new array, beside whatever batches
+ * are in flight (nothing they read is touched).
+ */
+int
+ensure_algo(nxsgpu_index_t *ix, int algo)
+{
+	if (algo != NXSGPU_BM25 && algo != NXSGPU_TF_IDF) {
+		set_error("invalid algorithm");
+		return -1;
+	}
+	if (ix->algo_on[algo]) {
+		return 0;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	const uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(ix->cap_post, ix->n_post), 1);
+	if (hipMalloc(&ix->d_post[algo], cap * sizeof(posting_t)) != hipSuccess) {
+		ix->d_post[algo] = NULL;
+		set_error("hipMalloc(%llu) for the impacts of ranking function %d failed",
+		    (unsigned long long)(cap * sizeof(posting_t)), algo);
+		return -1;
+	}
+	ix->algo_on[algo] = true;
+	if (rebuild_impacts(ix, 1u << algo) != 0) {
+		(void)hipFree(ix->d_post[algo]);
+		ix->d_post[algo] = NULL;
+		ix->algo_on[algo] = false;
+		return -1;
+	}
+	return 0;
+}
 
 extern "C" nxsgpu_index_t *
 nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
@@ -836,8 +891,13 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipMalloc(&ix->d_doc_len, ix->cap_docs_len * 4));
 	HIP_TRY(hipMalloc(&ix->d_post_off, ((size_t)T + 2) * 8));
 	HIP_TRY(hipMalloc(&ix->d_post_dt, std::max<uint64_t>(P, 1) * 8));
-	HIP_TRY(hipMalloc(&ix->d_post[0], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
-	HIP_TRY(hipMalloc(&ix->d_post[1], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
+	for (int a = 0; a < 2; a++) {
+		/* (the other ranking function's impacts: on its first search, ensure_algo) */
+		ix->algo_on[a] = src->default_algo < 0 || src->default_algo == a;
+		if (ix->algo_on[a]) {
+			HIP_TRY(hipMalloc(&ix->d_post[a], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
+		}
+	}
 	ix->h_post_off.assign((size_t)T + 2, 0);
 
 	if (D) {
@@ -1168,8 +1228,11 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			(void)hipFree(ix->d_post[1]);
 			ix->d_post[0] = ix->d_post[1] = NULL;
 			ix->cap_post = P_new + P_new / 16 + 4096;
-			HIP_TRY(hipMalloc(&ix->d_post[0], ix->cap_post * sizeof(posting_t)));
-			HIP_TRY(hipMalloc(&ix->d_post[1], ix->cap_post * sizeof(posting_t)));
+			for (int a = 0; a < 2; a++) {
+				if (ix->algo_on[a]) {
+					HIP_TRY(hipMalloc(&ix->d_post[a], ix->cap_post * sizeof(posting_t)));
+				}
+			}
 		}
 	}
 	if (rebuild_impacts(ix) != 0) {
@@ -1367,9 +1430,9 @@ nxsgpu_hbm_calibrate(nxsgpu_index_t *ix, uint64_t *bytes_out)
 	}
 	(void)hipMemsetAsync(d_sink, 0, 4, ix->stream);
 	hipLaunchKernelGGL(k_hbm_read, dim3(256 * 16), dim3(256), 0, ix->stream,
-	    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+	    (const v4u_t *)ix->d_post_dt, bytes / 16, d_sink);
 	hipLaunchKernelGGL(k_hbm_read_x2, dim3(256 * 16), dim3(256), 0, ix->stream,
-	    (const uint2 *)ix->d_post[NXSGPU_TF_IDF], bytes / 8, d_sink);
+	    (const uint2 *)ix->d_post_dt, bytes / 8, d_sink);
 	(void)hipStreamSynchronize(ix->stream);
 	(void)hipFree(d_sink);
 	return 0;
@@ -1420,7 +1483,7 @@ warm_streams(nxsgpu_index_t *ix)
 	for (int round = 0; round < 3; round++) {
 		for (hipStream_t s : st) {
 			hipLaunchKernelGGL(k_stream_warm, dim3(1024), dim3(256), 0, s,
-			    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+			    (const v4u_t *)ix->d_post_dt, bytes / 16, d_sink);
 		}
 		if (h_buf && d_buf) {
 			(void)hipMemcpyAsync(d_buf, h_buf, cb, hipMemcpyHostToDevice, ix->stream_up);
@@ -1450,7 +1513,7 @@ warm_streams(nxsgpu_index_t *ix)
 			}
 			if ((i & 63) == 63) {
 				hipLaunchKernelGGL(k_stream_warm, dim3(64), dim3(256), 0, sb,
-				    (const v4u_t *)ix->d_post[NXSGPU_BM25], (uint64_t)4096, d_sink);
+				    (const v4u_t *)ix->d_post_dt, (uint64_t)4096, d_sink);
 			}
 		}
 		for (hipStream_t s2 : st) {
@@ -1492,7 +1555,7 @@ nxsgpu_hbm_read_gbs(nxsgpu_index_t *ix, int reps)
 		float ms = 0;
 		(void)hipEventRecord(e0, ix->stream);
 		hipLaunchKernelGGL(k_hbm_read, dim3(256 * 16), dim3(256), 0, ix->stream,
-		    (const v4u_t *)ix->d_post[NXSGPU_BM25], bytes / 16, d_sink);
+		    (const v4u_t *)ix->d_post_dt, bytes / 16, d_sink);
 		(void)hipEventRecord(e1, ix->stream);
 		if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
 			break;

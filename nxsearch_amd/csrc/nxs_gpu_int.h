@@ -194,7 +194,8 @@ struct nxsgpu_index {
 	uint64_t	cap_post;	/* capacity of d_post[*] */
 	uint64_t	cap_docs_ids, cap_docs_len;
 	uint32_t	max_tf;
-	posting_t *	d_post[2];	/* [P] per ranking algo */
+	posting_t *	d_post[2];	/* [P] per ranking algo; NULL until the algo is first used (algo_on) */
+	bool		algo_on[2];	/* impacts of this ranking function are materialised */
 	std::vector<uint64_t> h_post_off;
 	std::vector<float> h_maximp[2];	/* [T+2] largest impact per term and ranking algo */
 	std::vector<uint32_t> df_global;	/* [T+2] doc-sharded mode: collection-wide df, else empty */
@@ -388,7 +389,9 @@ void *	xbuf_get(nxsgpu_index_t *ix, int which, size_t need);
 void	xbuf_put(nxsgpu_index_t *ix, int which);
 bool	ensure_ws(nxsgpu_index_t *ix, size_t need);
 bool	ensure_pin(nxsgpu_index_t *ix, size_t need);
-int	rebuild_impacts(nxsgpu_index_t *ix);
+int	rebuild_impacts(nxsgpu_index_t *ix, unsigned only = 3);	/* bit a: ranking function a */
+/* materialise the impacts of `algo` (first search with the non-default function) */
+int	ensure_algo(nxsgpu_index_t *ix, int algo);
 void	warm_streams(nxsgpu_index_t *ix);
 
 /* ---- nxs_gpu_fuzzy.hip ---- */

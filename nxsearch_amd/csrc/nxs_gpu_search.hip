@@ -586,6 +586,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		set_error("hipSetDevice failed");
 		return -1;
 	}
+	if (ensure_algo(ix, algo) != 0) {
+		return -1;
+	}
 	if (res) {
 		memset(res, 0, sizeof(*res));
 		res->n_queries = nq;
@@ -1129,6 +1132,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	if (hipSetDevice(ix->device) != hipSuccess) {
 		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (ensure_algo(ix, algo) != 0) {
 		return -1;
 	}
 	for (int i = 0; i < 2; i++) {

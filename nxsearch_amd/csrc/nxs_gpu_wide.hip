@@ -240,6 +240,9 @@ nxsgpu_search_wide(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_wi
 		set_error("hipSetDevice failed");
 		return -1;
 	}
+	if (ensure_algo(ix, algo) != 0) {
+		return -1;
+	}
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + WTILE - 1) / WTILE);
 	for (uint32_t i = 0; i < nq; i++) {
 		const nxsgpu_wide_query_t &q = queries[i];

@@ -760,6 +760,7 @@ nxs_index_load(nxs_index_t *idx, const char *terms_path, const char *dtmap_path)
 		src.bk_depth = bk.depth;
 		src.bk_bytes = bk.bytes;
 		src.bk_bytes_len = bk.bytes_len;
+		src.default_algo = idx->algo;	/* the other ranking function's impacts: on first use */
 
 		idx->device = idx->want_device ? idx->want_device - 1 : dev_env ? atoi(dev_env) : 0;
 		idx->dev = nxsgpu_index_create(idx->device, &src);

@@ -188,6 +188,13 @@ uint64_t	nxsgpu_index_docs(const nxsgpu_index_t *);
 /* first live doc (file order) whose block names an unknown term, or ~0 */
 uint64_t	nxsgpu_index_first_bad_doc(const nxsgpu_index_t *);
 
+/*
+ * Threading: an nxsgpu_index_t belongs to ONE host thread at a time, like the
+ * reference's nxs_t (docs/c-api.md:5-8).  A blocking nxsgpu_search() while batches
+ * are in flight runs on stream and event sets of its own (it swaps them into the
+ * index for the call): another thread calling into the same index meanwhile would
+ * enqueue on the wrong streams.
+ */
 int		nxsgpu_search(nxsgpu_index_t *, int algo, uint64_t limit,
 		    const nxsgpu_query_t *queries, uint32_t n_queries,
 		    nxsgpu_results_t *res);

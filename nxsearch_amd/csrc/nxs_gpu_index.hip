@@ -1175,8 +1175,11 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			set_error("sort failed");
 			goto fail;
 		}
-		HIP_TRY(hipStreamSynchronize(ix->stream));
-		(void)hipFree(tmp2);
+		{
+			const hipError_t se = hipStreamSynchronize(ix->stream);
+			(void)hipFree(tmp2);
+			HIP_TRY(se);
+		}
 		/* a posting that was not found would corrupt the merge */
 		uint64_t last = 0;
 		HIP_TRY(hipMemcpy(&last, d_dead_sorted + (n_dead - 1), 8, hipMemcpyDeviceToHost));

@@ -477,9 +477,16 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 		}
 		for (uint32_t t = 0; t < d.nt; t++) {
 			const uint32_t tid = q.term_id[t];
-			if (tid == 0 || tid > ix->n_terms) {
+			if (tid == 0) {
 				set_error("query %u: bad term id %u", i, tid);
 				return -1;
+			}
+			if (tid > ix->n_terms) {
+				/* a term the host dictionary has consumed but whose docs this snapshot
+				 * does not hold yet (a refresh that stopped half way: partial sync,
+				 * dtmap.c:527-535): no postings, like the reference's empty bitmap */
+				d.pbeg[t] = d.pend[t] = 0;
+				continue;
 			}
 			d.pbeg[t] = ix->h_post_off[tid];
 			d.pend[t] = ix->h_post_off[tid + 1];
@@ -827,13 +834,22 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		uint32_t *dx_bnd_q = carve<uint32_t>(mp, xseg + nx);
 		uint32_t *dx_cursors = carve<uint32_t>(mp, (xseg + nx) * NXSGPU_MAX_TOKENS);
 
+		/* every failure of the pass leaves through here: nothing queued may still
+		 * reference the buffers, and an oversized one is not kept */
+		auto exact_fail = [&]() -> int {
+			(void)hipStreamSynchronize(ix->stream);
+			(void)hipGetLastError();
+			xbuf_put(ix, 0);
+			xbuf_put(ix, 1);
+			return -1;
+		};
 		/* pass 1: count */
 		if (hipMemcpyAsync(dx_q, xhq.data(), nx * sizeof(dev_query_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(dx_qmeta, xwl.qmeta.data(), nx * sizeof(qmeta_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(dx_items, xwl.items.data(), xseg * sizeof(item_t), hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
 		    hipMemcpyAsync(dx_bnd_q, xwl.bnd_q.data(), (xseg + nx) * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
 			set_error("query upload failed");
-			return -1;
+			return exact_fail();
 		}
 		sa.queries = dx_q;
 		sa.qmeta = dx_qmeta;
@@ -846,7 +862,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		if (hipMemcpyAsync(sc_cnt.data(), dx_seg_count, xseg * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
 		    hipStreamSynchronize(ix->stream) != hipSuccess) {
 			set_error("count pass failed: %s", hipGetErrorString(hipGetLastError()));
-			return -1;
+			return exact_fail();
 		}
 		for (uint64_t sgi = 0; sgi < xseg; sgi++) {
 			sc_off[sgi + 1] = sc_off[sgi] + sc_cnt[sgi];
@@ -862,7 +878,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		xneed = 8192 + (xseg + 1) * 8 + tot_c * 8 + tot_o * 8 * 2 + tot_o * 12 + (nx + 1) * 16 + nx * 4;
 		if ((xws = xbuf_get(ix, 1, xneed)) == NULL) {
 			set_error("hipMalloc(%zu) for the exact pass failed", xneed);
-			return -1;
+			return exact_fail();
 		}
 		xp = (uint8_t *)xws;
 		uint64_t *dx_seg_off = carve<uint64_t>(xp, xseg + 1);

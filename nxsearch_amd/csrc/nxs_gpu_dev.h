@@ -497,4 +497,75 @@ bigk_update_every(uint32_t k)
 	return max(k >> 4, 32u);
 }
 
+/* the 64 lanes' values, sorted descending across the lanes (bitonic network) */
+static __device__ __forceinline__ float
+wave_sort_desc(float v)
+{
+	const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+	for (unsigned k2 = 2; k2 <= WAVE; k2 <<= 1) {
+#pragma unroll
+		for (unsigned j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+			const float o = __shfl_xor(v, (int)j2);
+			const bool desc = (lane & k2) == 0, lower = (lane & j2) == 0;
+			v = (lower == desc) ? fmaxf(v, o) : fminf(v, o);
+		}
+	}
+	return v;
+}
+
+/*
+ * Threshold hand-down for limits > 64.  One range's own k-th best is a weak hint
+ * when k is large (the best 1000 of the ~5000 matches of a range: its top fifth),
+ * but the heap root while range g is fed is at least the k-th best of ALL higher
+ * docs together.  A finished range therefore publishes lower bounds c_j of its
+ * ceil(k / 2^j)-th best score, j = 0..5 (read off its histogram); if 2^j
+ * DIFFERENT higher ranges each hold ceil(k / 2^j) docs scoring >= v, the docs
+ * above range g hold k such docs and the root is >= v.  Every lane takes the
+ * largest c_j over its own subset of the higher ranges (disjoint subsets:
+ * different ranges), the 64 lane values are sorted, and the 2^j-th largest is
+ * such a v.  The hint is the best over j.  Stale or partial reads only weaken it.
+ */
+#define	BIGK_SK		6
+
+__device__ static inline float
+bigk_hint(const scan_args_t &A, const qmeta_t &qm, uint32_t g)
+{
+	const unsigned lane = threadIdx.x & 63;
+	float m[BIGK_SK], h = 0.0f;
+
+#pragma unroll
+	for (int j = 0; j < BIGK_SK; j++) {
+		m[j] = 0.0f;
+	}
+	for (uint32_t g2 = g + 1 + lane; g2 < qm.n_groups; g2 += WAVE) {
+		const float *p = A.pub_sk + ((uint64_t)qm.seg_first + g2) * 8;
+#pragma unroll
+		for (int j = 0; j < BIGK_SK; j++) {
+			m[j] = fmaxf(m[j], __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		}
+	}
+	if (g + 1 >= qm.n_groups) {
+		return 0.0f;		/* the top range: nothing above it */
+	}
+#pragma unroll
+	for (int j = 0; j < BIGK_SK; j++) {
+		const float s = wave_sort_desc(m[j]);
+		h = fmaxf(h, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), (1 << j) - 1)));
+	}
+	return h;
+}
+
+__device__ static inline void
+bigk_publish(const scan_args_t &A, uint64_t seg, const uint32_t *hist, uint32_t k)
+{
+#pragma unroll
+	for (int j = 0; j < BIGK_SK; j++) {
+		const float c = bigk_threshold(hist, (k + (1u << j) - 1) >> j);
+		if ((threadIdx.x & 63) == 0 && c > 0.0f) {
+			__hip_atomic_store(A.pub_sk + seg * 8 + j, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
 #endif /* NXS_GPU_DEV_H */

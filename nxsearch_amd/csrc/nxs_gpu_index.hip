@@ -75,7 +75,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.seg_cap = (uint32_t)u64("NXS_GPU_SEGCAP", SEG_CAP_DEFAULT, 1, 1u << 16);
 	c.scan1_split = (uint32_t)u64("NXS_GPU_SCAN1_SPLIT", 64, 1, 1u << 30);
 	c.seg_cap_big = (uint32_t)u64("NXS_GPU_SEGCAP_BIG", 0, 0, 1u << 20);
-	c.big_minpost = u64("NXS_GPU_BIG_MINPOST", 32, 0, 1u << 20);
+	c.big_minpost = u64("NXS_GPU_BIG_MINPOST", 16, 0, 1u << 20);
 	c.fuzzy_items = u64("NXS_GPU_FUZZY_ITEMS", 256ull << 20, 1, 1ull << 32);
 	c.use_scanr = !on("NXS_GPU_NOSCANR");
 	c.no_step = on("NXS_GPU_NOSTEP");

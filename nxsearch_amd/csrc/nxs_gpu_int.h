@@ -283,6 +283,8 @@ struct scan_args_t {
 	float *			cand_sc;
 	uint32_t *		overflow;	/* [Q] */
 	float *			pub;		/* [segments] k-th best score of a finished range (0 = none) */
+	float *			pub_sk;		/* MODE_BIG: [segments][8] lower bounds of a finished range's ceil(k / 2^j)-th
+						 * best score, j = 0..5 (bigk_publish / bigk_hint) */
 	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class);
 						 * bit 1 (k_scan8): the work items are the retry list's */
 	/*

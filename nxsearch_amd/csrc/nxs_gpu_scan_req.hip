@@ -98,7 +98,8 @@ k_scan1(const scan_args_t A)
 	}
 
 	float top = -INFINITY;
-	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
+	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
+	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
@@ -165,7 +166,7 @@ k_scan1(const scan_args_t A)
 	}
 	if constexpr (MODE == MODE_BIG) {
 		if (!ovf) {
-			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
 		}
 	}
 	if (lane == 0) {
@@ -346,7 +347,8 @@ k_scanr(const scan_args_t A)
 	});
 
 	float top = -INFINITY;
-	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
+	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
+	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
@@ -573,7 +575,7 @@ k_scanr(const scan_args_t A)
 	}
 	if constexpr (MODE == MODE_BIG) {
 		if (!ovf) {
-			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
 		}
 	}
 	if (lane == 0) {
@@ -706,7 +708,8 @@ k_scanh(const scan_args_t A)
 	}
 
 	float top = -INFINITY;
-	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
+	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
+	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
@@ -917,7 +920,7 @@ k_scanh(const scan_args_t A)
 	}
 	if constexpr (MODE == MODE_BIG) {
 		if (!ovf) {
-			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
 		}
 	}
 	if (lane == 0) {

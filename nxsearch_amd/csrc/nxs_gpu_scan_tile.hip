@@ -67,7 +67,8 @@ k_scan(const scan_args_t A)
 	 * i-th largest; thr = k-th largest (or -inf).  Everything the global
 	 * heap replay could accept is > thr (see DESIGN.md "candidate filter"). */
 	float top = -INFINITY;
-	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
+	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
+	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
@@ -258,7 +259,7 @@ k_scan(const scan_args_t A)
 	}
 	if constexpr (MODE == MODE_BIG) {
 		if (!ovf) {
-			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
 		}
 	}
 	if (lane == 0) {
@@ -496,7 +497,8 @@ k_scan8(const scan_args_t A)
 	});
 
 	float top = -INFINITY;
-	const float hint = ((MODE == MODE_TOPK && A.k <= WAVE) || MODE == MODE_BIG) ? range_hint(A, qm, g) : -INFINITY;
+	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
+	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
 	float thr = hint;
 	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
 	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
@@ -507,6 +509,7 @@ k_scan8(const scan_args_t A)
 	bool ovf = false;
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
 
+	uint32_t tile_no = 0;
 	for (;;) {
 		int32_t md = -1, rq = 0x7fffffff;
 #pragma unroll
@@ -518,6 +521,14 @@ k_scan8(const scan_args_t A)
 		}
 		if (md < 0 || rq < 0) {
 			break;		/* all consumed, or a required term ran out */
+		}
+		if constexpr (MODE == MODE_BIG) {
+			/* limits > 64: ranges are long (>= 32 x limit postings) and higher ranges
+			 * finish meanwhile: look at what they have published every 64 tiles */
+			if ((++tile_no & 63) == 0) {
+				hint = fmaxf(hint, bigk_hint(A, qm, g));
+				thr = fmaxf(thr, hint);
+			}
 		}
 		const uint32_t base = ((uint32_t)(req ? rq : md) / TILE_W) * TILE_W;
 
@@ -913,7 +924,7 @@ k_scan8(const scan_args_t A)
 	}
 	if constexpr (MODE == MODE_BIG) {
 		if (!ovf) {
-			range_publish(A, seg, bigk_threshold(s_hist, A.k));	/* a lower bound of this range's k-th best */
+			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
 		}
 	}
 	if (lane == 0) {

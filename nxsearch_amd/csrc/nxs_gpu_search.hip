@@ -637,7 +637,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 		    + nseg * sizeof(item_t) + nseg * 4 + nq * 4
 		    + (nseg + nq) * 4 * (1 + NXSGPU_MAX_TOKENS) + nseg * 4 + 1024
 		    + nseg * seg_cap * 8 + (size_t)nq * kfast * 12 + nq * 4 + 16 * 256
-		    + nseg * (16 * 4 + 64 * 4) + 1024 + RETRY_LISTS * (4 + RETRY_CAP * sizeof(item_t)) + 1024;
+		    + nseg * (16 * 4 + 64 * 4) + 1024 + RETRY_LISTS * (4 + RETRY_CAP * sizeof(item_t)) + 1024
+		    + (big ? nseg * 32 + 256 : 0);
 		if (!ensure_ws(ix, need)) {
 			return -1;
 		}
@@ -672,6 +673,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
 	float *d_cold_top = carve<float>(p, nseg * 64);
 	item_t *d_retry_items = carve<item_t>(p, RETRY_LISTS * RETRY_CAP);
+	float *d_pub_sk = carve<float>(p, big ? nseg * 8 : 0);
 
 	if (!ensure_pin(ix, up_len + down_len + 512)) {
 		return -1;
@@ -710,6 +712,11 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.cold_top = d_cold_top;
 	sa.retry_count = d_retry_cnt;
 	sa.retry_items = d_retry_items;
+	sa.pub_sk = d_pub_sk;
+	if (big && hipMemsetAsync(d_pub_sk, 0, nseg * 32, ix->stream) != hipSuccess) {
+		set_error("memset failed");
+		return -1;
+	}
 
 	h_ovf.assign(nq, 0);
 	if (fast) {
@@ -1330,7 +1337,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * offsets), then what only the kernels touch */
 	const size_t ws_need = 32768 + up_len + nseg * 4
 	    + (nseg + nq) * 4 * NXSGPU_MAX_TOKENS + nseg * (size_t)seg_cap * 8 + nseg * (16 * 4 + 64 * 4)
-	    + RETRY_LISTS * RETRY_CAP * sizeof(item_t) + 1024;
+	    + RETRY_LISTS * RETRY_CAP * sizeof(item_t) + 1024 + (big ? nseg * 32 + 256 : 0);
 	if (slot_ensure(*sl, ws_need, 0) != 0) {
 		return -1;
 	}
@@ -1352,6 +1359,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *d_cold_state = carve<uint32_t>(p, nseg * 16);
 	float *d_cold_top = carve<float>(p, nseg * 64);
 	item_t *d_retry_items = carve<item_t>(p, RETRY_LISTS * RETRY_CAP);
+	float *d_pub_sk = carve<float>(p, big ? nseg * 8 : 0);
 	if (block_on_host) {
 		d_myblock = sl->h_blocks_dev;
 	} else if (o.records && !block_in_ws) {
@@ -1396,6 +1404,11 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.cold_top = d_cold_top;
 	sa.retry_count = d_retry_cnt;
 	sa.retry_items = d_retry_items;
+	sa.pub_sk = d_pub_sk;
+	if (big && nseg && hipMemsetAsync(d_pub_sk, 0, nseg * 32, s_up) != hipSuccess) {
+		set_error("memset failed");
+		return begin_fail(ix);
+	}
 	memset(&ra, 0, sizeof(ra));
 	ra.flags = ix->cfg.old_replay ? 1u : 0u;
 	ra.qmeta = d_qmeta;

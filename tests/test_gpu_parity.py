@@ -471,7 +471,9 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
-                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"}])
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 # single-token classes: every query's top range in a launch of its own
+                                 {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by

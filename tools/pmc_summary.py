@@ -116,7 +116,7 @@ def main():
 
     def scan_total(cname):
         return sum(v[cname]["sum_per_step"] for k, v in counters.items()
-                   if k.startswith("k_scan") and cname in v)
+                   if (k.startswith("k_scan") or k.startswith("k_cold")) and cname in v)
 
     fetch_kb, write_kb = scan_total("FETCH_SIZE"), scan_total("WRITE_SIZE")
     factor, factor_src = 2.0, "MI355X_MICROARCH.md (16 B/lane streaming reads), unverified for 8 B/lane"
@@ -129,7 +129,7 @@ def main():
         "fetch_size_calibration": calib,
         "fetch_size_factor": factor,
         "fetch_size_factor_source": factor_src,
-        "kernel": "k_scan* (all query-class launches of one step summed)",
+        "kernel": "k_scan* + k_cold (all query-class launches of one step summed)",
         "steps_profiled": a.steps,
         "FETCH_SIZE_KB_per_step": fetch_kb,
         "WRITE_SIZE_KB_per_step": write_kb,

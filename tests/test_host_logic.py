@@ -72,6 +72,21 @@ def test_params_fromjson_is_what_the_lua_binding_needs(tmp_path):
             assert code == 2 and msg.startswith("params parsing failed: "), (bad, code, msg)
 
 
+@pytest.mark.timeout(120)
+def test_worker_pool_hands_every_item_out_exactly_once():
+    """The front half of a batch (parse, resolve, compile) runs on a worker pool
+    whose runs wait for their ITEMS, not for their slowest sleeper: a thread that
+    wakes up late must neither take items of the next run away nor work on stale
+    ones.  Thousands of back-to-back runs with more threads than cores."""
+    L = N.lib()
+    L.nxs_test_pool.restype = C.c_size_t
+    L.nxs_test_pool.argtypes = [C.c_uint, C.c_size_t, C.c_uint, C.c_size_t]
+    assert L.nxs_test_pool(15, 1024, 3000, 16) == 0
+    assert L.nxs_test_pool(31, 100, 3000, 1) == 0
+    assert L.nxs_test_pool(3, 5000, 300, 32) == 0
+    assert L.nxs_test_pool(0, 64, 10, 16) == 0
+
+
 def test_no_gpu_means_loud_failure(tmp_path):
     if N.lib().nxsgpu_device_count() > 0:
         pytest.skip("a GPU is present")

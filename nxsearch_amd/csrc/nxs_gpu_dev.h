@@ -400,9 +400,13 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
  * are not counted: the bound only gets weaker, never wrong.  Candidates = what
  * beats the edge; the replay applies the exact test.
  */
-#define	BIGK_BUCKETS	512
-#define	BIGK_SH		18
-#define	BIGK_BASE	((127 - 7) << 5)
+#ifndef BIGK_OCT_BITS
+#define	BIGK_OCT_BITS	5		/* log2(buckets per octave) */
+#endif
+#define	BIGK_BUCKETS	(16 << BIGK_OCT_BITS)	/* 16 octaves: 2^-7 .. 2^9 */
+#define	BIGK_SH		(23 - BIGK_OCT_BITS)
+#define	BIGK_BASE	((127 - 7) << BIGK_OCT_BITS)
+#define	BIGK_PER_LANE	(BIGK_BUCKETS / WAVE)
 
 static __device__ __forceinline__ uint32_t
 bigk_bucket(float s)
@@ -440,12 +444,15 @@ bigk_threshold(const uint32_t *hist, uint32_t k)
 	/* one wavefront's DS operations execute in issue order: the atomics above
 	 * are visible; this only keeps the compiler from moving the reads up */
 	asm volatile("" ::: "memory");
-	const uint4 lo4 = *(const uint4 *)&hist[lane * 8];
-	const uint4 hi4 = *(const uint4 *)&hist[lane * 8 + 4];
-	const uint32_t c[8] = { lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w };
+	uint32_t c[BIGK_PER_LANE];
 	uint32_t own = 0;
 #pragma unroll
-	for (int i = 0; i < 8; i++) {
+	for (int i = 0; i < BIGK_PER_LANE; i += 4) {
+		const uint4 q4 = *(const uint4 *)&hist[lane * BIGK_PER_LANE + i];
+		c[i] = q4.x; c[i + 1] = q4.y; c[i + 2] = q4.z; c[i + 3] = q4.w;
+	}
+#pragma unroll
+	for (int i = 0; i < BIGK_PER_LANE; i++) {
 		own += c[i];
 	}
 	uint32_t suf = own;
@@ -464,10 +471,10 @@ bigk_threshold(const uint32_t *hist, uint32_t k)
 	uint32_t acc = suf - own, j = 0;
 	bool found = false;
 #pragma unroll
-	for (int i = 7; i >= 0; i--) {
+	for (int i = BIGK_PER_LANE - 1; i >= 0; i--) {
 		acc += c[i];
 		if (!found && acc >= k) {
-			j = lane * 8 + i;
+			j = lane * BIGK_PER_LANE + i;
 			found = true;
 		}
 	}

@@ -392,8 +392,8 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
  * needs a value that is NEVER ABOVE that root: any lower bound of the k-th
  * largest score among the docs this wavefront has emitted will do (they were
  * all fed before the doc being tested).  A histogram gives one without keeping
- * k scores: bucket(s) = the top bits of the float (sign 0, exponent, 5 mantissa
- * bits: 32 buckets per octave, 2^-7 .. 2^9, clamped) is monotone in s, so if the
+ * k scores: bucket(s) = the top bits of the float (sign 0, exponent, 4 mantissa
+ * bits: 16 buckets per octave, 2^-7 .. 2^9, clamped) is monotone in s, so if the
  * buckets >= j together hold >= k emitted docs, the k-th largest emitted score
  * is >= the lower edge of bucket j -- exactly representable, no rounding
  * argument needed.  Docs that were not emitted (score <= an earlier threshold)
@@ -401,7 +401,7 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
  * beats the edge; the replay applies the exact test.
  */
 #ifndef BIGK_OCT_BITS
-#define	BIGK_OCT_BITS	5		/* log2(buckets per octave) */
+#define	BIGK_OCT_BITS	4		/* log2(buckets per octave): 16 (32: 2 KB of LDS, -2 % on a default-limit batch) */
 #endif
 #define	BIGK_BUCKETS	(16 << BIGK_OCT_BITS)	/* 16 octaves: 2^-7 .. 2^9 */
 #define	BIGK_SH		(23 - BIGK_OCT_BITS)
@@ -433,7 +433,7 @@ bigk_note(uint32_t *hist, bool cand, float sc)
 
 /*
  * Largest bucket edge with >= k counted docs at or above it (0 if there is none).
- * Lane L owns buckets [8L, 8L + 8): its sum, a suffix sum over the lanes, the
+ * Lane L owns BIGK_PER_LANE consecutive buckets: its sum, a suffix sum over the lanes, the
  * highest lane whose suffix reaches k, then that lane's own eight counters.
  * Wave-uniform result.
  */

@@ -454,7 +454,12 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 	for (uint32_t i = 0; i < nq; i++) {
 		const nxsgpu_query_t &q = queries[i];
 		dev_query_t &d = hq[i];
-		memset(&d, 0, sizeof(d));
+		/* (not the whole 900 bytes: posting ranges beyond the query's tokens and program
+		 * bytes beyond prog_len are never read -- 0.7 MB less to write per 1024 queries) */
+		d.nt = d.prog_len = 0;
+		memset(d.pbeg, 0, 8 * sizeof(d.pbeg[0]));
+		memset(d.pend, 0, 8 * sizeof(d.pend[0]));
+		memset(d.truth, 0, offsetof(dev_query_t, prog) - offsetof(dev_query_t, truth));
 		if (q.n_tokens > NXSGPU_MAX_TOKENS || q.prog_len > NXSGPU_MAX_PROG) {
 			set_error("query %u exceeds the device limits", i);
 			return -1;

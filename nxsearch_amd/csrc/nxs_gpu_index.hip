@@ -850,24 +850,27 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	 * the step takes 1.7: some serialisation helps) decides the order here:
 	 *   queue A: stream (scans), stream2 (replays of a class: short), stream_fz
 	 *   queue B: stream3 (dense-term class; limits > 64: replays of batch slot 0),
-	 *            xstream[0], stream_down (record blocks: sharded runs only)
+	 *            xstream[0], xstream[2]
 	 *   queue C: stream_up (uploads + k_cursors of the NEXT batch), xstream[1]
-	 *   queue D: stream_rp[1] (limits > 64: replays of batch slot 1), xstream[2]
+	 *   queue D: stream_rp[1] (limits > 64: replays of batch slot 1), stream_down (record
+	 *            blocks of a sharded batch: all-gather + copy, beside the next batch)
 	 */
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_up, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_rp[1], hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
-	for (int i = 0; i < 3; i++) {
-		HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[i], hipStreamNonBlocking));
-	}
+	HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[0], hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[1], hipStreamNonBlocking));
+	/* (queue D: a sharded batch's all-gather waits there for the batch's last replay -- on
+	 * queue B it would hold up the NEXT batch's dense-term class, queued behind it) */
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
 	/* (at the highest stream priority the fuzzy passes finish sooner -- the host
 	 * waits 8-10 instead of 27-32 ms per C5 step for them -- but that wait is
 	 * hidden behind the device's 38 ms anyway, and the changed timing made one
 	 * query per step overflow its candidate lists: plain priority) */
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[2], hipStreamNonBlocking));
 	ix->stream_rp[0] = ix->stream3;		/* (the dense-term class does not exist for limits > 64) */
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));

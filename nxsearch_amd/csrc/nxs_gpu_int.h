@@ -12,6 +12,8 @@
  *  nxs_gpu_scan_mask.hip  k_scanm / k_cold: OR-like queries of sparse terms, a
  *                         quantised score bound per doc in LDS, exact sums only
  *                         for the docs that can beat the threshold
+ *  nxs_gpu_scan_grid.hip  k_scang: the mask path over a doc grid (all terms' postings of a
+ *                         part in one run of slots): opt-in alternative to k_scanm
  *  nxs_gpu_scan_req.hip   k_cursors, k_scan1 (one token), k_scanr (required
  *                         terms: intersect first)
  *  nxs_gpu_replay.hip     k_replay: the reference's capped min-heap + heapsort
@@ -124,6 +126,8 @@ struct gpu_cfg_t {
 	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */
 	bool		old_replay;	/* NXS_GPU_OLDREPLAY: the LDS heap on one lane (k_replay<HEAP_LDS>) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
+	bool		use_grid;	/* NXS_GPU_GRID: the mask path on the doc grid (k_scang) instead of register windows
+					 * (k_scanm) -- measured slower on C3, kept as a tested alternative */
 };
 
 void cfg_from_env(gpu_cfg_t &c);
@@ -286,7 +290,8 @@ struct scan_args_t {
 	float *			pub_sk;		/* MODE_BIG: [segments][8] lower bounds of a finished range's ceil(k / 2^j)-th
 						 * best score, j = 0..5 (bigk_publish / bigk_hint) */
 	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class);
-						 * bit 1 (k_scan8): the work items are the retry list's */
+						 * bit 1 (k_scan8): the work items are the retry list's;
+						 * bit 2: the mask path walks the doc grid (k_scang) */
 	/*
 	 * Ranges whose pending list overflowed on the mask path (k_scanm: a burst of docs
 	 * above a still-weak threshold -- it depends on when higher ranges publish theirs,
@@ -415,6 +420,8 @@ void	nxs_launch_scan_generic(int mode, bool wide_mask, unsigned grid, hipStream_
 void	nxs_launch_scan8(int mode, uint32_t nt_bucket, uint32_t mm, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
+/* the same two on the doc grid (k_scang; scan_args_t::flags bit 2 routes the launchers above here) */
+void	nxs_launch_scang(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanh(int mode, uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);

@@ -339,6 +339,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			continue;
 		}
 		a.item_base = l.first;
+		a.flags |= ix->cfg.use_grid && ix->n_post < (1ull << 32) ? 4u : 0u;	/* (k_scang: 32-bit posting indexes) */
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
 		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5);
@@ -362,7 +363,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
 				forked3 = true;
 			}
-			a.flags = ix->cfg.drop_prio ? 1u : 0u;
+			a.flags |= ix->cfg.drop_prio ? 1u : 0u;
 			nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
 			launch_retry(ix->stream3);
 			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);

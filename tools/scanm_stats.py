@@ -30,14 +30,21 @@ sets = {
 }
 L = N.lib()
 L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+L.nxsgpu_debug_stats_grid.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "-", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
 names = ["waves", "tiles", "visits", "flushes", "pending", "emitted", "flush_cyc", "wave_cyc", "tile_w_sum", "lanes_in_visits", "overflows", "reg_chunks", "deep_chunks"]
 for name, qs in sets.items():
     plans, errs = idx.plan_batch(qs, limit=k, fuzzymatch=False)
     idx.search_dev(plans, batch, k, N.BM25, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     out = (C.c_ulonglong * 16)()
     L.nxsgpu_debug_stats(out, 1)
+    L.nxsgpu_debug_stats_grid(out, 1)
     idx.search_dev(plans, batch, k, N.BM25, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     L.nxsgpu_debug_stats(out, 1)
     v = dict(zip(names, list(out)))
     w = max(v["waves"], 1)
     print(name, {n: round(v[n] / w, 1) for n in names[1:]}, "waves", v["waves"], flush=True)
+    L.nxsgpu_debug_stats_grid(out, 1)
+    v = dict(zip(gnames, list(out)))
+    w = max(v["waves"], 1)
+    print(name, "grid", {n: round(v[n] / w, 1) for n in gnames[1:] if n != "-"}, "waves", v["waves"], flush=True)

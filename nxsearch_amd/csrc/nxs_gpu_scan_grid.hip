@@ -34,20 +34,20 @@
 #include "nxs_gpu_int.h"
 #include "nxs_gpu_dev.h"
 
-#ifndef MT_W
-#define	MT_W		8192		/* docs per byte map (and widest part) */
+#ifndef GT_W
+#define	GT_W		8192		/* docs per byte map (and widest part); a power of two */
 #endif
+#define	MT_W		GT_W
 #define	MT_W0		64		/* cold-start sub-tile width */
-#ifndef MT_W_HINTED
-#define	MT_W_HINTED	2048
-#endif
+#define	MT_W_HINTED	(MT_W < 2048 ? MT_W : 2048)
 #define	PEND_CAP	128
 #ifndef DROP_PEND_MULT
 #define	DROP_PEND_MULT	1
 #endif
 #define	QSUM_MAX	224
 #ifndef GT_G
-#define	GT_G		8		/* groups of 64 postings a part may hold (registers) */
+#define	GT_G		6		/* groups of 64 postings a part may hold (registers: 8 = 108 VGPRs and four
+					 * wavefronts per SIMD, 6 = 90 and five; C3 1.42 -> 1.31 ms) */
 #endif
 #define	GT_CAP		(GT_G * WAVE)
 
@@ -71,7 +71,7 @@ nxsgpu_debug_stats_grid(unsigned long long *out, int reset)
 #define	STAT_CLK()	0ull
 #endif
 #ifndef GT_FILL
-#define	GT_FILL		320		/* postings per part the boundary stride aims at */
+#define	GT_FILL		260		/* postings per part the boundary stride aims at */
 #endif
 
 template <int NT, bool GEN, bool DROP = false>
@@ -165,8 +165,8 @@ k_scang(const scan_args_t A)
 		n_all += (uint32_t)(hi[t] - lo[t]);
 		maxlen = max(maxlen, (uint32_t)(hi[t] - lo[t]));
 	}
-	uint32_t bshift = 13;
-	static_assert(MT_W == 8192, "bshift starts at log2(MT_W)");
+	static_assert((MT_W & (MT_W - 1)) == 0 && MT_W >= 1024, "the byte map is a power of two");
+	uint32_t bshift = 31 - __builtin_clz((uint32_t)MT_W);
 	{
 		const uint64_t span = d_top > d_bot ? d_top - d_bot : 1;
 		while (bshift > 6 && ((uint64_t)n_all << bshift) > (uint64_t)GT_FILL * span) {
@@ -729,24 +729,38 @@ k_scang(const scan_args_t A)
 				}
 			}
 			const uint32_t n_tile = n_pend - n_before;
-			if (n_pend > PCAP) {
+			/*
+			 * More docs above the threshold than the pending list takes (a weak threshold
+			 * and a wide sub-tile): nothing is lost -- the part is still in registers and
+			 * the bytes are wiped -- so the same docs are walked again in narrower
+			 * sub-tiles.  (The list is empty at every sub-tile's start: n_before == 0.)
+			 */
+			const bool over = n_pend > PCAP;
+			const bool redo = over && tw > (uint32_t)MT_W0;
+			if (over && !redo) {
 				ovf = true;
-			} else if (n_pend) {
+			} else if (!over && n_pend) {
 				flush();
 			}
-			if (DROP && dropped) {
-				if (n_tile <= 36) {
+			if (redo) {
+				STAT_ADD(6, 1);
+				n_pend = 0;
+				tw = max(min(tw, width + 1) >> 2, (uint32_t)MT_W0);
+			} else {
+				if (DROP && dropped) {
+					if (n_tile <= 36) {
+						tw = min(tw * 2, (uint32_t)MT_W);
+					} else if (n_tile > 88) {
+						tw = max(tw / 2, (uint32_t)MT_W0);
+					}
+				} else
+				if (n_tile <= 8) {
 					tw = min(tw * 2, (uint32_t)MT_W);
-				} else if (n_tile > 88) {
+				} else if (n_tile > 48) {
 					tw = max(tw / 2, (uint32_t)MT_W0);
 				}
-			} else
-			if (n_tile <= 8) {
-				tw = min(tw * 2, (uint32_t)MT_W);
-			} else if (n_tile > 48) {
-				tw = max(tw / 2, (uint32_t)MT_W0);
+				se = (int32_t)sb - 1;
 			}
-			se = (int32_t)sb - 1;
 		}
 	}
 

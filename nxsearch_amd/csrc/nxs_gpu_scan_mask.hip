@@ -49,7 +49,19 @@
 #define	DROP_PEND_MULT	1		/* k_scanm<.., DROP>: pending list x1 (x2: -8 %, x4: -25 % on C3) */
 #endif
 #define	PEND_FLUSH	32		/* score the pending docs once this many wait */
-#define	QSUM_MAX	224		/* quantised score bound of a doc holding every term at its largest impact */
+/*
+ * MT_FOLD = 1: two neighbouring docs share a byte -- a tile covers twice the docs
+ * for the same LDS, at half the quantisation range (both docs' bounds must fit the
+ * byte together).  A byte is then an upper bound of EITHER doc's score bound: what
+ * the sibling adds can only make a doc a candidate that is not one (its exact
+ * score decides, as for every candidate), never hide one.
+ */
+#ifndef MT_FOLD
+#define	MT_FOLD		0
+#endif
+#define	MT_DOCS		(MT_W << MT_FOLD)	/* docs per tile */
+/* quantised score bound of a doc holding every term at its largest impact (+ 2 per term: <= 240, or 2 x 124) */
+#define	QSUM_MAX	(MT_FOLD ? 108 : 224)
 
 #ifdef NXS_STATS
 /* diagnostic build only (make variant XFLAGS=-DNXS_STATS): k_scanm event counts
@@ -606,7 +618,7 @@ k_scanm(const scan_args_t A)
 		auto visit = [&](auto tc, uint64_t inm, uint32_t wd, float wi) {
 			constexpr int t = decltype(tc)::value;
 			const bool inl = lane_of(inm);
-			const uint32_t dd = wd - base;
+			const uint32_t dd = (wd - base) >> MT_FOLD;
 			const uint32_t sh = (dd & 3) * 8;
 			const uint32_t w = inl ? (dd >> 2) : MT_W / 4 + lane;
 			/* floor + 2 >= the exact ceiling whatever the f32 product rounds to */
@@ -650,7 +662,7 @@ k_scanm(const scan_args_t A)
 		{
 			/* (wave-uniform trip count: a lane-dependent one makes the compiler
 			 * treat the enclosing loop's state as divergent) */
-			const uint32_t words = ((uint32_t)md - base + 4) >> 2;
+			const uint32_t words = ((((uint32_t)md - base) >> MT_FOLD) + 4) >> 2;
 			for (uint32_t i0 = 0; i0 < words; i0 += WAVE * 4) {
 				*(uint4 *)&s_mask[i0 + lane * 4] = make_uint4(0, 0, 0, 0);
 			}
@@ -673,13 +685,13 @@ k_scanm(const scan_args_t A)
 			/* pushes are cheap here (refined in parallel in the flush): as wide as
 			 * the pending list takes */
 			if (n_tile <= 36) {
-				tw = min(tw * 2, (uint32_t)MT_W);
+				tw = min(tw * 2, (uint32_t)MT_DOCS);
 			} else if (n_tile > 88) {
 				tw = max(tw / 2, (uint32_t)MT_W0);
 			}
 		} else
 		if (n_tile <= 8) {
-			tw = min(tw * 2, (uint32_t)MT_W);
+			tw = min(tw * 2, (uint32_t)MT_DOCS);
 		} else if (n_tile > 48) {
 			tw = max(tw / 2, (uint32_t)MT_W0);
 		}

@@ -339,7 +339,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			continue;
 		}
 		a.item_base = l.first;
-		a.flags |= ix->cfg.use_grid && ix->n_post < (1ull << 32) ? 4u : 0u;	/* (k_scang: 32-bit posting indexes) */
+		/* (k_scang: 32-bit posting indexes) */
+		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) ? 4u : 0u;
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
 		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5);

@@ -473,8 +473,8 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  # the mask path walked over a doc grid (k_scang), with and without dense terms leaving
-                                 {"NXS_GPU_GRID": "1"}, {"NXS_GPU_GRID": "1", "NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_GRID": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  # single-token classes: every query's top range in a launch of its own
                                  {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
@@ -504,7 +504,7 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
                                  {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
-                                 {"NXS_GPU_GRID": "1"}, {"NXS_GPU_GRID": "1", "NXS_GPU_DROP_MINPOST": "1"}])
+                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
     tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""

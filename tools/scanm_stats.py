@@ -31,7 +31,7 @@ sets = {
 L = N.lib()
 L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 L.nxsgpu_debug_stats_grid.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "-", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
+gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "redone", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
 names = ["waves", "tiles", "visits", "flushes", "pending", "emitted", "flush_cyc", "wave_cyc", "tile_w_sum", "lanes_in_visits", "overflows", "reg_chunks", "deep_chunks"]
 for name, qs in sets.items():
     plans, errs = idx.plan_batch(qs, limit=k, fuzzymatch=False)

@@ -40,8 +40,8 @@ for env in ({}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NX
             {"NXS_GPU_SCANM_DENS": "0.01", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
             {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
             {"NXS_GPU_NOSCANM": "1"},
-            {"NXS_GPU_GRID": "1"}, {"NXS_GPU_GRID": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "256"},
-            {"NXS_GPU_GRID": "1", "NXS_GPU_SCANM_DENS": "1.0"}):
+            {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "256"},
+            {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"}):
     if os.environ.get("STRESS_ONLY") and os.environ["STRESS_ONLY"] not in env:
         continue
     for kk, v in env.items():

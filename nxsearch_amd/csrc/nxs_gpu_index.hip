@@ -540,6 +540,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	(void)hipFree(ix->d_doc_len);
 	(void)hipFree(ix->d_post_off);
 	(void)hipFree(ix->d_post_dt);
+	(void)hipFree(ix->d_post_dt_spare);
 	(void)hipFree(ix->d_post[0]);
 	(void)hipFree(ix->d_post[1]);
 	(void)hipFree(ix->d_dense_col[0]);
@@ -894,12 +895,15 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipMalloc(&ix->d_doc_ids, ix->cap_docs_ids * 8));
 	HIP_TRY(hipMalloc(&ix->d_doc_len, ix->cap_docs_len * 4));
 	HIP_TRY(hipMalloc(&ix->d_post_off, ((size_t)T + 2) * 8));
-	HIP_TRY(hipMalloc(&ix->d_post_dt, std::max<uint64_t>(P, 1) * 8));
+	/* (room to grow: the first appended document must not pay for new arrays) */
+	ix->cap_post = P + P / 16 + 4096;
+	HIP_TRY(hipMalloc(&ix->d_post_dt, ix->cap_post * 8));
+	ix->cap_post_dt = ix->cap_post;
 	for (int a = 0; a < 2; a++) {
 		/* (the other ranking function's impacts: on its first search, ensure_algo) */
 		ix->algo_on[a] = src->default_algo < 0 || src->default_algo == a;
 		if (ix->algo_on[a]) {
-			HIP_TRY(hipMalloc(&ix->d_post[a], std::max<uint64_t>(P, 1) * sizeof(posting_t)));
+			HIP_TRY(hipMalloc(&ix->d_post[a], ix->cap_post * sizeof(posting_t)));
 		}
 	}
 	ix->h_post_off.assign((size_t)T + 2, 0);
@@ -970,7 +974,6 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 
 	ix->max_tf = h_max_tf;
-	ix->cap_post = std::max<uint64_t>(P, 1);
 	if (rebuild_impacts(ix) != 0) {
 		goto fail;
 	}
@@ -1196,7 +1199,18 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 		const uint64_t P_new = P_old - n_dead + n_newp;
 		const unsigned blocks = (unsigned)(((uint64_t)T_new + 2 + 255) / 256);
 
-		HIP_TRY(hipMalloc(&d_out, std::max<uint64_t>(P_new + P_new / 16 + 4096, 1) * 8));
+		/* the merge writes the other CSR buffer: kept between refreshes (a fresh 2.6 GB
+		 * hipMalloc at 10M docs costs more than the merge itself) */
+		uint64_t cap_out = ix->cap_post_dt_spare;
+		d_out = ix->d_post_dt_spare;
+		ix->d_post_dt_spare = NULL;
+		ix->cap_post_dt_spare = 0;
+		if (!d_out || cap_out < P_new) {
+			(void)hipFree(d_out);
+			d_out = NULL;
+			cap_out = P_new + P_new / 16 + 4096;
+			HIP_TRY(hipMalloc(&d_out, cap_out * 8));
+		}
 		hipLaunchKernelGGL(k_new_row_offsets, dim3(blocks), dim3(256), 0, ix->stream,
 		    ix->d_post_off, T_old, P_old, d_dead_sorted, n_dead, d_new_off, T_new, d_off_new);
 		if (P_old) {
@@ -1216,9 +1230,11 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			    (unsigned long long)ix->h_post_off[(size_t)T_new + 1], (unsigned long long)P_new);
 			goto fail;
 		}
-		/* swap in the new CSR */
-		(void)hipFree(ix->d_post_dt);
+		/* swap in the new CSR; the old buffer is the next refresh's target */
+		ix->d_post_dt_spare = ix->d_post_dt;
+		ix->cap_post_dt_spare = ix->cap_post_dt;
 		ix->d_post_dt = d_out;
+		ix->cap_post_dt = cap_out;
 		d_out = NULL;
 		(void)hipFree(ix->d_post_off);
 		ix->d_post_off = d_off_new;

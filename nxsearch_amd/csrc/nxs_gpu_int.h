@@ -196,6 +196,8 @@ struct nxsgpu_index {
 	uint64_t *	d_post_dt;	/* [P] doc<<32 | tf, sorted by (term, doc): the primary array;
 					 * impacts are recomputed from it at every refresh (N1) */
 	uint64_t	cap_post;	/* capacity of d_post[*] */
+	uint64_t *	d_post_dt_spare;	/* the CSR buffer the next refresh merges into (NULL until the first one) */
+	uint64_t	cap_post_dt, cap_post_dt_spare;
 	uint64_t	cap_docs_ids, cap_docs_len;
 	uint32_t	max_tf;
 	posting_t *	d_post[2];	/* [P] per ranking algo; NULL until the algo is first used (algo_on) */

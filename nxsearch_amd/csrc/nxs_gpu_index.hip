@@ -83,6 +83,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.by_level = !on("NXS_GPU_NOLEVELS");
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
+	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
 	c.scanm_general = !on("NXS_GPU_SCANM_ORONLY");
 	c.old_scan = on("NXS_GPU_OLDSCAN");
 	c.no_scan1 = on("NXS_GPU_NOSCAN1");

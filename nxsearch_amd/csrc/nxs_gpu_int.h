@@ -125,6 +125,7 @@ struct gpu_cfg_t {
 	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
 	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */
 	bool		old_replay;	/* NXS_GPU_OLDREPLAY: the LDS heap on one lane (k_replay<HEAP_LDS>) */
+	bool		replay_join;	/* NXS_GPU_REPLAY_JOIN: the scan stream waits for a batch's last heap replay (limits <= 64) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
 					 * (k_scanm) -- measured slower on C3, kept as a tested alternative */

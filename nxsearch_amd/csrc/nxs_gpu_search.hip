@@ -435,6 +435,9 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	if (forked3) {
 		(void)hipEventRecord(ix->ev_join3, ix->stream3);
 		(void)hipStreamWaitEvent(ix->stream, ix->ev_join3, 0);
+		if (replays_aside) {
+			(void)hipStreamWaitEvent(st_rp, ix->ev_join3, 0);	/* the batch ends there */
+		}
 	}
 }
 
@@ -1456,8 +1459,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * not wait for them, so the NEXT batch's scans AND replays run beside them (a
 	 * replay stream per batch slot); the batch ends when its replay stream has.  With a collective behind the replays the usual join stays.
 	 */
-	const bool aside = big && nq && !gather && !solo && !ix->cfg.one_replay;
-	hipStream_t s_end = aside ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream;
+	const bool aside = (big || (o.records && !ix->cfg.replay_join)) && nq && !gather && !solo && !ix->cfg.one_replay;
+	/* (limits <= 64: the replays of both slots share the replay stream -- they are short, and
+	 * stream_rp[0] is the dense-term class's stream) */
+	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream2;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	if (nq) {
 		if (ix->cfg.one_replay) {

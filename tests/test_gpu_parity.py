@@ -7,6 +7,7 @@ identical float bits, which the design guarantees (DESIGN.md "bit-exact
 scores")."""
 import os
 import random
+import shutil
 import struct
 
 import pytest
@@ -1096,3 +1097,135 @@ def test_dense_terms_leave_sparse_or_scans(nxs, tmp_path, monkeypatch, env):
             for q, g in zip(qs, got):
                 assert_same(g, oidx.search(q, algo=algo, limit=limit, fuzzymatch=False), (env, q, limit, name))
     gidx.close()
+
+
+def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
+    """BASELINE.json configs[1] at its FULL size (10M docs / 1M terms, a batch of 1024 five-term
+    AND / OR queries, top-10) -- where the oracle answers only a sample in reasonable time -- through
+    properties that do not depend on the size: every answer is sorted by descending score with valid
+    doc ids; the same batch gives the same bits again, blocking and with two batches in flight; the
+    top-10 scores are the first ten of the top-64 scores, and those the first 64 of the top-200 (the
+    lane heap, the LDS heap and the histogram threshold agree); three independent scan algorithms --
+    the byte-bound filter (k_scanm / k_scanr), the f32 accumulator tiles alone (NXS_GPU_NOSCANM,
+    NXS_GPU_NOSCANR) and the doc-grid walk (NXS_GPU_GRID) -- return identical ids and score bits;
+    single-term answers are the term's largest impacts; and a sample is checked against the oracle."""
+    work = "/dev/shm/nxs_fullsize_%d" % os.getpid()
+    try:
+        c = corpus.write_corpus(work, 10_000_000, 1_000_000, seed=0)
+        terms = corpus.term_strings(1_000_000, seed=0)
+        gidx = nxs.open_files(c["terms"], c["dtmap"])
+        qs = corpus.queries_bool5(terms, 1024, seed=3, hi=1000)
+        bits = lambda res: [[(d, struct.pack("<f", s)) for d, s in r] for r in res]
+        base = gidx.search_batch(qs, limit=10, fuzzymatch=False)
+        assert not any(isinstance(r, N.NxsError) for r in base)
+        n_docs = 10_000_000
+        for r in base:
+            assert len(r) <= 10 and len({d for d, _ in r}) == len(r)
+            assert all(1 <= d <= n_docs for d, _ in r)
+            assert all(a[1] >= b[1] for a, b in zip(r, r[1:]))
+        assert sum(len(r) == 10 for r in base) >= 512         # every OR query fills its ten
+        # idempotence: blocking again, then two batches in flight
+        assert bits(gidx.search_batch(qs, limit=10, fuzzymatch=False)) == bits(base)
+        gidx.search_batch_begin(qs, limit=10, fuzzymatch=False)
+        gidx.search_batch_begin(qs[::-1], limit=10, fuzzymatch=False)
+        assert bits(gidx.search_batch_end()) == bits(base)
+        assert bits(gidx.search_batch_end()) == bits(base[::-1])
+        # score prefixes across the heap homes
+        sub = qs[:128]
+        r64 = gidx.search_batch(sub, limit=64, fuzzymatch=False)
+        r200 = gidx.search_batch(sub, limit=200, fuzzymatch=False)
+        sc = lambda r: [struct.pack("<f", s) for _, s in r]
+        for a, b, cc in zip(base, r64, r200):
+            assert sc(b)[:len(a)] == sc(a) and sc(cc)[:len(b)] == sc(b)
+            assert len(a) == min(10, len(b)) and len(b) == min(64, len(cc))
+        # independent scan algorithms, same bits
+        for env in ({"NXS_GPU_NOSCANM": "1", "NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_GRID": "3"},
+                    {"NXS_GPU_NODROP": "1", "NXS_GPU_WAVES": "8192"}):
+            for kk, v in env.items():
+                monkeypatch.setenv(kk, v)
+            gidx.reconfigure()
+            assert bits(gidx.search_batch(qs, limit=10, fuzzymatch=False)) == bits(base), env
+            for kk in env:
+                monkeypatch.delenv(kk)
+        gidx.reconfigure()
+        # a single-term query's scores are its list's largest impacts: the top-3 of top-10 and of top-1000 agree
+        for q in (terms[0].decode(), terms[99].decode(), terms[4999].decode()):
+            a, b = gidx.search(q, limit=10, fuzzymatch=False), gidx.search(q, fuzzymatch=False)
+            assert sc(b)[:10] == sc(a) and len(b) == 1000
+        # the oracle on a sample (both operators; ~0.25 s per query)
+        oidx = O.Index(c["terms"], c["dtmap"])
+        for i in (0, 1, 2, 3, 510, 511, 1022, 1023):
+            assert_same(base[i], oidx.search(qs[i], limit=10, fuzzymatch=False), qs[i])
+        # ---- configs[3]: Levenshtein d <= 2 over the 1M-term BK-tree, batch 1024 ----
+        toks = corpus.queries_fuzzy(terms, 1024, seed=4)
+        ids = gidx.fuzzy(toks)
+        assert all(ids), "every token has a match at distance 1"
+
+        def lev(a, b):
+            row = list(range(len(b) + 1))
+            for i, ca in enumerate(a, 1):
+                prev, row[0] = row[0], i
+                for j, cb in enumerate(b, 1):
+                    prev, row[j] = row[j], min(row[j] + 1, row[j - 1] + 1, prev + (ca != cb))
+            return row[-1]
+        for tok, t in zip(toks, ids):
+            assert lev(tok.encode(), terms[t - 1]) <= 2, (tok, t)
+        assert gidx.fuzzy(toks) == ids                                   # idempotent
+        assert gidx.fuzzy(toks[:1]) == ids[:1] and gidx.fuzzy(toks[500:600]) == ids[500:600]
+        ids_v, vis = gidx.fuzzy(toks, want_visited=True)                 # the frontier search, visit counts
+        assert ids_v == ids and min(vis) > 0
+        monkeypatch.setenv("NXS_GPU_FUZZY_BFS", "1")                     # level-by-level frontier only
+        gidx.reconfigure()
+        assert gidx.fuzzy(toks) == ids
+        monkeypatch.delenv("NXS_GPU_FUZZY_BFS")
+        gidx.reconfigure()
+        for i in range(0, 1024, 128):                                    # the oracle's BK-tree walk on a sample
+            assert (ids[i], vis[i]) == oidx.fuzzy(toks[i].encode()), toks[i]
+        # fuzzy tokens inside boolean queries resolve to the same terms (tokenset fallback)
+        fq = ["%s OR %s" % (toks[i], terms[200 + i].decode()) for i in range(4)]
+        pq = ["%s OR %s" % (terms[ids[i] - 1].decode(), terms[200 + i].decode()) for i in range(4)]
+        assert bits(gidx.search_batch(fq, limit=10, fuzzymatch=True)) == bits(gidx.search_batch(pq, limit=10, fuzzymatch=False))
+        oidx.close()
+        gidx.close()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_full_size_c2_properties(nxs):
+    """BASELINE.json configs[1]: 1M docs / 100k terms, single-term BM25 top-10, at full size: sorted
+    answers, blocking == pipelined, the single-token kernel == the accumulator tiles
+    (NXS_GPU_NOSCAN1), top-10 a prefix of the default limit's 1000, TF-IDF and BM25 rank the same
+    docs of a list differently but return as many, and the oracle on a sample."""
+    work = "/dev/shm/nxs_fullsize_c2_%d" % os.getpid()
+    try:
+        c = corpus.write_corpus(work, 1_000_000, 100_000, seed=0)
+        terms = corpus.term_strings(100_000, seed=0)
+        gidx = nxs.open_files(c["terms"], c["dtmap"])
+        qs = corpus.queries_single(terms, 1024, seed=2, lo=1, hi=100_000)
+        bits = lambda res: [[(d, struct.pack("<f", s)) for d, s in r] for r in res]
+        base = gidx.search_batch(qs, limit=10, fuzzymatch=False)
+        for r in base:
+            assert 1 <= len(r) <= 10 and all(a[1] >= b[1] for a, b in zip(r, r[1:]))
+        gidx.search_batch_begin(qs, limit=10, fuzzymatch=False)
+        gidx.search_batch_begin(qs, limit=10, fuzzymatch=False)
+        assert bits(gidx.search_batch_end()) == bits(base) and bits(gidx.search_batch_end()) == bits(base)
+        import os as _os
+        _os.environ["NXS_GPU_NOSCAN1"] = "1"
+        try:
+            gidx.reconfigure()
+            assert bits(gidx.search_batch(qs, limit=10, fuzzymatch=False)) == bits(base)
+        finally:
+            del _os.environ["NXS_GPU_NOSCAN1"]
+            gidx.reconfigure()
+        big = gidx.search_batch(qs[:64], fuzzymatch=False)               # params NULL => 1000
+        tf = gidx.search_batch(qs[:64], limit=10, algo="TF-IDF", fuzzymatch=False)
+        for a, b, t in zip(base, big, tf):
+            assert [struct.pack("<f", s) for _, s in b][:len(a)] == [struct.pack("<f", s) for _, s in a]
+            assert len(t) == len(a)
+        oidx = O.Index(c["terms"], c["dtmap"])
+        for i in range(0, 1024, 32):
+            assert_same(base[i], oidx.search(qs[i], limit=10, fuzzymatch=False), qs[i])
+        oidx.close()
+        gidx.close()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

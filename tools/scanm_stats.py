@@ -33,13 +33,14 @@ L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 L.nxsgpu_debug_stats_grid.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "redone", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
 names = ["waves", "tiles", "visits", "flushes", "pending", "emitted", "flush_cyc", "wave_cyc", "tile_w_sum", "lanes_in_visits", "overflows", "reg_chunks", "deep_chunks"]
+ALGO = N.TF_IDF if os.environ.get("STATS_TFIDF") else N.BM25
 for name, qs in sets.items():
     plans, errs = idx.plan_batch(qs, limit=k, fuzzymatch=False)
-    idx.search_dev(plans, batch, k, N.BM25, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
+    idx.search_dev(plans, batch, k, ALGO, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     out = (C.c_ulonglong * 16)()
     L.nxsgpu_debug_stats(out, 1)
     L.nxsgpu_debug_stats_grid(out, 1)
-    idx.search_dev(plans, batch, k, N.BM25, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
+    idx.search_dev(plans, batch, k, ALGO, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     L.nxsgpu_debug_stats(out, 1)
     v = dict(zip(names, list(out)))
     w = max(v["waves"], 1)

@@ -900,6 +900,14 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	ix->cap_post = P + P / 16 + 4096;
 	HIP_TRY(hipMalloc(&ix->d_post_dt, ix->cap_post * 8));
 	ix->cap_post_dt = ix->cap_post;
+	/* the buffer the first refresh merges into: taken now, so that no refresh pays for a
+	 * multi-GB allocation (not fatal if it cannot be had: nxsgpu_index_apply tries again) */
+	if (hipMalloc(&ix->d_post_dt_spare, ix->cap_post * 8) == hipSuccess) {
+		ix->cap_post_dt_spare = ix->cap_post;
+	} else {
+		(void)hipGetLastError();
+		ix->d_post_dt_spare = NULL;
+	}
 	for (int a = 0; a < 2; a++) {
 		/* (the other ranking function's impacts: on its first search, ensure_algo) */
 		ix->algo_on[a] = src->default_algo < 0 || src->default_algo == a;
@@ -1070,6 +1078,13 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 	unsigned int h_max_tf = 0;
 	int rc = -1;
 
+	auto now_ms = []() -> double {
+		struct timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+	};
+	const double t_a0 = now_ms();
+	double t_a1 = t_a0, t_a2 = t_a0;
 	if (ix->slot[0].active || ix->slot[1].active) {
 		set_error("nxsgpu_index_apply: batches are in flight");
 		return -1;
@@ -1196,6 +1211,7 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			goto fail;
 		}
 	}
+	t_a1 = now_ms();
 	{
 		const uint64_t P_new = P_old - n_dead + n_newp;
 		const unsigned blocks = (unsigned)(((uint64_t)T_new + 2 + 255) / 256);
@@ -1259,8 +1275,13 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			}
 		}
 	}
+	t_a2 = now_ms();
 	if (rebuild_impacts(ix) != 0) {
 		goto fail;
+	}
+	if (ix->cfg.debug_timing) {
+		fprintf(stderr, "[nxsgpu apply] delta %.1f ms, merge %.1f ms, impacts + columns %.1f ms\n",
+		    t_a1 - t_a0, t_a2 - t_a1, now_ms() - t_a2);
 	}
 	rc = 0;
 fail:

@@ -22,6 +22,7 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 
 #include "nxs_impl.h"
 #include "nxs_lev.h"
@@ -979,9 +980,19 @@ nxs_index_changed(const nxs_index_t *idx)
 	    rd32(idx->dmap + 24) != idx->hdr_docs_seen || rd64(idx->dmap + 16) != idx->hdr_tokens_seen;
 }
 
+static double
+dbg_ms(void)
+{
+	struct timespec ts;
+
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
 int
 nxs_index_refresh(nxs_index_t *idx)
 {
+	double t_dbg[3] = { dbg_ms(), 0, 0 };
 	uint64_t t_now, d_now, hd_docs, hd_tokens;
 	uint64_t *nb_off = NULL, *nb_ids = NULL, *nb_base = NULL;
 	uint32_t *dead_term = NULL, *dead_ord = NULL, *dead_list = NULL;
@@ -1143,6 +1154,7 @@ nxs_index_refresh(nxs_index_t *idx)
 	dl.n_dead_pairs = n_deadp;
 	dl.hdr_doc_count = (uint32_t)hd_docs;
 	dl.hdr_token_count = hd_tokens;
+	t_dbg[1] = dbg_ms();
 	if (nxsgpu_index_apply(idx->dev, &dl) != 0) {
 		for (size_t i = 0; i < n_dead; i++) {
 			idx->h_alive[dead_list[i]] = 1;
@@ -1150,6 +1162,7 @@ nxs_index_refresh(nxs_index_t *idx)
 		ret = refresh_rebuild(idx);
 		goto out;
 	}
+	t_dbg[2] = dbg_ms();
 	/* commit the host tables */
 	for (size_t i = 0; i < n_dead; i++) {
 		idx->h_alive[dead_list[i]] = 0;
@@ -1179,6 +1192,10 @@ nxs_index_refresh(nxs_index_t *idx)
 	(void)old_last_id;
 	idx->n_incremental++;
 	ret = 0;
+	if (getenv("NXS_GPU_DEBUG_TIMING")) {
+		fprintf(stderr, "[nxs refresh] host walk %.1f ms, device apply %.1f ms, commit %.1f ms\n",
+		    t_dbg[1] - t_dbg[0], t_dbg[2] - t_dbg[1], dbg_ms() - t_dbg[2]);
+	}
 out:
 	free(nb_off);
 	free(nb_ids);

@@ -226,9 +226,9 @@ k_scanm(const scan_args_t A)
 		vmA[t] = vmN[t] = 0;
 		rp[t] = 0;
 		tmx[t] = 0.0f;
-		Ad[t] = 0xffffffffu;		/* no doc */
+		Ad[t] = 0;
 		Ai[t] = 0.0f;
-		Nd[t] = 0xffffffffu;
+		Nd[t] = 0xffffffffu;		/* no doc */
 		Ni[t] = 0.0f;
 		ldocN[t] = 0;
 		if (t < (int)nt) {
@@ -669,58 +669,31 @@ k_scanm(const scan_args_t A)
 		}
 
 		const uint32_t n_tile = n_pend - n_before;
-		/*
-		 * More docs above the threshold than the pending list takes (a still-weak
-		 * threshold and a wide tile): nothing is lost -- the tile's postings are still in
-		 * sets A and N (no shift yet) and its bytes are wiped -- so the lanes it consumed
-		 * are handed back (exactly those holding a doc of [base, md]: earlier tiles took
-		 * higher docs only) and the same docs are walked again in narrower tiles.  Only
-		 * a tile that cannot shrink sends the range to the retry list.  (The list is
-		 * empty at every tile's start: n_before == 0.)
-		 */
-		const bool over = n_pend > PCAP;
-		const bool redo = over && tw > (uint32_t)MT_W0 && (uint32_t)md > base;
-		if (over && !redo) {
+		if (n_pend > PCAP) {
 			ovf = true;
-		} else if (!over && n_pend) {
+		} else if (n_pend) {
 			flush();		/* looks the docs up in A and N: before any shift */
 		}
-		if (redo) {
-			STAT_ADD(11, 1);
-			/* (lanes outside [lo, hi) hold clamped copies of a valid posting: one that
-			 * comes back with its original only raises the doc's byte bound a second
-			 * time -- the exact score reads one lane per term -- and is consumed with it) */
-			const uint32_t span = (uint32_t)md - base;
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				vmA[t] |= ballot64(Ad[t] - base <= span);
-				vmN[t] |= ballot64(Nd[t] - base <= span);
-				refresh_pdoc(tc);
-			});
-			n_pend = 0;
-			tw = max(min(tw, (uint32_t)md - base + 1) >> 2, (uint32_t)MT_W0);
-		} else {
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				while (vmA[t] == 0 && ab[t] > lo[t]) {
-					shift(tc);
-				}
-				refresh_pdoc(tc);
-			});
-			if (DROP && dropped) {
-				/* pushes are cheap here (refined in parallel in the flush): as wide as
-				 * the pending list takes */
-				if (n_tile <= 36) {
-					tw = min(tw * 2, (uint32_t)MT_DOCS);
-				} else if (n_tile > 88) {
-					tw = max(tw / 2, (uint32_t)MT_W0);
-				}
-			} else
-			if (n_tile <= 8) {
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			while (vmA[t] == 0 && ab[t] > lo[t]) {
+				shift(tc);
+			}
+			refresh_pdoc(tc);
+		});
+		if (DROP && dropped) {
+			/* pushes are cheap here (refined in parallel in the flush): as wide as
+			 * the pending list takes */
+			if (n_tile <= 36) {
 				tw = min(tw * 2, (uint32_t)MT_DOCS);
-			} else if (n_tile > 48) {
+			} else if (n_tile > 88) {
 				tw = max(tw / 2, (uint32_t)MT_W0);
 			}
+		} else
+		if (n_tile <= 8) {
+			tw = min(tw * 2, (uint32_t)MT_DOCS);
+		} else if (n_tile > 48) {
+			tw = max(tw / 2, (uint32_t)MT_W0);
 		}
 	}
 

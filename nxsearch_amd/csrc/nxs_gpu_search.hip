@@ -1459,7 +1459,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * not wait for them, so the NEXT batch's scans AND replays run beside them (a
 	 * replay stream per batch slot); the batch ends when its replay stream has.  With a collective behind the replays the usual join stays.
 	 */
-	const bool aside = (big || (o.records && !ix->cfg.replay_join)) && nq && !gather && !solo && !ix->cfg.one_replay;
+	/* (limits <= 64: only where the tail is a visible share of the step -- short batches; a C5 batch scans
+	 * for 35 ms, its host side is nearly as long, and ending it on the replay stream cost 7 %) */
+	const bool short_batch = total_post < (1ull << 32);
+	const bool aside = (big || (o.records && short_batch && !ix->cfg.replay_join)) && nq && !gather && !solo && !ix->cfg.one_replay;
 	/* (limits <= 64: the replays of both slots share the replay stream -- they are short, and
 	 * stream_rp[0] is the dense-term class's stream) */
 	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream2;

@@ -84,6 +84,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
+	c.tfidf_drop = !on("NXS_GPU_TFIDF_NODROP");
+	c.outl_share = (uint32_t)u64("NXS_GPU_OUTL_SHARE", 8, 2, 1u << 20);
 	c.scanm_general = !on("NXS_GPU_SCANM_ORONLY");
 	c.old_scan = on("NXS_GPU_OLDSCAN");
 	c.no_scan1 = on("NXS_GPU_NOSCAN1");
@@ -624,6 +626,124 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	delete ix;
 }
 
+/* elements of d_post[a]: the postings, then (TF-IDF) room for the dense terms' outlier lists */
+static size_t
+post_elems(const nxsgpu_index_t *ix, int a)
+{
+	return (size_t)ix->cap_post + (a == NXSGPU_TF_IDF ? (size_t)(ix->cap_post / 8 + 4096) : 0);
+}
+
+/*
+ * TF-IDF outlier lists (nxsgpu_index::outl_off): tf histogram of one dense term's
+ * postings, then an order-preserving compaction of the postings above the cap --
+ * per-block counts, one scan, per-block writes.
+ */
+#define	OUTL_CHUNK	4096		/* postings per block (256 threads x 16) */
+__global__ void __launch_bounds__(256)
+k_tf_hist(const uint64_t *__restrict__ dt, uint64_t n, uint32_t *__restrict__ hist)
+{
+	__shared__ uint32_t s_h[64];
+	if (threadIdx.x < 64) {
+		s_h[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		atomicAdd(&s_h[min((uint32_t)dt[i], 63u)], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 64 && s_h[threadIdx.x]) {
+		atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_outl_count(const uint64_t *__restrict__ dt, uint64_t n, uint32_t tf_cap, uint32_t *__restrict__ cnt)
+{
+	__shared__ uint32_t s_n;
+	if (threadIdx.x == 0) {
+		s_n = 0;
+	}
+	__syncthreads();
+	const uint64_t b0 = (uint64_t)blockIdx.x * OUTL_CHUNK + (uint64_t)threadIdx.x * 16;
+	uint32_t c = 0;
+	for (int k = 0; k < 16; k++) {
+		c += (b0 + k < n && (uint32_t)dt[b0 + k] > tf_cap) ? 1u : 0u;
+	}
+	if (c) {
+		atomicAdd(&s_n, c);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		cnt[blockIdx.x] = s_n;
+	}
+}
+
+/* exclusive scan of cnt[0..nb) in place, total to cnt[nb]: one block */
+__global__ void __launch_bounds__(1024)
+k_outl_scan(uint32_t *__restrict__ cnt, uint32_t nb)
+{
+	__shared__ uint32_t s_part[1024];
+	const uint32_t per = (nb + 1023) / 1024;
+	const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nb);
+	uint32_t sum = 0;
+	for (uint32_t i = lo; i < hi; i++) {
+		sum += cnt[i];
+	}
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (int i = 0; i < 1024; i++) {
+			const uint32_t v = s_part[i];
+			s_part[i] = run;
+			run += v;
+		}
+		cnt[nb] = run;
+	}
+	__syncthreads();
+	uint32_t run = s_part[threadIdx.x];
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint32_t v = cnt[i];
+		cnt[i] = run;
+		run += v;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_outl_write(const uint64_t *__restrict__ dt, const posting_t *__restrict__ imp, uint64_t n, uint32_t tf_cap,
+    float cap_imp, const uint32_t *__restrict__ cnt, posting_t *__restrict__ out, uint32_t *__restrict__ max_excess)
+{
+	__shared__ uint32_t s_c[256];
+	const uint64_t b0 = (uint64_t)blockIdx.x * OUTL_CHUNK + (uint64_t)threadIdx.x * 16;
+	uint32_t c = 0;
+	for (int k = 0; k < 16; k++) {
+		c += (b0 + k < n && (uint32_t)dt[b0 + k] > tf_cap) ? 1u : 0u;
+	}
+	s_c[threadIdx.x] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = cnt[blockIdx.x];
+		for (int i = 0; i < 256; i++) {
+			const uint32_t v = s_c[i];
+			s_c[i] = run;
+			run += v;
+		}
+	}
+	__syncthreads();
+	uint32_t o = s_c[threadIdx.x], mx = 0;
+	for (int k = 0; k < 16; k++) {
+		if (b0 + k < n && (uint32_t)dt[b0 + k] > tf_cap) {
+			posting_t p = imp[b0 + k];
+			p.imp = p.imp - cap_imp;	/* > 0: the impact grows with tf */
+			mx = max(mx, __float_as_uint(p.imp));
+			out[o++] = p;
+		}
+	}
+	if (mx) {
+		atomicMax(max_excess, mx);
+	}
+}
+
 /*
  * Impacts of every posting from the CSR form (d_post_off, d_post_dt) and the
  * header statistics: host libm tables (the device only does IEEE + - * / on
@@ -717,9 +837,9 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 		    hipMemcpyDeviceToHost, ix->stream));
 	}
 	HIP_TRY(hipStreamSynchronize(ix->stream));
-	/* impact columns of the dense terms (at most 64, densest first): BM25 only -- the
-	 * class that reads them is (k_scanm<.., DROP>, fill_dev_queries) */
-	if (do_b) {
+	/* impact columns of the dense terms (at most 64, densest first), per materialised
+	 * ranking function -- the class that reads them is (k_scanm<.., DROP>, fill_dev_queries) */
+	{
 		std::vector<std::pair<uint64_t, uint32_t>> dn;
 		for (uint32_t t = 1; t <= T; t++) {
 			const uint64_t df = ix->h_post_off[t + 1] - ix->h_post_off[t];
@@ -733,24 +853,28 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 		if (dn.size() > 64) {
 			dn.resize(64);
 		}
+		/* (the same list whichever function is rebuilt: it depends on the df only) */
 		ix->dense_terms.clear();
 		for (auto &e : dn) {
 			ix->dense_terms.push_back(e.second);
 		}
 		std::sort(ix->dense_terms.begin(), ix->dense_terms.end());
 		const uint64_t words = (uint64_t)ix->dense_terms.size() * ix->n_docs;
-		if (words > ix->dense_cap || (!words && ix->dense_cap)) {
-			(void)hipFree(ix->d_dense_col[NXSGPU_BM25]);
-			ix->d_dense_col[NXSGPU_BM25] = NULL;
-			ix->dense_cap = 0;
-			if (words) {
-				const uint64_t cap = words + words / 16 + 1024;
-				HIP_TRY(hipMalloc((void **)&ix->d_dense_col[NXSGPU_BM25], cap * 4));
-				ix->dense_cap = cap;
+		for (int a = 0; a < 2; a++) {
+			if (!(a == NXSGPU_BM25 ? do_b : do_t) || (a == NXSGPU_TF_IDF && !ix->cfg.tfidf_drop)) {
+				continue;
 			}
-		}
-		if (words) {
-			for (int a = NXSGPU_BM25; a == NXSGPU_BM25; a = -1) {
+			if (words > ix->dense_cap[a] || (!words && ix->dense_cap[a])) {
+				(void)hipFree(ix->d_dense_col[a]);
+				ix->d_dense_col[a] = NULL;
+				ix->dense_cap[a] = 0;
+				if (words) {
+					const uint64_t cap = words + words / 16 + 1024;
+					HIP_TRY(hipMalloc((void **)&ix->d_dense_col[a], cap * 4));
+					ix->dense_cap[a] = cap;
+				}
+			}
+			if (words) {
 				HIP_TRY(hipMemsetAsync(ix->d_dense_col[a], 0xff, words * 4, ix->stream));
 				for (size_t c = 0; c < ix->dense_terms.size(); c++) {
 					const uint32_t t = ix->dense_terms[c];
@@ -758,9 +882,88 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 					    ix->d_post[a], ix->h_post_off[t], ix->h_post_off[t + 1],
 					    ix->d_dense_col[a] + c * ix->n_docs);
 				}
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(ix->stream));
 			}
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(ix->stream));
+		}
+	}
+	/* TF-IDF: cap + outlier list per dense term (nxsgpu_index::outl_off) */
+	if (do_t) {
+		const size_t nc = ix->cfg.tfidf_drop ? ix->dense_terms.size() : 0;
+		const uint64_t room = post_elems(ix, NXSGPU_TF_IDF) - ix->cap_post;
+		uint32_t *d_hist = NULL, *d_cnt = NULL, *d_mx = NULL;
+		uint64_t at = ix->cap_post;
+		bool ok = true;
+
+		ix->outl_off.assign(nc + 1, at);
+		ix->outl_cap.assign(nc, 0.0f);
+		ix->outl_max.assign(nc, 0.0f);
+		if (nc) {
+			uint64_t max_df = 0;
+			for (size_t c = 0; c < nc; c++) {
+				const uint32_t t = ix->dense_terms[c];
+				max_df = std::max<uint64_t>(max_df, ix->h_post_off[t + 1] - ix->h_post_off[t]);
+			}
+			const uint64_t max_nb = (max_df + OUTL_CHUNK - 1) / OUTL_CHUNK;
+			ok = hipMalloc((void **)&d_hist, 64 * 4) == hipSuccess &&
+			    hipMalloc((void **)&d_cnt, (max_nb + 1) * 4) == hipSuccess &&
+			    hipMalloc((void **)&d_mx, 4) == hipSuccess;
+		}
+		for (size_t c = 0; c < nc && ok; c++) {
+			const uint32_t t = ix->dense_terms[c];
+			const uint64_t p0 = ix->h_post_off[t], n = ix->h_post_off[t + 1] - p0;
+			const uint32_t nb = (uint32_t)((n + OUTL_CHUNK - 1) / OUTL_CHUNK);
+			uint32_t hist[64], tf_cap = 0, n_out = 0, mx = 0;
+
+			ix->outl_cap[c] = ix->h_maximp[NXSGPU_TF_IDF][t];
+			ix->outl_off[c] = at;
+			(void)hipMemsetAsync(d_hist, 0, 64 * 4, ix->stream);
+			hipLaunchKernelGGL(k_tf_hist, dim3(std::min<uint32_t>(nb, 1024)), dim3(256), 0, ix->stream,
+			    ix->d_post_dt + p0, n, d_hist);
+			ok = hipMemcpyAsync(hist, d_hist, 64 * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
+			    hipStreamSynchronize(ix->stream) == hipSuccess;
+			if (!ok) {
+				break;
+			}
+			/* the smallest tf that all but 1/outl_share of the postings stay at or below */
+			uint64_t above = 0;
+			for (int k = 63; k >= 1; k--) {
+				above += hist[k];
+			}
+			for (tf_cap = 1; tf_cap < 62 && above - hist[tf_cap] > n / ix->cfg.outl_share; tf_cap++) {
+				above -= hist[tf_cap];
+			}
+			above -= hist[tf_cap];		/* postings with tf > tf_cap */
+			if (above == 0 || tf_cap >= 62 || at + above > ix->cap_post + room) {
+				continue;		/* no outliers (or no room): the cap is the largest impact */
+			}
+			const float cap_imp = (float)logtf[tf_cap] * idf_t[t];	/* k_impacts_csr's own expression */
+			(void)hipMemsetAsync(d_mx, 0, 4, ix->stream);
+			hipLaunchKernelGGL(k_outl_count, dim3(nb), dim3(256), 0, ix->stream, ix->d_post_dt + p0, n, tf_cap, d_cnt);
+			hipLaunchKernelGGL(k_outl_scan, dim3(1), dim3(1024), 0, ix->stream, d_cnt, nb);
+			hipLaunchKernelGGL(k_outl_write, dim3(nb), dim3(256), 0, ix->stream, ix->d_post_dt + p0,
+			    ix->d_post[NXSGPU_TF_IDF] + p0, n, tf_cap, cap_imp, d_cnt, ix->d_post[NXSGPU_TF_IDF] + at, d_mx);
+			ok = hipMemcpyAsync(&n_out, d_cnt + nb, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
+			    hipMemcpyAsync(&mx, d_mx, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
+			    hipStreamSynchronize(ix->stream) == hipSuccess && n_out == above;
+			if (!ok) {
+				break;
+			}
+			ix->outl_cap[c] = cap_imp;
+			memcpy(&ix->outl_max[c], &mx, 4);
+			at += n_out;
+		}
+		for (size_t c = 0; c <= nc; c++) {
+			if (c == nc || ix->outl_off[c] > at) {
+				ix->outl_off[c] = at;
+			}
+		}
+		(void)hipFree(d_hist);
+		(void)hipFree(d_cnt);
+		(void)hipFree(d_mx);
+		if (!ok) {
+			set_error("outlier lists of the dense terms failed");
+			goto fail;
 		}
 	}
 	rc = 0;
@@ -793,7 +996,7 @@ ensure_algo(nxsgpu_index_t *ix, int algo)
 		set_error("hipSetDevice failed");
 		return -1;
 	}
-	const uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(ix->cap_post, ix->n_post), 1);
+	const uint64_t cap = post_elems(ix, algo);
 	if (hipMalloc(&ix->d_post[algo], cap * sizeof(posting_t)) != hipSuccess) {
 		ix->d_post[algo] = NULL;
 		set_error("hipMalloc(%llu) for the impacts of ranking function %d failed",
@@ -912,7 +1115,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 		/* (the other ranking function's impacts: on its first search, ensure_algo) */
 		ix->algo_on[a] = src->default_algo < 0 || src->default_algo == a;
 		if (ix->algo_on[a]) {
-			HIP_TRY(hipMalloc(&ix->d_post[a], ix->cap_post * sizeof(posting_t)));
+			HIP_TRY(hipMalloc(&ix->d_post[a], post_elems(ix, a) * sizeof(posting_t)));
 		}
 	}
 	ix->h_post_off.assign((size_t)T + 2, 0);
@@ -1270,7 +1473,7 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 			ix->cap_post = P_new + P_new / 16 + 4096;
 			for (int a = 0; a < 2; a++) {
 				if (ix->algo_on[a]) {
-					HIP_TRY(hipMalloc(&ix->d_post[a], ix->cap_post * sizeof(posting_t)));
+					HIP_TRY(hipMalloc(&ix->d_post[a], post_elems(ix, a) * sizeof(posting_t)));
 				}
 			}
 		}

@@ -92,6 +92,14 @@ struct dev_query_t {
 					 * threshold exceeds what they can contribute together */
 	uint32_t	drop_col[8];	/* ... and their impact columns (scan_args_t::dense_col) */
 	float		tmax[8];	/* k_scanm: largest impact of tokens 0..7 */
+	float		tcap[8];	/* dropped tokens: what the term adds to a doc that is NOT in its outlier list at
+					 * most (== tmax when it has none) -- the ceiling the dropping rests on */
+	uint32_t	outl_mask;	/* dropped tokens whose pbeg / pend name the term's OUTLIER list (the postings
+					 * above tcap, impact = the excess over it): scanned like a sparse term for the
+					 * bounds, never for the exact score (that comes from the column) */
+	uint32_t	outl_tfidf;	/* host only: the dropped tokens have outlier lists to put in place (build_worklist) */
+	uint32_t	qflags;		/* bit 0: no second chance on the accumulator tiles (pbeg / pend are not the
+					 * terms' lists) -- an overflowing range flags the query for the exact passes */
 	uint8_t		prog[NXSGPU_MAX_PROG];
 };
 
@@ -125,6 +133,8 @@ struct gpu_cfg_t {
 	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
 	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */
 	bool		old_replay;	/* NXS_GPU_OLDREPLAY: the LDS heap on one lane (k_replay<HEAP_LDS>) */
+	bool		tfidf_drop;	/* !NXS_GPU_TFIDF_NODROP: dense terms leave TF-IDF scans too (capped ceiling + outlier lists) */
+	uint32_t	outl_share;	/* NXS_GPU_OUTL_SHARE (8): at most 1/this of a dense term's postings are outliers */
 	bool		replay_join;	/* NXS_GPU_REPLAY_JOIN: the scan stream waits for a batch's last heap replay (limits <= 64) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
@@ -214,7 +224,19 @@ struct nxsgpu_index {
 	 */
 	std::vector<uint32_t> dense_terms;	/* ascending term ids; column = position */
 	uint32_t *	d_dense_col[2];
-	uint64_t	dense_cap;		/* allocated words per algo */
+	uint64_t	dense_cap[2];		/* allocated words per algo */
+	/*
+	 * TF-IDF: log(tf + 1) does not saturate, so one posting with an outlier tf sets a
+	 * ceiling far above what the term typically adds and the dense terms could never
+	 * leave a scan.  Each dense term's list is therefore split by value: the column
+	 * holds every impact, a CAP (the impact of the largest tf that all but 1/outl_share
+	 * of the postings stay at or below) bounds the ordinary ones, and the postings
+	 * above it form the term's OUTLIER list -- (doc, impact - cap), in doc order, behind
+	 * the regular postings in d_post[TF_IDF] -- which a query scans like a sparse term.
+	 */
+	std::vector<uint64_t> outl_off;		/* [columns + 1] positions in d_post[TF_IDF] (from cap_post on) */
+	std::vector<float> outl_cap;		/* [columns] the cap (== the largest impact: no outlier list) */
+	std::vector<float> outl_max;		/* [columns] largest excess over the cap */
 
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;

@@ -774,7 +774,7 @@ k_scang(const scan_args_t A)
 	if (lane == 0) {
 		A.seg_count[seg] = ovf ? 0 : n_out;
 		if (ovf) {
-			const uint32_t ri = A.retry_items ? atomicAdd(A.retry_count, 1u) : 0xffffffffu;
+			const uint32_t ri = (A.retry_items && !(Q->qflags & 1)) ? atomicAdd(A.retry_count, 1u) : 0xffffffffu;
 			if (ri < A.retry_cap) {
 				A.retry_items[ri] = item;
 			} else {

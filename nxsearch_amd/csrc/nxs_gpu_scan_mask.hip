@@ -204,6 +204,7 @@ k_scanm(const scan_args_t A)
 	/* DROP: the dense tokens are never streamed; their impacts come from the
 	 * terms' columns (scan_args_t::dense_col) */
 	const uint32_t dmask = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->drop_mask) : 0u;
+	const uint32_t omask = DROP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->outl_mask) : 0u;
 	/* DROP: the range's cold phase (k_cold) stopped at doc cs_cur: only docs below
 	 * it are left, and only for the sparse terms */
 	const uint32_t *cs = A.cold_state + seg * 16;
@@ -242,8 +243,16 @@ k_scanm(const scan_args_t A)
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		if (DROP) {
-			if (((dmask >> t) & 1) || cs_left == 0) {
+			if ((((dmask & ~omask) >> t) & 1) || cs_left == 0) {
 				hi[t] = lo[t];		/* no postings as far as the windows are concerned */
+			} else if ((omask >> t) & 1) {
+				/* a dropped term's OUTLIER list (TF-IDF: the postings above the term's
+				 * cap, impact = the excess) is scanned like a sparse term's -- for the
+				 * bounds only, the exact score takes the column; the cold phase never
+				 * looked at it: what is left of it lies below the doc it stopped at */
+				if (hi[t] > lo[t]) {
+					hi[t] = wave_lower_bound(pt[t], lo[t], hi[t], cs_left);
+				}
 			} else if (t < (int)nt) {
 				hi[t] = min(hi[t], (int32_t)__builtin_amdgcn_readfirstlane((int)cs[4 + t]));
 			}
@@ -317,8 +326,9 @@ k_scanm(const scan_args_t A)
 #pragma unroll
 		for (int t = 0; t < NT; t++) {
 			if ((dmask >> t) & 1) {
-				U += tmx[t];			/* token order, f32: see above */
-				qU += (uint32_t)(tmx[t] * qs) + 2;
+				const float cap = Q->tcap[t];	/* (== tmx[t] unless the term has an outlier list) */
+				U += cap;			/* token order, f32: see above */
+				qU += (uint32_t)(cap * qs) + 2;
 			} else {
 				q1max = max(q1max, (uint32_t)(tmx[t] * qs) + 2);
 			}
@@ -327,6 +337,7 @@ k_scanm(const scan_args_t A)
 		qU = (uint32_t)__builtin_amdgcn_readfirstlane((int)qU);
 		thr_q -= (int32_t)qU;
 	}
+	(void)U;
 
 	uint32_t n_pend = 0;
 	auto push = [&](uint64_t m, uint32_t doc, uint32_t sum) {
@@ -709,7 +720,7 @@ k_scanm(const scan_args_t A)
 		if (ovf) {
 			/* once more on the accumulator tiles (scan_args_t::retry_items); a full
 			 * retry list sends the query to the exact passes */
-			const uint32_t ri = A.retry_items ? atomicAdd(A.retry_count, 1u) : 0xffffffffu;
+			const uint32_t ri = (A.retry_items && !(Q->qflags & 1)) ? atomicAdd(A.retry_count, 1u) : 0xffffffffu;
 			if (ri < A.retry_cap) {
 				A.retry_items[ri] = item;
 			} else {
@@ -781,7 +792,9 @@ k_cold(const scan_args_t A)
 		colb[t] = 0;
 		if (t < (int)nt) {
 			if ((dmask >> t) & 1) {
-				U += Q->tmax[t];		/* token order, f32 */
+				/* (the cap: docs above it are in the term's outlier list, which
+				 * k_scanm<.., DROP> scans -- and this phase scores every doc anyway) */
+				U += Q->tcap[t];		/* token order, f32 */
 				colb[t] = (uint64_t)rfl32(Q->drop_col[t]) * A.dense_stride;
 			} else {
 				const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;

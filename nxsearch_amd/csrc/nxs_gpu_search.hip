@@ -29,7 +29,7 @@ nt_bucket(uint32_t nt)
 }
 
 static void
-build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false,
+build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_t &wl, bool solo = false,
     uint32_t big_k = 0)
 {
 	const uint64_t tiles = std::max<uint64_t>(1, (ix->n_docs + TILE_W - 1) / TILE_W);
@@ -127,9 +127,24 @@ build_worklist(const nxsgpu_index_t *ix, const dev_query_t *hq, uint32_t nq, wor
 					if (!((hq[i].drop_mask >> t) & 1)) {
 						ws += hq[i].pend[t] - hq[i].pbeg[t];
 						n_sparse++;
+					} else if (hq[i].outl_tfidf) {
+						const size_t c = hq[i].drop_col[t];
+						ws += ix->outl_off[c + 1] - ix->outl_off[c];	/* (a dropped term's outlier list is scanned) */
 					}
 				}
 				if (n_sparse && ws >= cf.drop_minpost) {
+					/* TF-IDF: from here on the dropped tokens' lists are their outlier lists
+					 * (kernels that stream the terms' own lists must not see this query again:
+					 * qflags) */
+					for (uint32_t t = 0; t < hq[i].nt && hq[i].outl_tfidf; t++) {
+						const size_t c = hq[i].drop_col[t];
+						if (((hq[i].drop_mask >> t) & 1) && ix->outl_off[c + 1] > ix->outl_off[c]) {
+							hq[i].pbeg[t] = ix->outl_off[c];
+							hq[i].pend[t] = ix->outl_off[c + 1];
+							hq[i].outl_mask |= 1u << t;
+							hq[i].qflags |= 1;
+						}
+					}
 					total -= work[i];
 					work[i] = cf.drop_workmul * (ws + 16384);	/* latency-bound wavefronts: more, shorter ranges */
 					total += work[i];
@@ -340,7 +355,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		}
 		a.item_base = l.first;
 		/* (k_scang: 32-bit posting indexes) */
-		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) ? 4u : 0u;
+		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) &&
+		    !(l.kind == 5 && a0.dense_col == ix->d_dense_col[NXSGPU_TF_IDF]) ? 4u : 0u;	/* (nor outlier lists) */
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
 		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5);
@@ -507,18 +523,30 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 		}
 		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
 		/*
-		 * (BM25 only: its tf part saturates, so a term's largest impact says what
-		 * the term typically adds.  TF-IDF's log(tf + 1) does not: one posting with
-		 * an outlier tf sets a ceiling that thresholds reach late -- measured 3x
-		 * slower than the accumulator tiles there.)
+		 * (BM25's tf part saturates, so a term's largest impact says what the term
+		 * typically adds.  TF-IDF's log(tf + 1) does not -- one posting with an outlier
+		 * tf sets a ceiling that thresholds reach late: 3x slower than the accumulator
+		 * tiles -- so there the ceiling is the term's CAP and the postings above it are
+		 * scanned as the term's outlier list: nxsgpu_index::outl_off.)
 		 */
 		d.drop_mask = 0;
-		if (allow_drop && d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && algo == NXSGPU_BM25) {
+		d.outl_mask = 0;
+		d.qflags = 0;
+		for (uint32_t t = 0; t < 8; t++) {
+			d.tcap[t] = d.tmax[t];
+		}
+		const bool cols = algo == NXSGPU_BM25 || (ix->cfg.tfidf_drop && ix->d_dense_col[algo] &&
+		    ix->outl_cap.size() == ix->dense_terms.size());
+		if (allow_drop && d.nt >= 2 && d.nt <= 8 && ix->cfg.use_drop && !ix->dense_terms.empty() && cols) {
 			for (uint32_t t = 0; t < d.nt; t++) {
 				const auto it = std::lower_bound(ix->dense_terms.begin(), ix->dense_terms.end(), q.term_id[t]);
 				if (it != ix->dense_terms.end() && *it == q.term_id[t]) {
+					const size_t c = (size_t)(it - ix->dense_terms.begin());
 					d.drop_mask |= 1u << t;
-					d.drop_col[t] = (uint32_t)(it - ix->dense_terms.begin());
+					d.drop_col[t] = (uint32_t)c;
+					if (algo == NXSGPU_TF_IDF) {
+						d.tcap[t] = ix->outl_cap[c];
+					}
 				}
 			}
 		}
@@ -528,13 +556,21 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			float u = 0.0f, smin = INFINITY;
 			for (uint32_t t = 0; t < d.nt; t++) {
 				if ((d.drop_mask >> t) & 1) {
-					u += d.tmax[t];
+					u += d.tcap[t];
 				} else {
 					smin = std::min(smin, d.tmax[t]);
 				}
 			}
 			if (!(u <= 1.25f * smin)) {
 				d.drop_mask = 0;
+			}
+		}
+		/* (a dropped token's list as the scan sees it -- its outlier list, TF-IDF -- is put in
+		 * its place by build_worklist, once the query is known to take the dense-term class) */
+		d.outl_tfidf = (d.drop_mask && algo == NXSGPU_TF_IDF) ? 1u : 0u;
+		if (!d.drop_mask) {
+			for (uint32_t t = 0; t < 8; t++) {
+				d.tcap[t] = d.tmax[t];
 			}
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */

@@ -1070,7 +1070,11 @@ def test_doc_sharded_rank_form_through_rccl(nxs, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},
-                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"}])
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
+                                 # TF-IDF: the dense terms' caps and outlier lists -- few outliers, half of the list, none
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "64"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "2", "NXS_GPU_WAVES": "64"},
+                                 {"NXS_GPU_TFIDF_NODROP": "1"}])
 def test_dense_terms_leave_sparse_or_scans(nxs, tmp_path, monkeypatch, env):
     """k_scanm<.., DROP>: pure-OR queries that mix dense terms (8 % of the docs and
     more) with sparse ones.  The dense lists are scanned only until the threshold
@@ -1148,6 +1152,13 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
             for kk in env:
                 monkeypatch.delenv(kk)
         gidx.reconfigure()
+        # TF-IDF: dense terms leave the scan on a capped ceiling + outlier lists; without them (accumulator tiles) the same bits
+        tf = gidx.search_batch(qs, limit=10, algo="TF-IDF", fuzzymatch=False)
+        monkeypatch.setenv("NXS_GPU_TFIDF_NODROP", "1")
+        gidx.reconfigure()
+        assert bits(gidx.search_batch(qs, limit=10, algo="TF-IDF", fuzzymatch=False)) == bits(tf)
+        monkeypatch.delenv("NXS_GPU_TFIDF_NODROP")
+        gidx.reconfigure()
         # a single-term query's scores are its list's largest impacts: the top-3 of top-10 and of top-1000 agree
         for q in (terms[0].decode(), terms[99].decode(), terms[4999].decode()):
             a, b = gidx.search(q, limit=10, fuzzymatch=False), gidx.search(q, fuzzymatch=False)
@@ -1156,6 +1167,8 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
         oidx = O.Index(c["terms"], c["dtmap"])
         for i in (0, 1, 2, 3, 510, 511, 1022, 1023):
             assert_same(base[i], oidx.search(qs[i], limit=10, fuzzymatch=False), qs[i])
+        for i in (1, 3, 511, 1023):
+            assert_same(tf[i], oidx.search(qs[i], algo=0, limit=10, fuzzymatch=False), (qs[i], "TF-IDF"))
         # ---- configs[3]: Levenshtein d <= 2 over the 1M-term BK-tree, batch 1024 ----
         toks = corpus.queries_fuzzy(terms, 1024, seed=4)
         ids = gidx.fuzzy(toks)

@@ -887,81 +887,90 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 			}
 		}
 	}
-	/* TF-IDF: cap + outlier list per dense term (nxsgpu_index::outl_off) */
+	/* TF-IDF: cap + outlier list per dense term (nxsgpu_index::outl_off).  Two host
+	 * round trips for all terms together: the tf histograms, then the lists. */
 	if (do_t) {
 		const size_t nc = ix->cfg.tfidf_drop ? ix->dense_terms.size() : 0;
 		const uint64_t room = post_elems(ix, NXSGPU_TF_IDF) - ix->cap_post;
-		uint32_t *d_hist = NULL, *d_cnt = NULL, *d_mx = NULL;
-		uint64_t at = ix->cap_post;
+		uint32_t *d_hist = NULL, *d_cnt = NULL, *d_res = NULL;	/* d_res: [nc] largest excess, [nc] postings written */
+		std::vector<uint32_t> hist(nc * 64), res(2 * nc, 0), tf_cap(nc, 0);
+		std::vector<uint64_t> above(nc, 0);
+		uint64_t at = ix->cap_post, max_nb = 1;
 		bool ok = true;
 
 		ix->outl_off.assign(nc + 1, at);
 		ix->outl_cap.assign(nc, 0.0f);
 		ix->outl_max.assign(nc, 0.0f);
+		for (size_t c = 0; c < nc; c++) {
+			const uint32_t t = ix->dense_terms[c];
+			max_nb = std::max<uint64_t>(max_nb, (ix->h_post_off[t + 1] - ix->h_post_off[t] + OUTL_CHUNK - 1) / OUTL_CHUNK);
+		}
 		if (nc) {
-			uint64_t max_df = 0;
-			for (size_t c = 0; c < nc; c++) {
-				const uint32_t t = ix->dense_terms[c];
-				max_df = std::max<uint64_t>(max_df, ix->h_post_off[t + 1] - ix->h_post_off[t]);
-			}
-			const uint64_t max_nb = (max_df + OUTL_CHUNK - 1) / OUTL_CHUNK;
-			ok = hipMalloc((void **)&d_hist, 64 * 4) == hipSuccess &&
+			ok = hipMalloc((void **)&d_hist, nc * 64 * 4) == hipSuccess &&
 			    hipMalloc((void **)&d_cnt, (max_nb + 1) * 4) == hipSuccess &&
-			    hipMalloc((void **)&d_mx, 4) == hipSuccess;
+			    hipMalloc((void **)&d_res, 2 * nc * 4) == hipSuccess &&
+			    hipMemsetAsync(d_hist, 0, nc * 64 * 4, ix->stream) == hipSuccess &&
+			    hipMemsetAsync(d_res, 0, 2 * nc * 4, ix->stream) == hipSuccess;
 		}
 		for (size_t c = 0; c < nc && ok; c++) {
 			const uint32_t t = ix->dense_terms[c];
 			const uint64_t p0 = ix->h_post_off[t], n = ix->h_post_off[t + 1] - p0;
 			const uint32_t nb = (uint32_t)((n + OUTL_CHUNK - 1) / OUTL_CHUNK);
-			uint32_t hist[64], tf_cap = 0, n_out = 0, mx = 0;
+			hipLaunchKernelGGL(k_tf_hist, dim3(std::min<uint32_t>(nb, 1024)), dim3(256), 0, ix->stream,
+			    ix->d_post_dt + p0, n, d_hist + c * 64);
+		}
+		if (nc && ok) {
+			ok = hipMemcpyAsync(hist.data(), d_hist, nc * 64 * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
+			    hipStreamSynchronize(ix->stream) == hipSuccess;
+		}
+		for (size_t c = 0; c < nc && ok; c++) {
+			const uint32_t t = ix->dense_terms[c];
+			const uint64_t p0 = ix->h_post_off[t], n = ix->h_post_off[t + 1] - p0;
+			const uint32_t nb = (uint32_t)((n + OUTL_CHUNK - 1) / OUTL_CHUNK);
+			const uint32_t *h = &hist[c * 64];
+			uint64_t ab = 0;
+			uint32_t cap = 1;
 
 			ix->outl_cap[c] = ix->h_maximp[NXSGPU_TF_IDF][t];
 			ix->outl_off[c] = at;
-			(void)hipMemsetAsync(d_hist, 0, 64 * 4, ix->stream);
-			hipLaunchKernelGGL(k_tf_hist, dim3(std::min<uint32_t>(nb, 1024)), dim3(256), 0, ix->stream,
-			    ix->d_post_dt + p0, n, d_hist);
-			ok = hipMemcpyAsync(hist, d_hist, 64 * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
-			    hipStreamSynchronize(ix->stream) == hipSuccess;
-			if (!ok) {
-				break;
-			}
 			/* the smallest tf that all but 1/outl_share of the postings stay at or below */
-			uint64_t above = 0;
 			for (int k = 63; k >= 1; k--) {
-				above += hist[k];
+				ab += h[k];
 			}
-			for (tf_cap = 1; tf_cap < 62 && above - hist[tf_cap] > n / ix->cfg.outl_share; tf_cap++) {
-				above -= hist[tf_cap];
+			for (; cap < 62 && ab - h[cap] > n / ix->cfg.outl_share; cap++) {
+				ab -= h[cap];
 			}
-			above -= hist[tf_cap];		/* postings with tf > tf_cap */
-			if (above == 0 || tf_cap >= 62 || at + above > ix->cap_post + room) {
+			ab -= h[cap];			/* postings with tf > cap */
+			if (ab == 0 || cap >= 62 || at + ab > ix->cap_post + room) {
 				continue;		/* no outliers (or no room): the cap is the largest impact */
 			}
-			const float cap_imp = (float)logtf[tf_cap] * idf_t[t];	/* k_impacts_csr's own expression */
-			(void)hipMemsetAsync(d_mx, 0, 4, ix->stream);
-			hipLaunchKernelGGL(k_outl_count, dim3(nb), dim3(256), 0, ix->stream, ix->d_post_dt + p0, n, tf_cap, d_cnt);
+			const float cap_imp = (float)logtf[cap] * idf_t[t];	/* k_impacts_csr's own expression */
+			tf_cap[c] = cap;
+			above[c] = ab;
+			hipLaunchKernelGGL(k_outl_count, dim3(nb), dim3(256), 0, ix->stream, ix->d_post_dt + p0, n, cap, d_cnt);
 			hipLaunchKernelGGL(k_outl_scan, dim3(1), dim3(1024), 0, ix->stream, d_cnt, nb);
 			hipLaunchKernelGGL(k_outl_write, dim3(nb), dim3(256), 0, ix->stream, ix->d_post_dt + p0,
-			    ix->d_post[NXSGPU_TF_IDF] + p0, n, tf_cap, cap_imp, d_cnt, ix->d_post[NXSGPU_TF_IDF] + at, d_mx);
-			ok = hipMemcpyAsync(&n_out, d_cnt + nb, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
-			    hipMemcpyAsync(&mx, d_mx, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
-			    hipStreamSynchronize(ix->stream) == hipSuccess && n_out == above;
-			if (!ok) {
-				break;
-			}
+			    ix->d_post[NXSGPU_TF_IDF] + p0, n, cap, cap_imp, d_cnt, ix->d_post[NXSGPU_TF_IDF] + at, d_res + c);
+			ok = hipMemcpyAsync(d_res + nc + c, d_cnt + nb, 4, hipMemcpyDeviceToDevice, ix->stream) == hipSuccess;
 			ix->outl_cap[c] = cap_imp;
-			memcpy(&ix->outl_max[c], &mx, 4);
-			at += n_out;
+			at += ab;
 		}
-		for (size_t c = 0; c <= nc; c++) {
-			if (c == nc || ix->outl_off[c] > at) {
-				ix->outl_off[c] = at;
-			}
+		ix->outl_off[nc] = at;
+		if (nc && ok) {
+			ok = hipMemcpyAsync(res.data(), d_res, 2 * nc * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess &&
+			    hipStreamSynchronize(ix->stream) == hipSuccess;
 		}
+		for (size_t c = 0; c < nc && ok; c++) {
+			memcpy(&ix->outl_max[c], &res[c], 4);
+			ok = res[nc + c] == above[c];		/* the compaction wrote what the histogram promised */
+		}
+		(void)tf_cap;
 		(void)hipFree(d_hist);
 		(void)hipFree(d_cnt);
-		(void)hipFree(d_mx);
+		(void)hipFree(d_res);
 		if (!ok) {
+			ix->outl_off.assign(nc + 1, ix->cap_post);	/* no outlier lists: the caps must not be used */
+			ix->outl_cap.clear();
 			set_error("outlier lists of the dense terms failed");
 			goto fail;
 		}

@@ -340,17 +340,29 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_extras:
             out.update(side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev))
-        if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, info, queries, idx, fuzzy_on, work)
         if not args.no_extras:
+            # N1 on a private copy of the two index files, with an index of its own: the measurement
+            # modifies them like an indexer would, and it runs BEFORE the CPU baseline (whose 256
+            # forked workers leave the parent's first large device allocation 10x slower)
+            rwork = os.path.join(work, "refresh_copy")
             try:
-                out["refresh"] = refresh_measurements(args, idx, info, terms)
+                os.makedirs(rwork, exist_ok=True)
+                rinfo = dict(info)
+                for k in ("terms", "dtmap"):
+                    rinfo[k] = os.path.join(rwork, os.path.basename(info[k]))
+                    shutil.copyfile(info[k], rinfo[k])
+                rnxs = N.Nxs(rwork)
+                ridx = rnxs.open_files(rinfo["terms"], rinfo["dtmap"], algo="BM25")
+                try:
+                    out["refresh"] = refresh_measurements(args, ridx, rinfo, terms)
+                finally:
+                    ridx.close()
+                    rnxs.close()
             except Exception as e:        # a side measurement never costs the run
                 out["refresh"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:
-                os.unlink(marker)             # the corpus files were modified: do not reuse them
-            except OSError:
-                pass
+            shutil.rmtree(rwork, ignore_errors=True)
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, info, queries, idx, fuzzy_on, work)
     barrier()
     L.nxs_params_release(params)
     idx.close()
@@ -604,7 +616,7 @@ def refresh_measurements(args, idx, info, terms):
     """N1: what one appended / removed document costs the NEXT search (the
     reference re-syncs before every search, search.c:309-312).  The corpus files
     are modified in place like an indexer process would: block first, header
-    counters and data_len last.  Runs last: the corpus is not pristine after it."""
+    counters and data_len last.  The files are not pristine after it: the caller hands in a private copy."""
     import struct
     import ctypes as C
     import nxsearch_amd as N

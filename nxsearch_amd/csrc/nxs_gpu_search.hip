@@ -365,6 +365,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		a.retry_cap = retry ? RETRY_CAP : 0;
 		/* the ranges whose pending list overflowed, once more on the accumulator
 		 * tiles: a fixed, small grid whose wavefronts beyond the list's end return */
+		bool retry_pending = false;
 		auto launch_retry = [&](hipStream_t st) {
 			if (retry) {
 				scan_args_t a2 = a;
@@ -399,7 +400,13 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		} else if (l.kind == 4) {
 			if (topk64) {
 				nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
-				launch_retry(ix->stream);
+				/* (the second chance of its overflowed ranges: in front of the class's heap
+				 * replay, on the replay's stream -- not in front of the next class's scan) */
+				retry_pending = retry;
+				if (!(ra && l.q_count)) {
+					launch_retry(ix->stream);
+					retry_pending = false;
+				}
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, l.nomask == 1 ? 1u : 0u, grid, ix->stream, a);
 			}
@@ -422,6 +429,9 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			if (&l == last_launch && !replays_aside) {
 				/* nothing left to run beside it: same stream, no event
 				 * round trip (a single query has only this one) */
+				if (retry_pending) {
+					launch_retry(ix->stream);
+				}
 				if (scans_done) {
 					(void)hipEventRecord(scans_done, ix->stream);
 					scans_done = NULL;
@@ -430,9 +440,13 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				(void)hipEventRecord(ix->ev_cls, ix->stream);
 				(void)hipStreamWaitEvent(st_rp, ix->ev_cls, 0);
+				if (retry_pending) {
+					launch_retry(st_rp);
+				}
 				nxs_launch_replay(heap, l.q_count, heap_lds, st_rp, r);
 				forked = true;
 			}
+			retry_pending = false;
 		}
 	}
 	if (scans_done) {

@@ -204,6 +204,24 @@ k_scan1(const scan_args_t A)
  *    threshold filter / candidate emission as the other scan kernels; lanes
  *    are in ascending doc order, so emission is by descending lane.
  */
+#ifdef NXS_STATS
+/* diagnostic build only: k_scanr event counts (tools/scanr_stats.py) */
+__device__ unsigned long long g_stats_req[16];
+#define	RSTAT(i, v)	do { if (lane == 0) atomicAdd(&g_stats_req[i], (unsigned long long)(v)); } while (0)
+extern "C" void
+nxsgpu_debug_stats_req(unsigned long long *out, int reset)
+{
+	unsigned long long z[16] = { 0 };
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_req), sizeof(z));
+	if (reset) {
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats_req), z, sizeof(z));
+	}
+}
+#else
+#define	RSTAT(i, v)	do { } while (0)
+#endif
+
 #ifndef RW
 #define	RW	4096		/* docs per round span (LDS byte map; SCANR_HASH 0) */
 #endif
@@ -360,7 +378,9 @@ k_scanr(const scan_args_t A)
 	bool done = false;		/* a required slot ran out: nothing below can match */
 	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
 
+	RSTAT(0, 1);
 	while (!done && pdoc[0] >= 0) {
+		RSTAT(1, 1);
 		const int32_t dtop = pdoc[0];
 		const uint32_t base = HASH ? 0u : (uint32_t)dtop & ~(uint32_t)(RW - 1);
 		/* the driver's postings of this round: its whole window (HASH), or those
@@ -395,6 +415,7 @@ k_scanr(const scan_args_t A)
 		const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)Ad[0], __builtin_ctzll(inm0));
 		uint64_t alive = inm0;
 
+		RSTAT(2, __popcll(inm0));
 		vm[0] ^= inm0;
 		if constexpr (!HASH) {
 			s_mark[dd0] = in0 ? (uint8_t)(lane + 1) : (uint8_t)0;
@@ -407,6 +428,7 @@ k_scanr(const scan_args_t A)
 			constexpr int j = decltype(jc)::value + 1;
 			using JC = std::integral_constant<int, j>;
 			if (j < (int)nt && alive && !done) {
+				RSTAT(3 + (j > 1 ? 1 : 0), 1);
 				/* nothing above the driver's top doc can match: drop it unread */
 				if (pdoc[j] > dtop) {
 					for (int tries = 0; ; tries++) {
@@ -415,6 +437,7 @@ k_scanr(const scan_args_t A)
 							break;		/* the boundary is in this window / list exhausted */
 						}
 						if (tries < 2) {
+							RSTAT(5, 1);
 							rotate_sets(JC());	/* stream a little ... */
 							continue;
 						}
@@ -432,6 +455,7 @@ k_scanr(const scan_args_t A)
 							const int32_t far = max(li - WAVE * WAVE, lo[j]);
 							nh = far > lo[j] ? wave_lower_bound(pt[j], lo[j], far, (uint32_t)dtop + 1) : lo[j];
 						}
+						RSTAT(6, 1);
 						load_sets(JC(), nh);
 						tries = 2;
 						if (nh <= lo[j]) {
@@ -479,6 +503,7 @@ k_scanr(const scan_args_t A)
 							}
 						}
 						if (left == 0 && ab[j] > lo[j]) {
+							RSTAT(7, 1);
 							rotate_sets(JC());
 							left = vm[j];
 							continue;
@@ -505,6 +530,8 @@ k_scanr(const scan_args_t A)
 		});
 
 		if (alive) {
+			RSTAT(8, 1);
+			RSTAT(9, __popcll(alive));
 			const bool al = lane_of(alive);
 			const uint32_t mask = al ? s_bits[lane] : 0;
 			const bool match = al && ((s_truth[mask >> 5] >> (mask & 31)) & 1);

@@ -499,6 +499,11 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
     B.nxs_bench_batches(idx._h, p, qarr, nq, 2, 1, C.byref(o))
     B.nxs_bench_batches(idx._h, p, qarr, nq, 10, 1, C.byref(o))
     res["blocking_qps"] = round(nq * 10 / o.seconds, 1)
+    # (2b) the pipelined loop on ONE repeated batch (what rounds 1-2 reported as `value`,
+    #      before the timed loop rotated seed-distinct batches): for comparison only
+    B.nxs_bench_batches(idx._h, p, qarr, nq, 3, 2, C.byref(o))
+    B.nxs_bench_batches(idx._h, p, qarr, nq, args.steps, 2, C.byref(o))
+    res["repeated_batch_qps"] = round(nq * args.steps / o.seconds, 1)
 
     # (3) single-query latency: nxs_index_search(), one term of rank uniform in
     #     [10, 10^4], top-k, n = 1000, timed inside the C consumer

@@ -82,6 +82,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.mask_off = !on("NXS_GPU_NOMASKOFF");
 	c.by_level = !on("NXS_GPU_NOLEVELS");
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
+	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
 	c.tfidf_drop = !on("NXS_GPU_TFIDF_NODROP");

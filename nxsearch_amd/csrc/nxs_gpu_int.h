@@ -12,6 +12,8 @@
  *  nxs_gpu_scan_mask.hip  k_scanm / k_cold: OR-like queries of sparse terms, a
  *                         quantised score bound per doc in LDS, exact sums only
  *                         for the docs that can beat the threshold
+ *  nxs_gpu_scan_bit.hip   k_scanb: the same class on one presence BIT per doc pair (64k-doc tiles),
+ *                         candidates scored one per lane by lower-bound searches (the default)
  *  nxs_gpu_scan_grid.hip  k_scang: the mask path over a doc grid (all terms' postings of a
  *                         part in one run of slots): opt-in alternative to k_scanm
  *  nxs_gpu_scan_req.hip   k_cursors, k_scan1 (one token), k_scanr (required
@@ -137,6 +139,8 @@ struct gpu_cfg_t {
 	uint32_t	outl_share;	/* NXS_GPU_OUTL_SHARE (8): at most 1/this of a dense term's postings are outliers */
 	bool		replay_join;	/* NXS_GPU_REPLAY_JOIN: the scan stream waits for a batch's last heap replay (limits <= 64) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
+	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's plain class on the presence-bit kernel (k_scanb);
+					 * off: the byte-bound kernel (k_scanm), the forced variant of the tests */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
 					 * (k_scanm) -- measured slower on C3, kept as a tested alternative */
 };
@@ -445,6 +449,8 @@ void	nxs_launch_scan_generic(int mode, bool wide_mask, unsigned grid, hipStream_
 void	nxs_launch_scan8(int mode, uint32_t nt_bucket, uint32_t mm, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
+/* the mask path on presence bits, candidates scored one per lane (k_scanb) */
+void	nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the same two on the doc grid (k_scang; scan_args_t::flags bit 2 routes the launchers above here) */
 void	nxs_launch_scang(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a);

@@ -399,7 +399,11 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			}
 		} else if (l.kind == 4) {
 			if (topk64) {
-				nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
+				if (ix->cfg.use_scanb && !(a.flags & 4)) {
+					nxs_launch_scanb(l.nt_bucket, l.nomask != 1, false, grid, ix->stream, a);
+				} else {
+					nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
+				}
 				/* (the second chance of its overflowed ranges: in front of the class's heap
 				 * replay, on the replay's stream -- not in front of the next class's scan) */
 				retry_pending = retry;
@@ -589,6 +593,20 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 		}
 		/* k_scanr slot order: required tokens first, shortest list first */
 		d.n_req = 0;
+		if (!d.req && d.nt <= 8) {
+			/* k_scanb slot order: ascending largest impact -- the commonest term first, so
+			 * that the postings that are many meet the bound that is sharp */
+			uint32_t ord[8];
+			for (uint32_t t = 0; t < d.nt; t++) {
+				ord[t] = t;
+			}
+			std::sort(ord, ord + d.nt, [&](uint32_t x, uint32_t y) {
+				return d.tmax[x] != d.tmax[y] ? d.tmax[x] < d.tmax[y] : x < y;
+			});
+			for (uint32_t t = 0; t < d.nt; t++) {
+				d.slot_tok[t] = (uint8_t)ord[t];
+			}
+		}
 		if (d.req && d.nt <= 8) {
 			uint32_t ord[8];
 			for (uint32_t t = 0; t < d.nt; t++) {

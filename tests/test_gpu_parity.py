@@ -485,6 +485,9 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 # the byte-bound mask kernel (k_scanm; the default is the presence-bit kernel, k_scanb)
+                                 {"NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  # the mask path walked over a doc grid (k_scang), with and without dense terms leaving
                                  {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
@@ -516,6 +519,7 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
 
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
                                  {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
                                  {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
@@ -542,16 +546,21 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     gidx.close()
 
 
+@pytest.mark.parametrize("kern", ["scanb", "scanm"])
 @pytest.mark.parametrize("seed,n_docs,vocab_n,max_len", [
     (11, 3000, 12, 6),       # tiny vocabulary: massive score ties, every term dense
     (12, 40000, 400, 10),    # Zipf vocabulary: sparse and dense terms in one query
     (13, 150000, 5000, 8),   # mostly sparse terms: wide tiles, few candidates
 ])
-def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len):
-    """k_scanm (quantised score bounds in a byte per doc + exact scores from the
-    register windows) forced for every pure-OR query of 2..8 tokens, whatever
-    the density of its terms: identical ids, order and score bits."""
+def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len, kern):
+    """The mask path -- k_scanb (a presence bit per doc pair, candidates scored one
+    per lane by lower-bound searches; the default) and k_scanm (quantised score
+    bounds in a byte per doc + exact scores from the register windows) -- forced
+    for every pure-OR query of 2..8 tokens, whatever the density of its terms:
+    identical ids, order and score bits."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    if kern == "scanm":
+        monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
     rng = random.Random(seed)
     vocab = ["w%d" % i for i in range(vocab_n)]
     weights = [1.0 / (i + 1) for i in range(vocab_n)]
@@ -572,11 +581,14 @@ def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, voc
     gidx.close()
 
 
-def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch):
+@pytest.mark.parametrize("kern", ["scanb", "scanm"])
+def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch, kern):
     """The highest docs all hold every query term: the cold-start tile pushes
     more docs than the pending list takes, the query is flagged and re-run on
     the exact two-pass path."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    if kern == "scanm":
+        monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
     rng = random.Random(5)
     vocab = ["w%d" % i for i in range(50)]
     docs = random_corpus(rng, 4000, vocab, max_len=6)

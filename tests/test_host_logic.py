@@ -398,6 +398,8 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
     ring8 = int(re.search(r"#define\s+SCAN8_RING_MAX\s+(\d+)", src).group(1))
     ringm = int(re.search(r"#define\s+SCANM_RING\s+(\d+)", src).group(1))
     ringr = int(re.search(r"#define\s+SCANR_RING\s+(\d+)", src).group(1))
+    srcb = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu_scan_bit.hip")).read()
+    ringb = int(re.search(r"#define\s+SB_RING\s+(\d+)", srcb).group(1))
     so = shutil.copy(N.LIB_PATH, str(tmp_path / "lib.so"))
     subprocess.run([llvm + "/llvm-objdump", "--offloading", so], check=True, capture_output=True)
     co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
@@ -410,6 +412,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
         k8 = re.match(r"_Z7k_scan8ILi\d+ELi(\d+)ELi(\d+)EE", name)
         kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)ELb[01]EE", name)
         km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]ELb[01]EE", name)
+        kb = re.match(r"_Z7k_scanbILi(\d+)ELb[01]ELb[01]EE", name)
         if k8:
             nt, mm = int(k8.group(1)), int(k8.group(2))
             want = 2 * ring8 * nt if (nt >= 3 and mm != 2) else 0
@@ -417,6 +420,8 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
             want = 2 * ringr * int(kr.group(1))
         elif km:
             want = 2 * ringm * int(km.group(1))
+        elif kb:
+            want = 2 * ringb * int(kb.group(1))
         else:
             continue
         seen += 1

@@ -83,6 +83,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.by_level = !on("NXS_GPU_NOLEVELS");
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
+	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
 	c.tfidf_drop = !on("NXS_GPU_TFIDF_NODROP");

@@ -139,8 +139,8 @@ struct gpu_cfg_t {
 	uint32_t	outl_share;	/* NXS_GPU_OUTL_SHARE (8): at most 1/this of a dense term's postings are outliers */
 	bool		replay_join;	/* NXS_GPU_REPLAY_JOIN: the scan stream waits for a batch's last heap replay (limits <= 64) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
-	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's plain class on the presence-bit kernel (k_scanb);
-					 * off: the byte-bound kernel (k_scanm), the forced variant of the tests */
+	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
+	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
 					 * (k_scanm) -- measured slower on C3, kept as a tested alternative */
 };

@@ -112,6 +112,13 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt &&
 			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
 				cls[i] = 4u * 64 + (or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
+				/* ... on presence bits (k_scanb) where that kernel is the faster one: its cost per
+				 * posting does not fall with the lists' density as the byte map's does, so it
+				 * takes the queries whose lists TOGETHER hold few docs (measured cross-over on
+				 * 10M docs: 5-term ORs of rank 500-1000 -29 %, of rank 100-1000 +9 %) */
+				if (cf.use_scanb && hq[i].nt <= 5 && (double)w <= cf.scanb_dens * (double)ix->n_docs) {
+					cls[i] += 2u * 64;
+				}
 			} else if (tile && or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
 				/*
@@ -175,7 +182,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
 	/* (the sparse + dense class leads: it runs on a stream of its own, beside the rest) */
-	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 4 ? 64 + (c & 63) : c + 256; };
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 4 ? 64 + (c & 63) : (c >> 6) == 6 ? 128 + (c & 63) : c + 256; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
 		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
@@ -359,7 +366,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		    !(l.kind == 5 && a0.dense_col == ix->d_dense_col[NXSGPU_TF_IDF]) ? 4u : 0u;	/* (nor outlier lists) */
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
-		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5);
+		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6);
 		a.retry_count = retry ? a0.retry_count + li : NULL;
 		a.retry_items = retry ? a0.retry_items + li * RETRY_CAP : NULL;
 		a.retry_cap = retry ? RETRY_CAP : 0;
@@ -397,9 +404,9 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, l.nt_bucket == 1 ? 0u : l.nomask, grid, ix->stream, a);
 			}
-		} else if (l.kind == 4) {
+		} else if (l.kind == 4 || l.kind == 6) {
 			if (topk64) {
-				if (ix->cfg.use_scanb && !(a.flags & 4)) {
+				if (l.kind == 6) {
 					nxs_launch_scanb(l.nt_bucket, l.nomask != 1, false, grid, ix->stream, a);
 				} else {
 					nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);

@@ -485,9 +485,11 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
-                                 # the byte-bound mask kernel (k_scanm; the default is the presence-bit kernel, k_scanb)
-                                 {"NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 # the mask path's two kernels: presence bits (k_scanb: by default only the sparsest
+                                 # queries) for everything up to 5 tokens / the byte map (k_scanm) for everything
+                                 {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_NOSCANB": "1"},
                                  # the mask path walked over a doc grid (k_scang), with and without dense terms leaving
                                  {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
@@ -519,7 +521,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
 
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
                                  {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_NOSCANB": "1", "NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
+                                 {"NXS_GPU_NOSCANB": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
                                  {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
@@ -553,12 +556,13 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     (13, 150000, 5000, 8),   # mostly sparse terms: wide tiles, few candidates
 ])
 def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len, kern):
-    """The mask path -- k_scanb (a presence bit per doc pair, candidates scored one
-    per lane by lower-bound searches; the default) and k_scanm (quantised score
-    bounds in a byte per doc + exact scores from the register windows) -- forced
-    for every pure-OR query of 2..8 tokens, whatever the density of its terms:
-    identical ids, order and score bits."""
+    """The mask path -- k_scanb (a presence bit per four docs, the windows' docs staged
+    in LDS, candidates scored by lower-bound searches there; 2..5 tokens) and
+    k_scanm (quantised score bounds in a byte per doc + exact scores from the
+    register windows) -- forced for every pure-OR query of 2..8 tokens, whatever
+    the density of its terms: identical ids, order and score bits."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    monkeypatch.setenv("NXS_GPU_SCANB_DENS", "1.0")
     if kern == "scanm":
         monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
     rng = random.Random(seed)
@@ -587,6 +591,7 @@ def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch, kern)
     more docs than the pending list takes, the query is flagged and re-run on
     the exact two-pass path."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
+    monkeypatch.setenv("NXS_GPU_SCANB_DENS", "1.0")
     if kern == "scanm":
         monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
     rng = random.Random(5)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# wait / busy / LDS counters of the scan kernels on the C3 bench (GPU box). usage: tools/pmc_probe.sh [ENV=val ...]
+set -u
+out=$PWD/gpurun_out/pmcp
+rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+for kv in "$@"; do export $kv; done
+B="python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-extras"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$out/a" -o run -- $B > /dev/null 2> "$out/a.log" &&
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --output-format csv -d "$out/b" -o run -- $B > /dev/null 2> "$out/b.log" &&
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --output-format csv -d "$out/c" -o run -- $B > /dev/null 2> "$out/c.log"
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+for k in acc:
+    if "k_scan" not in k and "k_cold" not in k: continue
+    print(k[:44], " ".join("%s=%.1fM" % (c.replace("SQ_", ""), v / max(n[k][c], 1) / 1e6) for c, v in sorted(acc[k].items())))
+PY

@@ -82,6 +82,9 @@ cfg_from_env(gpu_cfg_t &c)
 	c.mask_off = !on("NXS_GPU_NOMASKOFF");
 	c.by_level = !on("NXS_GPU_NOLEVELS");
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
+	c.use_blkmap = !on("NXS_GPU_NOBLKMAP");
+	c.bm_share = u64("NXS_GPU_BM_SHARE", 1024, 1, 1u << 30);
+	c.bm_gain = dbl("NXS_GPU_BM_GAIN", 16.0);
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
@@ -259,6 +262,59 @@ k_dense_fill(const posting_t *__restrict__ post, uint64_t beg, uint64_t end, uin
 	for (uint64_t i = beg + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
 		const posting_t p = post[i];
 		col[p.doc] = __float_as_uint(p.imp);
+	}
+}
+
+/*
+ * Block-presence bitmap + rank directory of one list (d_blkmap / d_bmrank rows): a thread takes
+ * CH consecutive postings, ORs their block bits into the word it is in and writes that word
+ * (atomically: neighbours share words) whenever it changes; a posting that is the first of its
+ * 4096-doc word -- its predecessor lies in an earlier word -- records its position for that word
+ * and for the empty words in between.
+ */
+__global__ void
+k_blkmap_fill(const uint64_t *__restrict__ post_dt, const uint64_t *__restrict__ rows_beg,
+    const uint64_t *__restrict__ rows_end, uint64_t words, unsigned long long *__restrict__ blkmap,
+    uint32_t *__restrict__ bmrank)
+{
+	constexpr uint32_t CH = 16;
+	const uint32_t row = blockIdx.y;
+	const uint64_t beg = rows_beg[row], end = rows_end[row];
+	unsigned long long *bm = blkmap + (uint64_t)row * words;
+	uint32_t *rk = bmrank + (uint64_t)row * (words + 1);
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * CH;
+
+	for (uint64_t i0 = beg + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH; i0 < end; i0 += stride) {
+		const uint64_t i1 = min(i0 + CH, end);
+		uint64_t cw = ~0ull, acc = 0;
+		uint64_t pw = i0 > beg ? (post_dt[i0 - 1] >> 32) >> 12 : ~0ull;	/* word of the predecessor */
+		for (uint64_t i = i0; i < i1; i++) {
+			const uint32_t doc = (uint32_t)(post_dt[i] >> 32);
+			const uint64_t w = doc >> 12;
+			if (w != cw) {
+				if (acc) {
+					atomicOr(&bm[cw], (unsigned long long)acc);
+				}
+				cw = w;
+				acc = 0;
+			}
+			acc |= 1ull << ((doc >> 6) & 63);
+			if (w != pw) {
+				/* first posting of word w: it starts w and every empty word after pw */
+				for (uint64_t e = (pw == ~0ull ? 0 : pw + 1); e <= w; e++) {
+					rk[e] = (uint32_t)(i - beg);
+				}
+				pw = w;
+			}
+		}
+		if (acc) {
+			atomicOr(&bm[cw], (unsigned long long)acc);
+		}
+		if (i1 == end) {
+			for (uint64_t e = pw + 1; e <= words; e++) {
+				rk[e] = (uint32_t)(end - beg);
+			}
+		}
 	}
 }
 
@@ -550,6 +606,8 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	(void)hipFree(ix->d_post[1]);
 	(void)hipFree(ix->d_dense_col[0]);
 	(void)hipFree(ix->d_dense_col[1]);
+	(void)hipFree(ix->d_blkmap);
+	(void)hipFree(ix->d_bmrank);
 	(void)hipFree(ix->d_bk);
 	(void)hipFree(ix->d_bk_bytes);
 	bk_aux_free(ix);
@@ -814,6 +872,9 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 		ix->h_maximp[NXSGPU_TF_IDF].assign((size_t)T + 2, 0.0f);
 	}
 	if (P == 0 || (!do_b && !do_t)) {
+		if (only == 3) {
+			ix->bm_terms.clear();
+		}
 		return 0;
 	}
 	HIP_TRY(hipMalloc(&d_logtf, logtf.size() * 8));
@@ -886,6 +947,70 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 				}
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamSynchronize(ix->stream));
+			}
+		}
+	}
+	/* block-presence bitmaps + rank directories of the longer lists (they depend on the
+	 * postings alone: rebuilt at build and refresh, not when a second ranking function is
+	 * materialised) */
+	if (only == 3) {
+		const uint64_t words = (ix->n_docs + 4095) / 4096;
+		const uint64_t min_df = std::max<uint64_t>(1, ix->n_docs / std::max<uint64_t>(ix->cfg.bm_share, 1));
+		std::vector<std::pair<uint64_t, uint32_t>> bt;
+		ix->bm_terms.clear();
+		ix->bm_words = words;
+		if (ix->cfg.use_blkmap && ix->n_docs < (1ull << 31) && ix->n_post < (1ull << 32)) {
+			for (uint32_t t = 1; t <= T; t++) {
+				const uint64_t df = ix->h_post_off[t + 1] - ix->h_post_off[t];
+				if (df >= min_df) {
+					bt.push_back(std::make_pair(df, t));
+				}
+			}
+			std::sort(bt.begin(), bt.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
+				return x.first != y.first ? x.first > y.first : x.second < y.second;
+			});
+			if (bt.size() > 8192) {
+				bt.resize(8192);
+			}
+			for (auto &e : bt) {
+				ix->bm_terms.push_back(e.second);
+			}
+			std::sort(ix->bm_terms.begin(), ix->bm_terms.end());
+		}
+		const size_t rows = ix->bm_terms.size();
+		if (rows) {
+			const uint64_t need = (uint64_t)rows * (words + 1);
+			uint64_t *d_rows = NULL;
+			if (need > ix->bm_cap) {
+				(void)hipFree(ix->d_blkmap);
+				(void)hipFree(ix->d_bmrank);
+				ix->d_blkmap = NULL;
+				ix->d_bmrank = NULL;
+				ix->bm_cap = 0;
+				const uint64_t cap = need + need / 8 + 64;
+				HIP_TRY(hipMalloc((void **)&ix->d_blkmap, cap * 8));
+				HIP_TRY(hipMalloc((void **)&ix->d_bmrank, cap * 4));
+				ix->bm_cap = cap;
+			}
+			std::vector<uint64_t> rb(2 * rows);
+			for (size_t r = 0; r < rows; r++) {
+				rb[r] = ix->h_post_off[ix->bm_terms[r]];
+				rb[rows + r] = ix->h_post_off[ix->bm_terms[r] + 1];
+			}
+			HIP_TRY(hipMalloc((void **)&d_rows, rb.size() * 8));
+			if (hipMemcpyAsync(d_rows, rb.data(), rb.size() * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+			    hipMemsetAsync(ix->d_blkmap, 0, (uint64_t)rows * words * 8, ix->stream) != hipSuccess) {
+				(void)hipFree(d_rows);
+				set_error("block bitmaps: upload failed");
+				goto fail;
+			}
+			hipLaunchKernelGGL(k_blkmap_fill, dim3(64, (unsigned)rows), dim3(256), 0, ix->stream,
+			    ix->d_post_dt, d_rows, d_rows + rows, words, (unsigned long long *)ix->d_blkmap, ix->d_bmrank);
+			const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ix->stream);
+			(void)hipFree(d_rows);
+			if (e1 != hipSuccess || e2 != hipSuccess) {
+				set_error("k_blkmap_fill failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+				goto fail;
 			}
 		}
 	}

@@ -17,7 +17,8 @@
  *  nxs_gpu_scan_grid.hip  k_scang: the mask path over a doc grid (all terms' postings of a
  *                         part in one run of slots): opt-in alternative to k_scanm
  *  nxs_gpu_scan_req.hip   k_cursors, k_scan1 (one token), k_scanr (required
- *                         terms: intersect first)
+ *                         terms: intersect first), k_scanq (the same through
+ *                         block-presence bitmaps: postings of surviving blocks only)
  *  nxs_gpu_replay.hip     k_replay: the reference's capped min-heap + heapsort
  *                         (heap.c:58-221; results.c:165-220) replayed exactly
  *  nxs_gpu_wide.hip       k_scanw: queries beyond the fixed-size plan
@@ -100,6 +101,7 @@ struct dev_query_t {
 					 * above tcap, impact = the excess over it): scanned like a sparse term for the
 					 * bounds, never for the exact score (that comes from the column) */
 	uint32_t	outl_tfidf;	/* host only: the dropped tokens have outlier lists to put in place (build_worklist) */
+	uint32_t	bm_col[8];	/* k_scanq: the token's block-presence bitmap (nxsgpu_index::d_blkmap row), ~0 = none */
 	uint32_t	qflags;		/* bit 0: no second chance on the accumulator tiles (pbeg / pend are not the
 					 * terms' lists) -- an overflowing range flags the query for the exact passes */
 	uint8_t		prog[NXSGPU_MAX_PROG];
@@ -139,6 +141,10 @@ struct gpu_cfg_t {
 	uint32_t	outl_share;	/* NXS_GPU_OUTL_SHARE (8): at most 1/this of a dense term's postings are outliers */
 	bool		replay_join;	/* NXS_GPU_REPLAY_JOIN: the scan stream waits for a batch's last heap replay (limits <= 64) */
 	bool		down_inline;	/* NXS_GPU_DOWN_INLINE: sharded runs also keep everything on one stream */
+	bool		use_blkmap;	/* !NXS_GPU_NOBLKMAP: block-presence bitmaps for the longer lists; conjunctions whose
+					 * required terms all have one intersect THOSE first (k_scanq) */
+	uint64_t	bm_share;	/* NXS_GPU_BM_SHARE (1024): a term gets a bitmap if it holds >= n_docs / this docs */
+	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
@@ -242,6 +248,20 @@ struct nxsgpu_index {
 	std::vector<float> outl_cap;		/* [columns] the cap (== the largest impact: no outlier list) */
 	std::vector<float> outl_max;		/* [columns] largest excess over the cap */
 
+	/*
+	 * Block-presence bitmaps (the reference intersects roaring bitmaps before it looks at
+	 * a posting, search.c:118-174): per term holding >= n_docs / cfg.bm_share docs, one bit
+	 * per 64-doc block -- is there a posting in [64 b, 64 b + 64)? -- and, per 4096-doc word
+	 * of that map, the list position of the first posting at or above the word's first doc
+	 * (a rank directory: a block's postings are found by a search inside one word's span).
+	 * Rebuilt with the impacts at every refresh (one pass over the lists that have one).
+	 */
+	std::vector<uint32_t> bm_terms;		/* ascending term ids; row = position */
+	uint64_t *	d_blkmap;		/* [rows][bm_words] */
+	uint32_t *	d_bmrank;		/* [rows][bm_words + 1] */
+	uint64_t	bm_words;		/* ceil(n_docs / 4096) */
+	uint64_t	bm_cap;			/* allocated rows x words (grow-only) */
+
 	nxsgpu_bknode_t *d_bk;
 	uint8_t *	d_bk_bytes;
 	uint32_t	n_bk, bk_depth;
@@ -333,6 +353,9 @@ struct scan_args_t {
 	uint32_t		retry_cap;
 	uint32_t *		cold_state;	/* [segments][16]: what k_cold hands to k_scanm<.., DROP> */
 	float *			cold_top;	/* [segments][64]: its running top-k scores */
+	const uint64_t *	blkmap;		/* k_scanq: block-presence bitmaps [row][bm_words] and ... */
+	const uint32_t *	bmrank;		/* ... their rank directories [row][bm_words + 1] */
+	uint64_t		bm_words;
 	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
 						 * 0xffffffff = the doc does not hold the term */
 	uint64_t		dense_stride;
@@ -455,6 +478,8 @@ void	nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hi
 void	nxs_launch_scang(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStream_t st, const scan_args_t &a);
+/* conjunctions whose required terms all have a block bitmap: intersect the bitmaps, look only at surviving blocks */
+void	nxs_launch_scanq(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanh(int mode, uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_replay(int heap, unsigned grid, size_t dyn_lds, hipStream_t st, const replay_args_t &r);
 

@@ -615,6 +615,314 @@ k_scanr(const scan_args_t A)
 	}
 }
 
+/*
+ * k_scanq: conjunctions whose required terms all have a BLOCK-PRESENCE BITMAP (one bit per
+ * 64-doc block, nxsgpu_index::d_blkmap).  The reference intersects the terms' roaring bitmaps
+ * before it looks at a single posting (get_expr_bitmap, search.c:118-174); k_scanr does that
+ * on posting windows and still streams the driver list (0.65 GB per C3 step for 512 five-term
+ * ANDs that return one result in total).  Here the summaries are intersected first:
+ *
+ *  1. lane L ANDs word (top - L) of the required terms' bitmaps (64 blocks = 4096 docs per
+ *     word, 8 B per term): the surviving blocks -- around 1 % of them for C3's ANDs -- go to
+ *     an LDS list in descending order;
+ *  2. one LANE per surviving block: the driver's (slot 0: the shortest required list)
+ *     postings inside the block -- one or two -- are found by a lower-bound search inside the
+ *     span of ONE bitmap word (the term's rank directory, d_bmrank), and each of their docs is
+ *     looked up in the other required lists the same way, shortest list first, until one
+ *     lacks it: nearly every surviving block ends there, after two searches;
+ *  3. a doc that holds every required term (rare) also gets the optional tokens' impacts,
+ *     sums them in token order (results.c:134-136), applies the truth table and the
+ *     threshold, and waits in an LDS list; a round's matches are sorted by descending doc,
+ *     emitted, and fed to the top-k register.
+ * Every token counts towards a doc's score whatever its role (search.c:240-253); only the
+ * REQUIRED ones take part in steps 1 and 2.  Top-k filter pass (k <= 64) only; the other
+ * passes of these queries take k_scanr.
+ */
+#define	SQ_CAP	64		/* surviving blocks per round: one per lane */
+#define	SQ_MCAP	128		/* matches of a round */
+
+template <int NT>
+__global__ void __launch_bounds__(WAVE)
+k_scanq(const scan_args_t A)
+{
+	__shared__ uint32_t s_blk[SQ_CAP];
+	__shared__ float s_imp[NT][WAVE];	/* [token][lane]: the impacts of the doc the lane is looking at */
+	__shared__ uint32_t s_mdoc[SQ_MCAP];
+	__shared__ float s_msc[SQ_MCAP];
+	__shared__ uint32_t s_truth[8];
+
+	const unsigned lane = threadIdx.x;
+	const item_t item = A.items[A.item_base + blockIdx.x];
+	const uint32_t q = item.q, g = item.g;
+	const qmeta_t qm = A.qmeta[q];
+	const dev_query_t *Q = &A.queries[q];
+	const uint32_t nt = Q->nt;
+	const uint32_t n_req = Q->n_req;	/* slots [0, n_req) are the required tokens, shortest list first */
+	const uint64_t seg = (uint64_t)qm.seg_first + g;
+	const uint32_t d_bot = (uint32_t)min((uint64_t)g * qm.group_docs, A.n_docs);
+	const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
+	    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
+
+	if (lane < 8) {
+		s_truth[lane] = Q->truth[lane];
+	}
+	/* per SLOT (k_scanr's order: dev_query_t::slot_tok) */
+	const posting_t *pt[NT];
+	int32_t lo[NT], hi[NT];
+	uint32_t tok[NT];
+	const unsigned long long *bm[NT];
+	const uint32_t *rk[NT];
+	static_for<NT>([&](auto sc_) {
+		constexpr int s = decltype(sc_)::value;
+		pt[s] = A.post;
+		lo[s] = hi[s] = 0;
+		tok[s] = 0;
+		bm[s] = NULL;
+		rk[s] = NULL;
+		if (s < (int)nt) {
+			tok[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->slot_tok[s]);
+			pt[s] = A.post + Q->pbeg[tok[s]];
+			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + tok[s];
+			lo[s] = (int32_t)A.cursors[cb];
+			hi[s] = (int32_t)A.cursors[cb + NXSGPU_MAX_TOKENS];
+			const uint32_t col = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q->bm_col[tok[s]]);
+			if (col != 0xffffffffu) {
+				rk[s] = A.bmrank + (uint64_t)col * (A.bm_words + 1);
+				if (s < (int)n_req) {
+					bm[s] = (const unsigned long long *)A.blkmap + (uint64_t)col * A.bm_words;
+				}
+			}
+		}
+	});
+	WAVE_SYNC();
+
+	/* where doc `d` would be in slot s's list: a lower bound inside the span of d's bitmap word
+	 * (slots without a directory: inside the range's cursors); per lane */
+	auto find = [&](auto sc_, uint32_t d) -> int32_t {
+		constexpr int s = decltype(sc_)::value;
+		int32_t l = lo[s], h = hi[s];
+		if (rk[s]) {
+			/* (the directory counts from the list's first posting, like the cursors) */
+			const uint32_t *r = rk[s] + (d >> 12);
+			l = max(l, (int32_t)r[0]);
+			h = min(h, (int32_t)r[1]);
+		}
+		while (l < h) {
+			const int32_t mid = (l + h) >> 1;
+			if (pt[s][mid].doc < d) {
+				l = mid + 1;
+			} else {
+				h = mid;
+			}
+		}
+		return l;
+	};
+
+	float top = -INFINITY;
+	const float hint = range_hint(A, qm, g);
+	float thr = hint;
+	const uint32_t kidx = A.k - 1;		/* 1 <= k <= 64 (host) */
+	uint32_t n_out = 0;
+	bool ovf = false;
+	const uint64_t out_base = seg * A.seg_cap;
+
+	if (d_top > d_bot && n_req >= 1 && hi[0] > lo[0]) {
+		const uint32_t b0 = d_bot >> 6, b1 = (d_top - 1) >> 6;	/* first and last block of the range */
+		const int32_t w_lo = (int32_t)(b0 >> 6), w_hi = (int32_t)(b1 >> 6);
+		for (int32_t wtop = w_hi; wtop >= w_lo && !ovf; wtop -= WAVE) {
+			/* 1. my word of the intersection */
+			const int32_t w = wtop - (int32_t)lane;
+			unsigned long long m = 0;
+			if (w >= w_lo) {
+				m = ~0ull;
+				static_for<NT>([&](auto sc_) {
+					constexpr int s = decltype(sc_)::value;
+					if (bm[s]) {
+						m &= bm[s][w];
+					}
+				});
+				if (w == w_hi && (b1 & 63) != 63) {
+					m &= (2ull << (b1 & 63)) - 1;
+				}
+				if (w == w_lo) {
+					m &= ~0ull << (b0 & 63);
+				}
+			}
+			/* rounds of up to SQ_CAP surviving blocks, highest first */
+			while (ballot64(m != 0) && !ovf) {
+				const uint32_t cnt = (uint32_t)__popcll(m);
+				uint32_t pre = cnt;		/* inclusive prefix over the lanes (lane 0 = highest word) */
+#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1) {
+					const uint32_t v = (uint32_t)__shfl_up((int)pre, o);
+					if ((int)lane >= o) {
+						pre += v;
+					}
+				}
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+				const uint32_t excl = pre - cnt;
+				const uint32_t take = excl >= SQ_CAP ? 0u : min(cnt, (uint32_t)SQ_CAP - excl);
+				for (uint32_t i = 0; i < take; i++) {
+					const uint32_t bit = 63u - (uint32_t)__builtin_clzll(m);
+					s_blk[excl + i] = ((uint32_t)w << 6) | bit;
+					m &= ~(1ull << bit);
+				}
+				const uint32_t nb = min(total, (uint32_t)SQ_CAP);
+				WAVE_SYNC();
+
+				/* 2. my block: the driver's postings in it, each doc through the other required lists */
+				uint32_t n_match = 0;		/* wave-uniform: matches of this round in s_mdoc / s_msc */
+				const bool have = lane < nb;
+				const uint32_t base = have ? s_blk[lane] << 6 : 0u;
+				int32_t ip = have ? find(std::integral_constant<int, 0>(), base) : hi[0];
+				int32_t ie = ip;		/* [ip, ie): the driver's postings of my block, ascending docs */
+				if (have) {
+					while (ie < hi[0] && ie - ip < WAVE && pt[0][ie].doc < base + WAVE) {
+						ie++;
+					}
+				}
+				/* highest doc first (the emission order inside a block) */
+				while (ballot64(ie > ip) && !ovf) {
+					const bool act = ie > ip;
+					uint32_t d = 0, pmask = 0;
+					bool ok = act;
+					if (act) {
+						ie--;
+						const posting_t p = pt[0][ie];
+						d = p.doc;
+						s_imp[tok[0]][lane] = p.imp;
+						pmask = 1u << tok[0];
+						ok = d >= d_bot && d < d_top;
+					}
+					static_for<NT - 1>([&](auto jc) {
+						constexpr int s = decltype(jc)::value + 1;
+						using SC = std::integral_constant<int, s>;
+						if (s < (int)nt && ballot64(ok)) {
+							if (ok) {
+								const int32_t i = find(SC(), d);
+								bool f = false;
+								if (i < hi[s]) {
+									const posting_t p = pt[s][i];
+									f = p.doc == d;
+									if (f) {
+										s_imp[tok[s]][lane] = p.imp;
+										pmask |= 1u << tok[s];
+									}
+								}
+								if (s < (int)n_req && !f) {
+									ok = false;	/* a required term is missing: the doc cannot match */
+								}
+							}
+						}
+					});
+					/* 3. the docs that hold every required term */
+					bool match = ok && ((s_truth[pmask >> 5] >> (pmask & 31)) & 1);
+					float sc = 0.0f;
+					if (match) {
+						/* token order (results.c:134-136) */
+#pragma unroll
+						for (int k = 0; k < NT; k++) {
+							if ((pmask >> k) & 1) {
+								sc += s_imp[k][lane];
+							}
+						}
+						match = sc > thr;
+					}
+					const uint64_t bal = ballot64(match);
+					if (bal) {
+						const uint32_t ne = __popcll(bal);
+						if (n_match + ne > SQ_MCAP) {
+							ovf = true;
+						} else if (match) {
+							const uint32_t o = n_match + lanes_below(bal);
+							s_mdoc[o] = d;
+							s_msc[o] = sc;
+						}
+						n_match += ne;
+					}
+				}
+				WAVE_SYNC();
+				/* the round's matches: descending doc, then the common filter */
+				if (n_match && !ovf) {
+					constexpr int MC = SQ_MCAP / WAVE;
+					uint32_t pd[MC], rkk[MC];
+					float ps[MC];
+#pragma unroll
+					for (int c = 0; c < MC; c++) {
+						const uint32_t e = c * WAVE + lane;
+						pd[c] = e < n_match ? s_mdoc[e] : 0;
+						ps[c] = e < n_match ? s_msc[e] : 0.0f;
+						rkk[c] = 0;
+					}
+					WAVE_SYNC();
+#pragma unroll
+					for (int cj = 0; cj < MC; cj++) {
+						const uint32_t nj = n_match > (uint32_t)cj * WAVE ? min(n_match - cj * WAVE, (uint32_t)WAVE) : 0u;
+						for (uint32_t j = 0; j < nj; j++) {
+							const uint32_t dj = __builtin_amdgcn_readlane((int)pd[cj], j);
+#pragma unroll
+							for (int c = 0; c < MC; c++) {
+								rkk[c] += dj > pd[c];		/* (docs are distinct) */
+							}
+						}
+					}
+#pragma unroll
+					for (int c = 0; c < MC; c++) {
+						const uint32_t e = c * WAVE + lane;
+						if (e < n_match) {
+							s_mdoc[rkk[c]] = pd[c];
+							s_msc[rkk[c]] = ps[c];
+						}
+					}
+					WAVE_SYNC();
+					for (uint32_t off = 0; off < n_match && !ovf; off += WAVE) {
+						const uint32_t e = off + lane;
+						const bool valid = e < n_match;
+						const uint32_t d = valid ? s_mdoc[e] : 0;
+						const float sc = valid ? s_msc[e] : 0.0f;
+						const bool cand = valid && sc > thr;
+						uint64_t bal = ballot64(cand);
+						if (!bal) {
+							continue;
+						}
+						const uint32_t ne = __popcll(bal);
+						if (n_out + ne > A.seg_cap) {
+							ovf = true;
+						} else if (cand) {
+							/* lanes are in descending doc order */
+							const uint64_t o = out_base + n_out + lanes_below(bal);
+							A.cand_doc[o] = d;
+							A.cand_sc[o] = sc;
+						}
+						n_out += ne;
+						while (bal) {
+							const int L = __builtin_ctzll(bal);
+							bal &= bal - 1;
+							const float v = __shfl(sc, L);
+							if (v > thr) {
+								const uint32_t pos = __popcll(ballot64(top >= v));
+								const float up = __shfl_up(top, 1);
+								top = (lane < pos) ? top : (lane == pos ? v : up);
+								thr = fmaxf(__shfl(top, kidx), hint);
+							}
+						}
+					}
+					WAVE_SYNC();
+				}
+			}
+		}
+	}
+	if (!ovf) {
+		range_publish(A, seg, __shfl(top, kidx));
+	}
+	if (lane == 0) {
+		A.seg_count[seg] = ovf ? 0 : n_out;
+		if (ovf) {
+			A.overflow[q] = 1;
+		}
+	}
+}
+
 #ifdef NXS_EXPERIMENTAL	/* opt-in build: measured not faster than the tiles (DESIGN.md "dead ends") */
 /*
  * k_scanh: the posting-step path for queries without a very dense term.
@@ -982,6 +1290,19 @@ nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a)
 	case MODE_BIG: hipLaunchKernelGGL((k_scan1<MODE_BIG>), dim3(grid), dim3(WAVE), 0, st, a); break;
 	case MODE_COUNT: hipLaunchKernelGGL((k_scan1<MODE_COUNT>), dim3(grid), dim3(WAVE), 0, st, a); break;
 	default: hipLaunchKernelGGL((k_scan1<MODE_ALL>), dim3(grid), dim3(WAVE), 0, st, a); break;
+	}
+}
+
+void
+nxs_launch_scanq(uint32_t nt_bucket, unsigned grid_, hipStream_t st, const scan_args_t &a)
+{
+	const dim3 grid(grid_), block(WAVE);
+
+	switch (nt_bucket) {
+	case 2: hipLaunchKernelGGL((k_scanq<2>), grid, block, 0, st, a); break;
+	case 3: hipLaunchKernelGGL((k_scanq<3>), grid, block, 0, st, a); break;
+	case 5: hipLaunchKernelGGL((k_scanq<5>), grid, block, 0, st, a); break;
+	default: hipLaunchKernelGGL((k_scanq<8>), grid, block, 0, st, a); break;
 	}
 }
 

@@ -171,6 +171,32 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 				total += wr;
 				/* (four required terms and more: rounds of whole driver windows, k_scanr<.., true>) */
 			cls[i] = 3u * 64 + ((SCANR_HASH && hq[i].n_req >= 4) ? 16u : 0u) + nt_bucket(hq[i].nt);
+				/*
+				 * Two required terms and more that all have a block-presence bitmap: AND the
+				 * bitmaps and look at the postings of the surviving 64-doc blocks only
+				 * (k_scanq) -- if few blocks are expected to survive (independent lists: a
+				 * block holds term t with probability 1 - (1 - df_t / N)^64) against what
+				 * the driver list would cost k_scanr.
+				 */
+				if (cf.use_blkmap && hq[i].n_req >= 2 && big_k == 0 && ix->n_post < (1ull << 32)) {
+					double surv = (double)ix->n_docs / 64.0;
+					bool all = true;
+					for (uint32_t t = 0; t < hq[i].nt; t++) {
+						if (!((hq[i].req >> t) & 1)) {
+							continue;
+						}
+						all = all && hq[i].bm_col[t] != 0xffffffffu;
+						const double rho = (double)(hq[i].pend[t] - hq[i].pbeg[t]) / (double)std::max<uint64_t>(ix->n_docs, 1);
+						surv *= 1.0 - std::pow(1.0 - std::min(rho, 1.0), 64.0);
+					}
+					if (all && surv * cf.bm_gain < (double)dfd) {
+						total -= work[i];
+						/* the bitmaps' words + the surviving blocks (a lane each), in posting units */
+						work[i] = (uint64_t)(ix->n_docs / 256 + surv * 64.0) + 1;
+						total += work[i];
+						cls[i] = 7u * 64 + (cls[i] & 16u) + nt_bucket(hq[i].nt);
+					}
+				}
 			}
 		}
 	}
@@ -429,8 +455,12 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, 1u, grid, ix->stream, a);
 			}
-		} else if (l.kind == 3) {
-			nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, ix->stream, a);
+		} else if (l.kind == 3 || l.kind == 7) {
+			if (l.kind == 7 && topk64) {
+				nxs_launch_scanq(l.nt_bucket, grid, ix->stream, a);
+			} else {
+				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, ix->stream, a);
+			}
 		} else {
 			nxs_launch_scanh(MODE, l.nt_bucket, grid, ix->stream, a);
 		}
@@ -544,6 +574,18 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 			total_post += d.pend[t] - d.pbeg[t];
 			if (t < 8 && tid < ix->h_maximp[algo].size()) {
 				d.tmax[t] = ix->h_maximp[algo][tid];
+			}
+		}
+		/* block-presence bitmaps of the tokens that have one (k_scanq) */
+		for (uint32_t t = 0; t < 8; t++) {
+			d.bm_col[t] = 0xffffffffu;
+		}
+		if (d.nt <= 8 && !ix->bm_terms.empty()) {
+			for (uint32_t t = 0; t < d.nt; t++) {
+				const auto it = std::lower_bound(ix->bm_terms.begin(), ix->bm_terms.end(), q.term_id[t]);
+				if (it != ix->bm_terms.end() && *it == q.term_id[t]) {
+					d.bm_col[t] = (uint32_t)(it - ix->bm_terms.begin());
+				}
 			}
 		}
 		/* dense tokens (k_scanm<.., DROP>): lists above the mask path's density limit */
@@ -780,6 +822,9 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.post = ix->d_post[algo];
 	sa.dense_col = ix->d_dense_col[algo];
 	sa.dense_stride = ix->n_docs;
+	sa.blkmap = ix->d_blkmap;
+	sa.bmrank = ix->d_bmrank;
+	sa.bm_words = ix->bm_words;
 	sa.queries = d_q;
 	sa.n_docs = ix->n_docs;
 	sa.qmeta = d_qmeta;
@@ -1473,6 +1518,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.post = ix->d_post[algo];
 	sa.dense_col = ix->d_dense_col[algo];
 	sa.dense_stride = ix->n_docs;
+	sa.blkmap = ix->d_blkmap;
+	sa.bmrank = ix->d_bmrank;
+	sa.bm_words = ix->bm_words;
 	sa.queries = d_q;
 	sa.n_docs = ix->n_docs;
 	sa.qmeta = d_qmeta;

@@ -160,7 +160,11 @@ def random_query(rng, vocab, nmax=5):
     (3, 5000, 300, True),     # sparse u64 doc ids, ragged lists
     (4, 20000, 30, False),    # dense lists: many batches per tile
 ])
-def test_random_corpora_all_limits(nxs, tmp_path, seed, n_docs, vocab_n, sparse):
+@pytest.mark.parametrize("bm", [False, True])
+def test_random_corpora_all_limits(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, sparse, bm):
+    if bm:      # every conjunction through the block-presence bitmaps (k_scanq), every term with a bitmap
+        monkeypatch.setenv("NXS_GPU_BM_GAIN", "0")
+        monkeypatch.setenv("NXS_GPU_BM_SHARE", "1073741824")
     rng = random.Random(seed)
     vocab = ["w%d" % i for i in range(vocab_n)]
     weights = [1.0 / (i + 1) for i in range(vocab_n)]
@@ -494,7 +498,12 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  # single-token classes: every query's top range in a launch of its own
-                                 {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"}])
+                                 {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"},
+                                 # conjunctions through the block-presence bitmaps (k_scanq): whenever the required
+                                 # terms have one / every term has one / many short ranges / never
+                                 {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"},
+                                 {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_NOBLKMAP": "1"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
@@ -524,7 +533,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
                                  {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_NOSCANB": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
-                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"}])
+                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
     tiles skipped or wiped), 3- and 7-token shapes, mixed operators."""
@@ -925,7 +935,8 @@ def test_resync_in_a_pipelined_loop_that_never_drains(nxs, tmp_path):
     gidx.close()
 
 
-def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path):
+@pytest.mark.parametrize("bm", [False, True])
+def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path, monkeypatch, bm):
     """N1: 100 interleaved appends (new docs with growing ids, some with new
     terms) and removals, each published in place and picked up by the NEXT
     search through the incremental path (delta merged into the device CSR, all
@@ -933,6 +944,9 @@ def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path):
     results against a freshly loaded oracle after every step.  A re-used doc id
     then takes the rebuild path, also exactly."""
     import ctypes as C
+    if bm:      # conjunctions through the block-presence bitmaps, rebuilt at every refresh
+        monkeypatch.setenv("NXS_GPU_BM_GAIN", "0")
+        monkeypatch.setenv("NXS_GPU_BM_SHARE", "1073741824")
     rng = random.Random(97)
     vocab = ["w%d" % i for i in range(60)]
     weights = [1.0 / (i + 1) for i in range(len(vocab))]
@@ -950,7 +964,8 @@ def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path):
     L = N.lib()
     L.nxs_index_refresh_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     alive, next_id, n_new_terms = set(range(1, 401)), 401, 0
-    queries = ["w0", "w1 AND w2", "w3 OR w7 OR w20", "w0 AND NOT w1", "w5 OR w40 OR w55 OR w9 OR w2"]
+    queries = ["w0", "w1 AND w2", "w3 OR w7 OR w20", "w0 AND NOT w1", "w5 OR w40 OR w55 OR w9 OR w2",
+               "w2 AND w4 AND w1", "w3 AND (w0 OR w9) AND w1"]
     for step in range(100):
         r = rng.random()
         if r < 0.2 and len(alive) > 50:

@@ -730,7 +730,40 @@ js_value(jscan_t *j, nxs_params_t *into, const char *key, unsigned depth)
 			}
 			j->p++;
 			/* (an embedded NUL would truncate the key: such a key is no parameter) */
-			r = js_value(j, members, k, depth + 1);
+			/*
+			 * The reference's getters look a key up with yyjson_mut_obj_get(): the FIRST
+			 * member of that name, whatever its kind -- a later duplicate is never seen,
+			 * and a first member of a kind the getter does not read (null, a negative
+			 * number, an array ...) hides a later usable one.  So only the first
+			 * occurrence is kept, as a typeless entry if need be.
+			 */
+			{
+				nxs_params_t *dst = members;
+				bool first = false;
+
+				if (members && k) {
+					first = true;
+					for (size_t i = 0; i < members->n; i++) {
+						if (strcmp(members->kv[i].key, k) == 0) {
+							first = false;
+							break;
+						}
+					}
+					if (!first) {
+						dst = NULL;
+					}
+				}
+				const size_t n_before = members ? members->n : 0;
+				r = js_value(j, dst, k, depth + 1);
+				if (r == 0 && first && members->n == n_before) {
+					param_kv_t *kv = params_slot(members, k);
+					if (!kv) {
+						r = js_fail(j, "out of memory");
+					} else {
+						kv->type = PV_NONE;
+					}
+				}
+			}
 			free(k);
 			if (r == -1) {
 				return -1;
@@ -1587,6 +1620,43 @@ static int batch_end_core(nxs_index_t *, nxs_pend_t *, nxs_resp_t **, nxs_err_t 
  * index is refreshed and the new batch sees the change.  In the steady state of
  * a pipelined server (one batch always in flight) nothing else ever would.
  */
+/*
+ * Finish the batches in flight, oldest first, and keep their outcome (responses, error
+ * slot) for the caller's _end.
+ */
+static int
+stash_inflight(nxs_index_t *idx)
+{
+	for (;;) {
+		nxs_pend_t *pd = NULL;
+
+		for (int i = 0; i < 2; i++) {
+			nxs_pend_t *c = &idx->pend[i];
+			if (c->active && !c->stashed && (!pd || c->seq < pd->seq)) {
+				pd = c;
+			}
+		}
+		if (!pd) {
+			return 0;
+		}
+		pd->st_resps = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_resps));
+		pd->st_errs = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_errs));
+		if (!pd->st_resps || !pd->st_errs) {
+			free(pd->st_resps);
+			free(pd->st_errs);
+			pd->st_resps = NULL;
+			pd->st_errs = NULL;
+			nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
+			return -1;
+		}
+		pd->st_ret = batch_end_core(idx, pd, pd->st_resps, pd->st_errs);
+		pd->st_errcode = idx->nxs->errcode;
+		pd->st_errmsg = idx->nxs->errmsg ? strdup(idx->nxs->errmsg) : NULL;
+		pd->stashed = true;
+		nxs_clear_error(idx->nxs);
+	}
+}
+
 static int
 resync_before_batch(nxs_index_t *idx)
 {
@@ -1594,29 +1664,8 @@ resync_before_batch(nxs_index_t *idx)
 	 * flight -- their fix-up round is a collective --, so with a communicator attached
 	 * the files are re-read between batches only, as before) */
 	if (pend_oldest(idx) && !idx->comm && nxs_index_changed(idx)) {
-		for (;;) {
-			nxs_pend_t *pd = NULL;
-
-			for (int i = 0; i < 2; i++) {
-				nxs_pend_t *c = &idx->pend[i];
-				if (c->active && !c->stashed && (!pd || c->seq < pd->seq)) {
-					pd = c;
-				}
-			}
-			if (!pd) {
-				break;
-			}
-			pd->st_resps = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_resps));
-			pd->st_errs = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_errs));
-			if (!pd->st_resps || !pd->st_errs) {
-				nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
-				return -1;
-			}
-			pd->st_ret = batch_end_core(idx, pd, pd->st_resps, pd->st_errs);
-			pd->st_errcode = idx->nxs->errcode;
-			pd->st_errmsg = idx->nxs->errmsg ? strdup(idx->nxs->errmsg) : NULL;
-			pd->stashed = true;
-			nxs_clear_error(idx->nxs);
+		if (stash_inflight(idx) == -1) {
+			return -1;
 		}
 	}
 	return nxs_index_refresh(idx);
@@ -1696,14 +1745,18 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	pd->hi = hi;
 	pd->cap = (uint32_t)nxsgpu_shard_capacity(n, pd->world);
 	nl = hi - lo;
+	/* (a rank of a real communicator: its peers queue an all-gather for this batch, so from
+	 * here on a failure of this rank still has to contribute a block: abort_collective) */
+	const bool collective = idx->comm != NULL && !idx->emu_world && sp.limit <= NXSGPU_BIG_K;
 	pd->prep = calloc(nl ? nl : 1, sizeof(qprep_t));
 	if (!pd->prep) {
 		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		if (collective) {
+			goto abort_collective;
+		}
 		goto out;
 	}
 	t0 = now_s();
-	/* (a rank of a real communicator: its peers queue an all-gather for this batch) */
-	const bool collective = idx->comm != NULL && !idx->emu_world && sp.limit <= NXSGPU_BIG_K;
 	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1 ||
 	    (idx->test_fail_begin && idx->test_fail_begin-- == 1 &&
 	    (nxs_decl_err(nxs, NXS_ERR_SYSTEM, "injected failure (test)"), true))) {
@@ -1742,6 +1795,9 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		    idx->comm != NULL && pd->world >= 1 && !idx->emu_world) != 0) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
 			    nxsgpu_last_error());
+			if (collective) {
+				goto abort_collective;	/* (an empty block may still go up) */
+			}
 			goto out;
 		}
 		pd->on_device = true;
@@ -1778,9 +1834,21 @@ abort_collective:
 		for (uint32_t i = 0; status && i < pd->cap; i++) {
 			status[i] = STATUS_ABORT | (uint32_t)code;
 		}
+		/*
+		 * Order: the block's all-gather is queued FIRST (the peers queued theirs in their
+		 * _begin), then the batches this rank still has in flight are finished -- the
+		 * device hands its slots back oldest first, and an older batch's fix-up round is
+		 * a collective the peers enter in their _end, after this batch's all-gather --,
+		 * their outcome kept for the caller's _end; only then is the abort slot the
+		 * oldest one.  (Ending it at once took the OLDER batch's slot: that batch's
+		 * _end then read the abort block as its own.)
+		 */
 		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, NULL, 0, NULL, status, pd->cap, 1) == 0) {
+			(void)stash_inflight(idx);
 			(void)nxsgpu_batch_end(idx->dev, &v);
 		}
+		/* (if even the empty block cannot go up the communicator is unusable: the peers'
+		 * collective never completes -- fatal for the sharded group) */
 		nxs_decl_err(nxs, code, "%s", msg ? msg : "this rank aborted the sharded batch");
 		free(msg);
 	}

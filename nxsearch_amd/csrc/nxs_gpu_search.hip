@@ -1391,7 +1391,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	const uint64_t wave_target = ix->cfg.wave_target;
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
 	const size_t stage_need = 32768 + RETRY_LISTS * 4 + 256 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
-	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + sl->block_bytes;
+	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + (size_t)o.n_slots * 4 + 4096
+	    + (block_in_ws ? sl->block_bytes : 0);	/* (the record block itself lives in h_blocks) */
 	if (slot_ensure(*sl, 0, stage_need) != 0) {
 		return -1;
 	}
@@ -1422,6 +1423,10 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint8_t *h_block = carve<uint8_t>(hp, block_in_ws ? sl->block_bytes : 0);
 	const size_t up_len = (size_t)(hp - sl->h_stage);
 	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, o.n_slots);
+	if ((size_t)(hp - sl->h_stage) > sl->h_stage_len) {
+		set_error("staging area too small (%zu > %zu)", (size_t)(hp - sl->h_stage), sl->h_stage_len);
+		return -1;
+	}
 	if (nq) {
 		memcpy(h_qmeta, wl.qmeta.data(), nq * sizeof(qmeta_t));
 		memcpy(h_items, wl.items.data(), nseg * sizeof(item_t));

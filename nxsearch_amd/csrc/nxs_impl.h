@@ -39,7 +39,7 @@ void	nxs_decl_err(nxs_t *, nxs_err_t, const char *fmt, ...)
 
 /* ---- params ---------------------------------------------------------- */
 
-typedef enum { PV_STR, PV_UINT, PV_BOOL } pv_type_t;
+typedef enum { PV_STR, PV_UINT, PV_BOOL, PV_NONE } pv_type_t;	/* PV_NONE: a JSON member of a kind no getter reads */
 
 typedef struct {
 	char *		key;

@@ -724,6 +724,18 @@ def test_sharded_single_rank_through_rccl(nxs, tmp_path):
     assert e.value.code == 2 and "injected failure" in e.value.msg
     for q, g in zip(qs, gidx.search_batch(qs, limit=10)):
         assert_same(g, oidx.search(q, limit=10), q)
+    # the same with a healthy batch IN FLIGHT (the pipelined loop of a sharded server): the
+    # failing _begin must not consume that batch's device slot -- its _end still returns its
+    # own answers, and the batch after the failed one is in step
+    gidx.search_batch_begin(qs[:100], limit=10)
+    multi.inject_failure(gidx, "begin")
+    with pytest.raises(N.NxsError) as e:
+        gidx.search_batch_begin(qs[100:], limit=10)
+    assert e.value.code == 2 and "injected failure" in e.value.msg
+    for q, g in zip(qs[:100], gidx.search_batch_end()):
+        assert_same(g, oidx.search(q, limit=10), q)
+    for q, g in zip(qs[100:], gidx.search_batch(qs[100:], limit=10)):
+        assert_same(g, oidx.search(q, limit=10), q)
     gidx.shard(0, 1, None)                            # detach
     got = gidx.search_batch(qs[:16], limit=10)
     for q, g in zip(qs, got):

@@ -61,6 +61,15 @@ def test_params_fromjson_is_what_the_lua_binding_needs(tmp_path):
         for k in (b"neg", b"real", b"nil", b"nested", b"filters", b"huge", b"missing"):
             assert get(p, k) is None, k           # not a string / unsigned / bool member of the root
         L.nxs_params_release(p)
+        # duplicate keys: the reference's getters use yyjson_mut_obj_get, i.e. the FIRST member of that
+        # name whatever its kind -- a later duplicate is never seen, a first member of the wrong kind
+        # hides a usable one behind it (search.c:96-101 then falls back to the default limit)
+        for js, want in (('{"limit": 10, "limit": 20}', 10), ('{"limit": "x", "limit": 10}', "x"),
+                         ('{"limit": null, "limit": 10}', None), ('{"limit": -1, "limit": 10}', None),
+                         ('{"limit": [1], "limit": 10}', None), ('{"limit": 10, "limit": "x"}', 10)):
+            p = parse(js)
+            assert p and get(p, b"limit") == want, js
+            L.nxs_params_release(p)
         for ok in ("{}", "[1, 2]", "3", '"x"', "  null  "):    # valid JSON, no parameters
             p = parse(ok)
             assert p and get(p, b"limit") is None

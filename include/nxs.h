@@ -114,8 +114,14 @@ int		nxs_index_search_batch_end(nxs_index_t *, nxs_resp_t **resps,
  * every rank passes the SAME batch to nxs_index_search_batch[_begin]; each
  * rank runs its contiguous slice, one RCCL all-gather of fixed-size per-query
  * records over xGMI reassembles the batch, and every rank receives all n
- * responses.  Applies to limit <= 64; larger limits run replicated (every rank
- * computes the whole batch).  nxs_index_search() (one query) never shards.
+ * responses.  Applies to limit <= 8000 (NXSGPU_BIG_K: fixed-size records); larger
+ * limits run replicated (every rank computes the whole batch).  nxs_index_search()
+ * (one query) never shards.  With a communicator attached the files are re-read
+ * only while no batch is in flight (the ranks would have to agree on the batch at
+ * which to drain); a rank that cannot do its share of a batch still contributes an
+ * "aborted" block, so every rank fails that batch together and the next one is in
+ * step -- only a rank that cannot reach the collective at all (device memory for
+ * the staging buffer, a dead process) stalls the group, as with any collective.
  * nxs_index_shard(idx, 0, 1, NULL) detaches.
  */
 #define	NXS_SHARD_UID_BYTES	128
@@ -171,18 +177,8 @@ int		nxs_docshard_search_batch_rank(nxs_index_t *shard, nxs_params_t *,
 		    const char *const *queries, size_t n,
 		    nxs_resp_t **resps, nxs_err_t *errs);
 
-/*
- * Host-side phase times of the batches since the last call, in seconds:
- * out[0] parse/resolve/compile, out[1] queueing on the device, out[2] waiting
- * for the device, out[3] building responses, out[4] number of batches, out[5]
- * queries that had to be re-run on the exact two-pass path, out[6] / out[7] the
- * whole _begin() / _end() calls.
- */
-void		nxs_index_host_profile(nxs_index_t *, double out[8]);
-
-/* The device-side handle behind an index (see nxs_gpu.h), for benches. */
-struct nxsgpu_index;
-struct nxsgpu_index *nxs_index_device(nxs_index_t *);
+/* (test hooks and the bench's accessors -- nxs_index_host_profile, nxs_index_device, nxs_test_* -- are
+ * not part of this ABI: nxsearch_amd/csrc/nxs_hooks.h, builds with -DNXS_TEST_HOOKS only) */
 
 #ifdef __cplusplus
 }

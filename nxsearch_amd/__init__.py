@@ -80,12 +80,15 @@ NXS_H_SYMBOLS = [
     "nxs_params_release", "nxs_index_open", "nxs_index_close",
     "nxs_index_search", "nxs_resp_iter_reset", "nxs_resp_iter_result",
     "nxs_resp_resultcount", "nxs_resp_tojson", "nxs_resp_release",
-    "nxs_index_search_batch", "nxs_index_open_files", "nxs_index_device",
+    "nxs_index_search_batch", "nxs_index_open_files",
     "nxs_index_plan_batch", "nxs_index_search_batch_begin",
     "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
-    "nxs_index_host_profile", "nxs_index_open_shard", "nxs_docshard_search_batch",
+    "nxs_index_open_shard", "nxs_docshard_search_batch",
     "nxs_docshard_attach", "nxs_docshard_search_batch_rank",
 ]
+# csrc/nxs_hooks.h: test hooks + bench accessors, only in builds with -DNXS_TEST_HOOKS (the default)
+NXS_HOOK_SYMBOLS = ["nxs_index_device", "nxs_index_host_profile", "nxs_test_pool", "nxs_test_assemble",
+                    "nxs_test_fixup_scan", "nxs_test_inject_failure"]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
     "nxsgpu_index_destroy", "nxsgpu_index_df", "nxsgpu_index_postings",

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include "nxs_impl.h"
+#include "nxs_hooks.h"
 
 /* ---- host worker pool ------------------------------------------------------ */
 
@@ -202,6 +203,7 @@ pool_run(struct nxs_pool *p, pool_fn_t fn, void *arg, size_t n, size_t chunk)
 	}
 }
 
+#ifdef NXS_TEST_HOOKS	/* (nxs_hooks.h: test hooks and bench accessors are not part of the production ABI) */
 /* tests: `rounds` runs of `n` items each on a pool of `n_thr` threads; every item of
  * every run must be worked on exactly once.  Returns the number of items that were not. */
 static void
@@ -232,6 +234,8 @@ nxs_test_pool(unsigned n_thr, size_t n, unsigned rounds, size_t chunk)
 	free((void *)hits);
 	return (p && hits) ? bad : (size_t)-1;
 }
+
+#endif /* NXS_TEST_HOOKS */
 
 /* the pool of an instance: NXS_HOST_THREADS (read once), else min(cores, 16) */
 static struct nxs_pool *
@@ -1111,11 +1115,13 @@ nxs_index_close(nxs_index_t *idx)
 	free(idx);
 }
 
+#ifdef NXS_TEST_HOOKS
 struct nxsgpu_index *
 nxs_index_device(nxs_index_t *idx)
 {
 	return idx->dev;
 }
+#endif
 
 /* ---- response object --------------------------------------------------------- */
 
@@ -1529,6 +1535,7 @@ now_s(void)
 	return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+#ifdef NXS_TEST_HOOKS
 /*
  * Where the host's time goes, summed over the batches so far: out[0] parse +
  * resolve + compile (worker pool), out[1] queueing the batch on the device
@@ -1551,6 +1558,8 @@ nxs_index_host_profile(nxs_index_t *idx, double out[8])
 	idx->hp_plan = idx->hp_queue = idx->hp_wait = idx->hp_resps = 0;
 	idx->hp_batches = 0;
 }
+
+#endif /* NXS_TEST_HOOKS */
 
 /* status word of a record slot: 0, an nxs_err_t, or ... */
 #define	STATUS_HOSTPATH	0x100u	/* the owner evaluates it on the exact path (fix-up round) */
@@ -2003,6 +2012,66 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 	return ret;
 }
 
+/*
+ * The fix-up round of a sharded batch, as every rank decides it from the gathered blocks:
+ * a record marked inexact (candidate overflow) or a host-path query (wide plan) anywhere
+ * means ALL ranks take a second all-gather, after each owner has re-run its own such
+ * queries on the exact path (`which`: the owner's, local indexes).  `all` = the blocks of
+ * all W ranks are present (else: this rank's block only -- one emulated rank, tests).
+ */
+static bool
+fixup_scan(const uint8_t *blocks, bool all, uint32_t W, int rank, uint32_t n_slots, uint32_t k,
+    size_t n, uint32_t *which, size_t *nw)
+{
+	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
+	bool fixup = false;
+
+	for (uint32_t r = 0; r < W; r++) {
+		const uint8_t *blk = all ? blocks + (size_t)r * block_bytes : blocks;
+		const uint32_t *st = (const uint32_t *)(blk + (size_t)n_slots * rec_bytes);
+		uint64_t rlo, rhi;
+
+		if (!all && (int)r != rank) {
+			continue;
+		}
+		nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
+		for (uint64_t i = 0; i < rhi - rlo; i++) {
+			const uint32_t *rec = (const uint32_t *)(blk + i * rec_bytes);
+			if (rec[1] == NXSGPU_REC_INEXACT || st[i] == STATUS_HOSTPATH) {
+				fixup = true;
+				if ((int)r == rank) {
+					which[(*nw)++] = (uint32_t)i;
+				}
+			}
+		}
+	}
+	return fixup;
+}
+
+/* after the second all-gather: the rank that aborted in the fix-up round, or one that left a
+ * record unpatched (still marked) -- every rank fails the batch then --, else -1 */
+static int
+fixup_verify(const uint8_t *blocks, uint32_t W, uint32_t n_slots, uint32_t k, size_t n, nxs_err_t *acode)
+{
+	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
+	int ar = blocks_aborted(blocks, W, n_slots, k, acode);
+
+	for (uint32_t r = 0; ar < 0 && r < W; r++) {
+		const uint8_t *blk = blocks + (size_t)r * block_bytes;
+		const uint32_t *st = (const uint32_t *)(blk + (size_t)n_slots * rec_bytes);
+		uint64_t rlo, rhi;
+
+		nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
+		for (uint64_t i = 0; i < rhi - rlo; i++) {
+			if (((const uint32_t *)(blk + i * rec_bytes))[1] == NXSGPU_REC_INEXACT || st[i] == STATUS_HOSTPATH) {
+				ar = (int)r;
+				*acode = NXS_ERR_FATAL;
+			}
+		}
+	}
+	return ar;
+}
+
 static int
 batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *errs)
 {
@@ -2010,6 +2079,7 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 	nxsgpu_results_t res, wres;
 	slab_builder_t sb = { 0 };
 	uint8_t *patched = NULL;
+	bool patched_own = true;	/* `patched` is malloc()ed (not the slot's pinned blocks) */
 	uint32_t *which, *pos;
 	size_t nw = 0, total = 0, n, nl;
 	double t0;
@@ -2067,25 +2137,7 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 		}
 		/* records that need the exact path: every rank sees the same flags, so
 		 * every rank takes (or skips) the fix-up round together */
-		for (uint32_t r = 0; r < W; r++) {
-			const uint8_t *blk = all ? blocks + (size_t)r * v.block_bytes : blocks;
-			const uint32_t *st = (const uint32_t *)(blk + (size_t)v.n_slots * v.rec_bytes);
-			uint64_t rlo, rhi;
-
-			if (!all && (int)r != pd->rank) {
-				continue;
-			}
-			nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
-			for (uint64_t i = 0; i < rhi - rlo; i++) {
-				const uint32_t *rec = (const uint32_t *)(blk + i * v.rec_bytes);
-				if (rec[1] == NXSGPU_REC_INEXACT || st[i] == STATUS_HOSTPATH) {
-					fixup = true;
-					if ((int)r == pd->rank) {
-						which[nw++] = (uint32_t)i;
-					}
-				}
-			}
-		}
+		fixup = fixup_scan(blocks, all, W, pd->rank, v.n_slots, v.k, n, which, &nw);
 		if (fixup) {
 			const size_t len = (all ? (size_t)W : 1) * v.block_bytes;
 			uint8_t *mine;
@@ -2141,35 +2193,36 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			}
 			if (all && W > 1) {
 				uint8_t *gathered = malloc(len);
+				bool g_own = gathered != NULL;
 
-				/* (no buffer to receive into: a rank that cannot even allocate that
-				 * cannot be saved -- but it is the only case left that strands peers) */
-				if (!gathered || nxsgpu_comm_allgather(idx->comm, mine, gathered, v.block_bytes) != 0) {
-					nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather failed: %s",
-					    gathered ? nxsgpu_last_error() : "out of memory");
+				/*
+				 * No memory to receive into: the slot's own pinned blocks (the first
+				 * round's result: W blocks, the size this round needs) are always
+				 * there -- the all-gather stages through device memory, so receiving
+				 * over the block that is being sent is safe -- and what this rank
+				 * needs of the first round is in `patched` (or it sends its block
+				 * unpatched, which fails the batch everywhere).  A rank that is out
+				 * of memory no longer strands its peers.
+				 */
+				if (!gathered || (idx->test_fail_fixup_recv && idx->test_fail_fixup_recv-- == 1)) {
 					free(gathered);
+					gathered = (uint8_t *)(uintptr_t)v.blocks;
+					g_own = false;
+				}
+				if (nxsgpu_comm_allgather(idx->comm, mine, gathered, v.block_bytes) != 0) {
+					nxs_decl_err(nxs, NXS_ERR_FATAL, "all-gather failed: %s", nxsgpu_last_error());
+					if (g_own) {
+						free(gathered);
+					}
 					free(fix_msg);
 					goto out;
 				}
 				free(patched);
 				patched = gathered;
+				patched_own = g_own;
 				{
 					nxs_err_t acode;
-					int ar = blocks_aborted(patched, W, v.n_slots, v.k, &acode);
-					/* ... or a record a rank could not patch (it is still marked) */
-					for (uint32_t r = 0; ar < 0 && r < W; r++) {
-						const uint8_t *blk = patched + (size_t)r * v.block_bytes;
-						const uint32_t *st = (const uint32_t *)(blk + (size_t)v.n_slots * v.rec_bytes);
-						uint64_t rlo, rhi;
-						nxsgpu_shard_slice(n, (int)r, (int)W, &rlo, &rhi);
-						for (uint64_t i = 0; i < rhi - rlo; i++) {
-							if (((const uint32_t *)(blk + i * v.rec_bytes))[1] == NXSGPU_REC_INEXACT ||
-							    st[i] == STATUS_HOSTPATH) {
-								ar = (int)r;
-								acode = NXS_ERR_FATAL;
-							}
-						}
-					}
+					const int ar = fixup_verify(patched, W, v.n_slots, v.k, n, &acode);
 					if (ar >= 0) {
 						if (ar == pd->rank && fix_code) {
 							nxs_decl_err(nxs, fix_code, "%s", fix_msg ? fix_msg : "exact pass failed");
@@ -2268,7 +2321,9 @@ out:
 	if (wres.counts) {
 		nxsgpu_results_free(&wres);
 	}
-	free(patched);
+	if (patched_own) {
+		free(patched);
+	}
 	free(which);
 	free(pos);
 	idx->hp_end += now_s() - t_in;
@@ -2736,6 +2791,7 @@ nxs_docshard_search_batch_rank(nxs_index_t *shard, nxs_params_t *params,
 	return docshard_search(local, 1, shard->n_shards, shard->shard, params, queries, n, resps, errs, 0, NULL, NULL, NULL);
 }
 
+#ifdef NXS_TEST_HOOKS
 /*
  * Tests (one GPU, no second rank to talk to): the two halves of the rank form.
  * nxs_test_docshard_block() = this rank's candidate block (malloc'ed);
@@ -2776,6 +2832,8 @@ nxs_test_docshard_set_df(nxs_index_t *const *shards, unsigned n_shards)
 {
 	return docshard_set_global_df(shards, n_shards);
 }
+
+#endif /* NXS_TEST_HOOKS */
 
 /* ---- query sharding over the GPUs of a node ---------------------------------------- */
 
@@ -2819,6 +2877,7 @@ nxs_index_shard(nxs_index_t *idx, int rank, int world, const uint8_t *uid)
 }
 
 /* ---- test hooks (host-only pieces, exercised without a GPU) ------------------------ */
+#ifdef NXS_TEST_HOOKS
 
 char *
 nxs_test_query_repr(const char *query, char **errmsg)
@@ -2949,6 +3008,32 @@ nxs_test_pack_record(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot
 	st[slot] = status;
 }
 
+/* mark a record "inexact" (candidate overflow: the owner re-runs the query in the fix-up round) */
+void
+nxs_test_mark_inexact(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot)
+{
+	(void)n_slots;
+	((uint32_t *)(block + (size_t)slot * NXSGPU_REC_BYTES(k)))[1] = NXSGPU_REC_INEXACT;
+}
+
+/* what every rank reads off the gathered blocks: does the batch need a fix-up round, and which
+ * of `rank`'s own queries (local indexes) have to be re-run?  -> 1 / 0, *nw set */
+int
+nxs_test_fixup_scan(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k, size_t n,
+    int rank, uint32_t *which, size_t *nw)
+{
+	*nw = 0;
+	return fixup_scan(blocks, true, world, rank, n_slots, k, n, which, nw) ? 1 : 0;
+}
+
+/* ... and off the blocks of the second all-gather: -1 = fine, else the rank that failed the batch */
+int
+nxs_test_fixup_verify(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k, size_t n)
+{
+	nxs_err_t acode = NXS_ERR_SUCCESS;
+	return fixup_verify(blocks, world, n_slots, k, n, &acode);
+}
+
 /* what a rank that cannot do its share contributes instead (STATUS_ABORT) */
 void
 nxs_test_pack_abort(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t code)
@@ -2961,14 +3046,17 @@ nxs_test_pack_abort(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t code)
 	}
 }
 
-/* the n-th next _begin (which = 0) / exact fix-up round (1) of the index fails */
+/* the n-th next _begin (which = 0) / exact fix-up round (1) of the index fails; 2: the n-th next
+ * fix-up round finds no memory for its receive buffer */
 void
 nxs_test_inject_failure(nxs_index_t *idx, int which, unsigned nth)
 {
 	if (which == 0) {
 		idx->test_fail_begin = nth;
-	} else {
+	} else if (which == 1) {
 		idx->test_fail_fixup = nth;
+	} else {
+		idx->test_fail_fixup_recv = nth;
 	}
 }
 
@@ -3059,3 +3147,4 @@ nxs_test_levdist(const uint8_t *a, size_t n, const uint8_t *b, size_t m)
 	extern int nxs_levdist_export(const uint8_t *, size_t, const uint8_t *, size_t);
 	return nxs_levdist_export(a, n, b, m);
 }
+#endif /* NXS_TEST_HOOKS */

@@ -118,7 +118,7 @@ struct nxs_index {
 	nxsgpu_comm_t *	comm;
 	struct nxs_pend	pend[2];
 	/* tests: the n-th next _begin / exact fix-up of this index fails (0: off) */
-	unsigned	test_fail_begin, test_fail_fixup;
+	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv;
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
 	double		hp_plan, hp_queue, hp_wait, hp_resps, hp_begin, hp_end;

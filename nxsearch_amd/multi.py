@@ -99,6 +99,36 @@ def pack_abort(n_slots, k, code):
     return buf.raw[:block_bytes(n_slots, k)]
 
 
+def mark_inexact(block, n_slots, k, slot):
+    """tests: the record of `slot` says "inexact" (its owner re-runs the query in the fix-up round)."""
+    L = lib()
+    L.nxs_test_mark_inexact.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    buf = C.create_string_buffer(block, len(block))
+    L.nxs_test_mark_inexact(buf, n_slots, k, slot)
+    return buf.raw[:len(block)]
+
+
+def fixup_scan(blocks, world, n_slots, k, n, rank):
+    """What every rank reads off the gathered blocks (the library's fixup_scan): (a fix-up
+    round is needed, the local indexes of `rank`'s queries to re-run)."""
+    L = lib()
+    L.nxs_test_fixup_scan.restype = C.c_int
+    L.nxs_test_fixup_scan.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_int,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    which = (C.c_uint32 * max(n_slots, 1))()
+    nw = C.c_size_t()
+    r = L.nxs_test_fixup_scan(blocks, world, n_slots, k, n, rank, which, C.byref(nw))
+    return bool(r), [which[i] for i in range(nw.value)]
+
+
+def fixup_verify(blocks, world, n_slots, k, n):
+    """After the second all-gather (the library's fixup_verify): -1, or the rank that failed the batch."""
+    L = lib()
+    L.nxs_test_fixup_verify.restype = C.c_int
+    L.nxs_test_fixup_verify.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t]
+    return L.nxs_test_fixup_verify(blocks, world, n_slots, k, n)
+
+
 class ShardAborted(NxsError):
     """A rank aborted the sharded batch; every rank raises this for the batch."""
     def __init__(self, rank, code):
@@ -110,7 +140,7 @@ def inject_failure(index, which, nth=1):
     """tests: the nth next _begin ("begin") / exact fix-up round ("fixup") fails."""
     L = lib()
     L.nxs_test_inject_failure.argtypes = [C.c_void_p, C.c_int, C.c_uint]
-    L.nxs_test_inject_failure(index._h, 0 if which == "begin" else 1, nth)
+    L.nxs_test_inject_failure(index._h, {"begin": 0, "fixup": 1, "fixup_recv": 2}[which], nth)
 
 
 def assemble(blocks, world, n_slots, k, n):

@@ -27,6 +27,24 @@ def test_cabi_exports_every_declared_symbol():
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         declared = set(re.findall(r"\b(nxs(?:gpu)?_[a-z0-9_]+)\s*\(", text))
         assert declared == set(names), (hdr, declared ^ set(names))
+    # test hooks and bench accessors are NOT in the public header (csrc/nxs_hooks.h) ...
+    for sym in N.NXS_HOOK_SYMBOLS:
+        assert hasattr(L, sym), sym
+
+
+def test_production_build_has_no_test_hooks():
+    """`make nohooks` = the library a consumer of include/nxs.h links: every declared symbol,
+    none of nxs_hooks.h's (nxs_test_*, nxs_index_device, nxs_index_host_profile)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "nxsearch_amd", "csrc")
+    subprocess.run(["make", "-j8", "-C", csrc, "nohooks"], check=True, capture_output=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(csrc, "libnxsearch_gpu_nohooks.so")],
+                         check=True, capture_output=True, text=True).stdout
+    syms = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    for sym in N.NXS_H_SYMBOLS + N.NXS_GPU_H_SYMBOLS:
+        assert sym in syms, sym
+    assert not [x for x in syms if x.startswith("nxs_test_")]
+    assert not (set(N.NXS_HOOK_SYMBOLS) & syms)
 
 
 def test_params_fromjson_is_what_the_lua_binding_needs(tmp_path):

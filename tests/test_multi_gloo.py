@@ -148,3 +148,82 @@ def test_a_failing_rank_cannot_strand_its_peers(tmp_path):
     ret = mgr.dict()
     mp.spawn(_worker_abort, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
     assert dict(ret) == {0: (1, 2), 1: (1, 2)}
+
+
+def _worker8(rank, world, port, tdir, n, k, ret):
+    """Eight ranks, a C5-shaped batch (n = 8192: 1024 queries per rank), records marked inexact on
+    several ranks (candidate overflow) -> every rank reads the same flags and takes the fix-up
+    round; in the second batch rank 5's exact pass fails IN the fix-up round: it marks its block
+    and still joins the second all-gather, every rank fails that batch, the third is in step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oidx = O.Index(os.path.join(tdir, "nxsterms"), os.path.join(tdir, "nxsdtmap"))
+    queries = [QUERIES[i % len(QUERIES)] for i in range(n)]
+    lo, hi = multi.shard_slice(n, rank, world)
+    cap = multi.shard_capacity(n, world)
+    memo = {}
+
+    def answer(q):
+        if q not in memo:
+            memo[q] = _answer(oidx, q, k)
+        return memo[q]
+
+    def gather(block):
+        send = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+        recv = torch.empty(world * len(block), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)
+        return recv.numpy().tobytes()
+
+    def check(got):
+        ok = len(got) == n
+        for q, g in zip(queries, got):
+            code, want = answer(q)
+            if code:
+                ok &= isinstance(g, Exception) and g.code == code
+            else:
+                ok &= [d for d, _ in g] == [d for d, _ in want]
+                ok &= [struct.pack("<f", s) for _, s in g] == [struct.pack("<f", s) for _, s in want]
+        return ok
+
+    out = []
+    for batch, failing in ((0, None), (1, 5), (2, None)):
+        mine = [answer(q) for q in queries[lo:hi]]
+        # first pass: the overflowed queries carry a truncated answer and the "inexact" mark
+        inexact = [i for i in range(hi - lo) if (lo + i) % 97 == 3 and mine[i][0] == 0 and rank in (1, 5, 6)]
+        first = [(c, r[:1] if i in inexact else r) for i, (c, r) in enumerate(mine)]
+        block = multi.pack_block(first, cap, k)
+        for i in inexact:
+            block = multi.mark_inexact(block, cap, k, i)
+        blocks = gather(block)                                   # the batch's one collective ...
+        need, which = multi.fixup_scan(blocks, world, cap, k, n, rank)
+        assert need and which == inexact, (rank, which, inexact)
+        # ... and the fix-up round every rank enters together
+        blk_bytes = multi.block_bytes(cap, k)
+        own = blocks[rank * blk_bytes:(rank + 1) * blk_bytes]
+        if failing == rank:
+            own = multi.pack_abort(cap, k, 2)
+        else:
+            own = multi.pack_block(mine, cap, k) if which else own
+        blocks2 = gather(own)
+        bad = multi.fixup_verify(blocks2, world, cap, k, n)
+        if failing is None:
+            assert bad == -1
+            out.append(check(multi.assemble(blocks2, world, cap, k, n)))
+        else:
+            out.append(bad == failing)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_fixup_round_and_an_abort_inside_it(tmp_path):
+    world, n, k = 8, 8192, 10
+    nxsfmt.write_index(str(tmp_path), "idx", [(d, t.split()) for d, t in DOCS.items()])
+    tdir = str(tmp_path)
+    if not os.path.exists(os.path.join(tdir, "nxsterms")):
+        tdir = os.path.join(tdir, "data", "idx")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: [True, True, True] for r in range(world)}

@@ -109,6 +109,7 @@ typedef struct {
 	uint32_t	exact_requeries;/* queries re-run through the two-pass path */
 } nxsgpu_results_t;
 
+#define	NXSGPU_PROF_CLS	16
 typedef struct {
 	uint64_t	launches;	/* launches of the dominant scan kernel */
 	double		scan_ms;	/* summed HIP-event time of those      */
@@ -123,6 +124,18 @@ typedef struct {
 	double		fuzzy_dist_ms;	/* k_fz_dist                           */
 	double		fuzzy_chain_ms;	/* k_fz_chain + k_bk_finish            */
 	uint64_t	fuzzy_checked;	/* (token, term) pairs k_fz_filter compared */
+	/*
+	 * Per query CLASS (= one scan launch per batch): HIP events recorded on the stream
+	 * the class's kernels are launched on, around them.  cls_key = kind << 8 | shape << 4
+	 * bits | token bucket (nxs_gpu_search.hip: build_worklist); kind 1 k_scan1 / k_scan8,
+	 * 3 k_scanr, 4 k_scanm, 5 k_cold + k_scanm<.., DROP>, 6 k_scanb, 7 k_scanq, 0 k_scan.
+	 */
+	uint32_t	n_cls;
+	uint32_t	cls_key[NXSGPU_PROF_CLS];
+	uint64_t	cls_launches[NXSGPU_PROF_CLS];
+	double		cls_ms[NXSGPU_PROF_CLS];
+	uint64_t	cls_postings[NXSGPU_PROF_CLS];	/* algorithmic postings of the class's queries */
+	uint64_t	cls_queries[NXSGPU_PROF_CLS];
 } nxsgpu_profile_t;
 
 int		nxsgpu_device_count(void);

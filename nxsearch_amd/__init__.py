@@ -70,7 +70,9 @@ class GpuProfile(C.Structure):
                 ("postings", C.c_uint64), ("fuzzy_visits", C.c_uint64),
                 ("fuzzy_pairs", C.c_uint64), ("fuzzy_level", C.c_uint64 * 40),
                 ("fuzzy_filter_ms", C.c_double), ("fuzzy_dist_ms", C.c_double),
-                ("fuzzy_chain_ms", C.c_double), ("fuzzy_checked", C.c_uint64)]
+                ("fuzzy_chain_ms", C.c_double), ("fuzzy_checked", C.c_uint64),
+                ("n_cls", C.c_uint32), ("cls_key", C.c_uint32 * 16), ("cls_launches", C.c_uint64 * 16),
+                ("cls_ms", C.c_double * 16), ("cls_postings", C.c_uint64 * 16), ("cls_queries", C.c_uint64 * 16)]
 
 
 # every symbol include/nxs.h and include/nxs_gpu.h declare
@@ -621,6 +623,12 @@ class Index:
         lib().nxsgpu_get_profile(self.device, C.byref(p), 1 if reset else 0)
         d = {k: getattr(p, k) for k, _ in GpuProfile._fields_}
         d["fuzzy_level"] = list(d["fuzzy_level"])
+        n = d.pop("n_cls")
+        cls = [{"key": p.cls_key[i], "launches": p.cls_launches[i], "ms": p.cls_ms[i],
+                "postings": p.cls_postings[i], "queries": p.cls_queries[i]} for i in range(n)]
+        for k in ("cls_key", "cls_launches", "cls_ms", "cls_postings", "cls_queries"):
+            d.pop(k)
+        d["classes"] = cls
         return d
 
     def close(self):

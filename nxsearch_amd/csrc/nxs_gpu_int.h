@@ -185,6 +185,12 @@ struct nxsgpu_index {
 		uint8_t *	h_stage;	/* pinned: uploads, then the overflow flags coming back */
 		size_t		h_stage_len;
 		hipEvent_t	ev_up, ev_done, ev_res, ev_t[3];
+		/* profiling: events around each class's scan kernels, on the class's stream (created on demand) */
+		hipEvent_t	ev_cls[NXSGPU_PROF_CLS][2];
+		uint32_t	cls_key[NXSGPU_PROF_CLS];
+		uint64_t	cls_post[NXSGPU_PROF_CLS], cls_q[NXSGPU_PROF_CLS];
+		uint32_t	n_cls;
+		bool		ev_cls_ok;
 		bool		active;
 		bool		records;	/* nxsgpu_batch_begin: results as record blocks */
 		uint32_t	nq;
@@ -410,7 +416,7 @@ struct replay_args_t {
 #define	HEAP_LDS	2
 #define	REPLAY_LDS_K	8000
 
-struct launch_t { uint32_t first, count, nt_bucket, kind, nomask, q_first, q_count; };	/* kind: 0 wide, 1 tile, 2 step */
+struct launch_t { uint32_t first, count, nt_bucket, kind, nomask, q_first, q_count; uint64_t postings; };	/* kind: 0 wide, 1 tile, 2 step */
 
 struct worklist_t {
 	std::vector<qmeta_t>	qmeta;

@@ -334,6 +334,15 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 		l.count = (uint32_t)wl.items.size() - l.first;
 		l.q_first = o0;
 		l.q_count = o1 - o0;
+		l.postings = 0;
+		for (uint32_t oi = o0; oi < o1; oi++) {
+			const dev_query_t &dq = hq[order[oi]];
+			for (uint32_t t = 0; t < dq.nt; t++) {
+				/* (a dropped token whose list was replaced by its outlier list: the term's own df is not known
+				 * here any more -- the class's figure then counts what is scanned) */
+				l.postings += dq.pend[t] - dq.pbeg[t];
+			}
+		}
 		wl.launches.push_back(l);
 		o0 = o1;
 	}
@@ -355,7 +364,7 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
 static void
 launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL,
-    bool replays_aside = false, hipStream_t replay_stream = NULL)
+    bool replays_aside = false, hipStream_t replay_stream = NULL, nxsgpu_index::dev_slot_t *psl = NULL)
 {
 	const hipStream_t st_rp = replay_stream ? replay_stream : ix->stream2;
 	bool forked = false, forked3 = false;
@@ -387,6 +396,21 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			continue;
 		}
 		a.item_base = l.first;
+		/* profiling: events around this class's scan kernels, on the stream they go to */
+		const hipStream_t cls_stream = (side3 && l.kind == 5) ? ix->stream3 : ix->stream;
+		int pc = -1;
+		if (psl && psl->ev_cls_ok && psl->n_cls < NXSGPU_PROF_CLS && MODE_FILTERS(MODE)) {
+			pc = (int)psl->n_cls++;
+			psl->cls_key[pc] = l.kind << 8 | l.nomask << 4 | l.nt_bucket;
+			psl->cls_post[pc] = l.postings;
+			psl->cls_q[pc] = l.q_count;
+			(void)hipEventRecord(psl->ev_cls[pc][0], cls_stream);
+		}
+		auto prof_stop = [&]() {
+			if (pc >= 0) {
+				(void)hipEventRecord(psl->ev_cls[pc][1], cls_stream);
+			}
+		};
 		/* (k_scang: 32-bit posting indexes) */
 		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) &&
 		    !(l.kind == 5 && a0.dense_col == ix->d_dense_col[NXSGPU_TF_IDF]) ? 4u : 0u;	/* (nor outlier lists) */
@@ -416,6 +440,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			}
 			a.flags |= ix->cfg.drop_prio ? 1u : 0u;
 			nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
+			prof_stop();
 			launch_retry(ix->stream3);
 			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
 			continue;
@@ -464,6 +489,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		} else {
 			nxs_launch_scanh(MODE, l.nt_bucket, grid, ix->stream, a);
 		}
+		prof_stop();
 		if (ra && l.q_count) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
@@ -1595,6 +1621,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * stream_rp[0] is the dense-term class's stream) */
 	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream2;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
+	sl->n_cls = 0;
 	if (nq) {
 		if (ix->cfg.one_replay) {
 			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl);
@@ -1603,7 +1630,16 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		} else {
 			/* (profile: "replay" is then only what the last class's replay adds
 			 * after the last scan) */
-			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL);
+			sl->n_cls = 0;
+			if (ix->profiling && !sl->ev_cls_ok) {
+				bool ok = true;
+				for (int c = 0; c < NXSGPU_PROF_CLS && ok; c++) {
+					ok = hipEventCreate(&sl->ev_cls[c][0]) == hipSuccess && hipEventCreate(&sl->ev_cls[c][1]) == hipSuccess;
+				}
+				sl->ev_cls_ok = ok;
+			}
+			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL,
+			    ix->profiling ? sl : NULL);
 		}
 	} else if (ix->profiling) {
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);
@@ -1727,6 +1763,28 @@ slot_wait(nxsgpu_index_t *ix, nxsgpu_index::dev_slot_t *sl)
 		ix->prof.scan_ms += a;
 		ix->prof.replay_ms += b;
 		ix->prof.postings += sl->postings;
+		/* per class (the events sit on the classes' own streams; the batch is done: all have fired) */
+		for (uint32_t c = 0; c < sl->n_cls; c++) {
+			float ms = 0;
+			uint32_t k = 0;
+			if (hipEventElapsedTime(&ms, sl->ev_cls[c][0], sl->ev_cls[c][1]) != hipSuccess) {
+				continue;
+			}
+			while (k < ix->prof.n_cls && ix->prof.cls_key[k] != sl->cls_key[c]) {
+				k++;
+			}
+			if (k == ix->prof.n_cls) {
+				if (k == NXSGPU_PROF_CLS) {
+					continue;
+				}
+				ix->prof.cls_key[k] = sl->cls_key[c];
+				ix->prof.n_cls++;
+			}
+			ix->prof.cls_launches[k]++;
+			ix->prof.cls_ms[k] += ms;
+			ix->prof.cls_postings[k] += sl->cls_post[c];
+			ix->prof.cls_queries[k] += sl->cls_q[c];
+		}
 	}
 	return 0;
 }

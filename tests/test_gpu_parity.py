@@ -1200,7 +1200,10 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
             assert len(a) == min(10, len(b)) and len(b) == min(64, len(cc))
         # independent scan algorithms, same bits
         for env in ({"NXS_GPU_NOSCANM": "1", "NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_GRID": "3"},
-                    {"NXS_GPU_NODROP": "1", "NXS_GPU_WAVES": "8192"}):
+                    {"NXS_GPU_NODROP": "1", "NXS_GPU_WAVES": "8192"},
+                    {"NXS_GPU_NOBLKMAP": "1"},                  # conjunctions on k_scanr instead of the bitmaps
+                    {"NXS_GPU_BM_GAIN": "0"},                   # ... every one of them on the bitmaps (k_scanq)
+                    {"NXS_GPU_SCANB_DENS": "1.0"}):             # the sparse OR class on presence bits (k_scanb)
             for kk, v in env.items():
                 monkeypatch.setenv(kk, v)
             gidx.reconfigure()
@@ -1219,11 +1222,17 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
         for q in (terms[0].decode(), terms[99].decode(), terms[4999].decode()):
             a, b = gidx.search(q, limit=10, fuzzymatch=False), gidx.search(q, fuzzymatch=False)
             assert sc(b)[:10] == sc(a) and len(b) == 1000
-        # the oracle on a sample (both operators; ~0.25 s per query)
+        # the oracle on a sample of 40 (both operators; ~0.25 s per query): every 32nd query plus the
+        # first OR queries that hold a dense term (rank <= 27: the k_cold + k_scanm<.., DROP> class)
         oidx = O.Index(c["terms"], c["dtmap"])
-        for i in (0, 1, 2, 3, 510, 511, 1022, 1023):
+        dense = set(t.decode() for t in terms[:27])
+        with_dense = [i for i, q in enumerate(qs) if " OR " in q and dense & set(q.split())][:8]
+        assert len(with_dense) == 8
+        sample = sorted(set(range(0, 1024, 32)) | set(with_dense))
+        assert len(sample) >= 36
+        for i in sample:
             assert_same(base[i], oidx.search(qs[i], limit=10, fuzzymatch=False), qs[i])
-        for i in (1, 3, 511, 1023):
+        for i in sample[::4] + with_dense[:2]:
             assert_same(tf[i], oidx.search(qs[i], algo=0, limit=10, fuzzymatch=False), (qs[i], "TF-IDF"))
         # ---- configs[3]: Levenshtein d <= 2 over the 1M-term BK-tree, batch 1024 ----
         toks = corpus.queries_fuzzy(terms, 1024, seed=4)
@@ -1254,6 +1263,63 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
         fq = ["%s OR %s" % (toks[i], terms[200 + i].decode()) for i in range(4)]
         pq = ["%s OR %s" % (terms[ids[i] - 1].decode(), terms[200 + i].decode()) for i in range(4)]
         assert bits(gidx.search_batch(fq, limit=10, fuzzymatch=True)) == bits(gidx.search_batch(pq, limit=10, fuzzymatch=False))
+        oidx.close()
+        gidx.close()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_full_size_c5_properties(nxs, monkeypatch):
+    """BASELINE.json configs[4] at its FULL size on one GPU: 50M docs / 2M terms (1.6 G postings), the
+    8192-query mixed batch (75 % five-term AND / OR, 25 % with one misspelt token that the BK-tree
+    search has to resolve), top-10.  The batch goes through the SHARDED entry as the eight ranks of
+    the 8-GPU run, one after the other (each plans and scans ITS slice, the library reassembles
+    the eight record blocks): identical ids and score bits to the unsharded answer; every answer
+    sorted with valid, distinct doc ids; a query with a misspelt token == the same query with the
+    resolved term; eight queries and eight fuzzy tokens against the oracle."""
+    from nxsearch_amd import multi
+    work = "/dev/shm/nxs_fullsize_c5_%d" % os.getpid()
+    n_docs, n_terms, n, k, world = 50_000_000, 2_000_000, 8192, 10, 8
+    try:
+        c = corpus.write_corpus(work, n_docs, n_terms, seed=0)
+        terms = corpus.term_strings(n_terms, seed=0)
+        have = set(terms)
+        gidx = nxs.open_files(c["terms"], c["dtmap"])
+        qs = corpus.queries_mixed(terms, n, seed=6, hi=1000)
+        bits = lambda res: [[(d, struct.pack("<f", s)) for d, s in r] for r in res]
+        base = gidx.search_batch(qs, limit=k)
+        assert not any(isinstance(r, N.NxsError) for r in base)
+        for r in base:
+            assert len(r) <= k and len({d for d, _ in r}) == len(r)
+            assert all(1 <= d <= n_docs for d, _ in r)
+            assert all(a[1] >= b[1] for a, b in zip(r, r[1:]))
+        # the eight ranks of the sharded run, emulated on the one GPU
+        cap = multi.shard_capacity(n, world)
+        blocks = b""
+        for r in range(world):
+            multi.emulate(gidx, r, world)
+            gidx.search_batch_begin(qs, limit=k)
+            gidx.search_batch_end()
+            blk = multi.emulated_block(gidx)
+            assert len(blk) == multi.block_bytes(cap, k)
+            blocks += blk
+        multi.emulate(gidx, 0, 0)
+        assert bits(multi.assemble(blocks, world, cap, k, n)) == bits(base)
+        # fuzzy token inside a query == the resolved term inside it
+        fz = [(i, q) for i, q in enumerate(qs) if any(w.encode() not in have for w in q.split() if w not in ("AND", "OR"))]
+        assert len(fz) > n // 5
+        toks = [[w for w in q.split() if w not in ("AND", "OR") and w.encode() not in have][0] for _, q in fz[:64]]
+        ids = gidx.fuzzy(toks)
+        assert all(ids)
+        resolved = [q.replace(t, terms[tid - 1].decode()) for (_, q), t, tid in zip(fz[:64], toks, ids)]
+        assert bits(gidx.search_batch(resolved, limit=k, fuzzymatch=False)) == bits([base[i] for i, _ in fz[:64]])
+        # the oracle: eight queries (both operators, two with a misspelt token) and eight fuzzy tokens
+        oidx = O.Index(c["terms"], c["dtmap"])
+        sample = [0, 1, 4096, 4097, 8190, 8191, fz[0][0], fz[1][0]]
+        for i in sample:
+            assert_same(base[i], oidx.search(qs[i], limit=k), qs[i])
+        for tok, t in zip(toks[:8], ids[:8]):
+            assert t == oidx.fuzzy(tok.encode())[0], tok
         oidx.close()
         gidx.close()
     finally:

@@ -10,7 +10,7 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
 d = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
-print("bench under rocprof:", d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"])
+print("bench under rocprof:", d["value"], d["ms_per_step"], d["roofline"]["step"]["span_ms"], [(k["kernel"], k["ms"]) for k in d["roofline"]["per_kernel"]])
 f = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
 for i, r in enumerate(csv.DictReader(open(f))):
     if i < 12: print("%-44s calls %4s avg %10.1f us" % (r["Name"][:44], r["Calls"], float(r["AverageNs"]) / 1e3))

@@ -317,7 +317,11 @@ def main():
                            "moved_gbs": round(moved / (ms * 1e-3) / 1e9, 1) if moved else None,
                            "frac_moved": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if moved else None})
     per_kernel.sort(key=lambda e: -e["ms"])
-    dom = per_kernel[0] if per_kernel else None
+    # the dominant kernel: the class that moves the most bytes (classes overlap on two streams, so a
+    # latency-bound class with few wavefronts can span longer than the one that keeps the chip busy);
+    # without a PMC summary: the longest one
+    with_moved = [e for e in per_kernel if e["moved_bytes"]]
+    dom = max(with_moved, key=lambda e: e["moved_bytes"]) if with_moved else (per_kernel[0] if per_kernel else None)
     # the dominant kernel's own roofline point.  If it streams every posting it is charged for
     # (k_scanm, k_scan1) algorithmic == moved and the fraction is a bandwidth fraction; a kernel that
     # skips postings gets its fraction from the bytes it MOVED (never above 1).

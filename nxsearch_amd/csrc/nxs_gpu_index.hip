@@ -105,6 +105,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_workmul = u64("NXS_GPU_DROP_WORKMUL", 2, 1, 64);
 	c.drop_prio = !on("NXS_GPU_DROP_NOPRIO");
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
+	c.drop_tiles = on("NXS_GPU_DROP_TILES");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
 	c.down_inline = on("NXS_GPU_DOWN_INLINE");
 	c.old_replay = on("NXS_GPU_OLDREPLAY");
@@ -1698,6 +1699,17 @@ extern "C" void
 nxsgpu_set_profiling(nxsgpu_index_t *ix, int on)
 {
 	ix->profiling = on != 0;
+	/* the per-class events of both batch slots: created here, not inside a timed batch */
+	for (int i = 0; on && i < 2; i++) {
+		nxsgpu_index::dev_slot_t &sl = ix->slot[i];
+		if (!sl.ev_cls_ok && hipSetDevice(ix->device) == hipSuccess) {
+			bool ok = true;
+			for (int c = 0; c < NXSGPU_PROF_CLS && ok; c++) {
+				ok = hipEventCreate(&sl.ev_cls[c][0]) == hipSuccess && hipEventCreate(&sl.ev_cls[c][1]) == hipSuccess;
+			}
+			sl.ev_cls_ok = ok;
+		}
+	}
 }
 
 extern "C" void

@@ -143,7 +143,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 					/* TF-IDF: from here on the dropped tokens' lists are their outlier lists
 					 * (kernels that stream the terms' own lists must not see this query again:
 					 * qflags) */
-					for (uint32_t t = 0; t < hq[i].nt && hq[i].outl_tfidf; t++) {
+					for (uint32_t t = 0; t < hq[i].nt && hq[i].outl_tfidf && !cf.drop_tiles; t++) {
 						const size_t c = hq[i].drop_col[t];
 						if (((hq[i].drop_mask >> t) & 1) && ix->outl_off[c + 1] > ix->outl_off[c]) {
 							hq[i].pbeg[t] = ix->outl_off[c];
@@ -152,9 +152,11 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 							hq[i].qflags |= 1;
 						}
 					}
-					total -= work[i];
-					work[i] = cf.drop_workmul * (ws + 16384);	/* latency-bound wavefronts: more, shorter ranges */
-					total += work[i];
+					if (!cf.drop_tiles) {
+						total -= work[i];
+						work[i] = cf.drop_workmul * (ws + 16384);	/* latency-bound wavefronts: more, shorter ranges */
+						total += work[i];
+					}
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
 				}
 			}
@@ -438,10 +440,15 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
 				forked3 = true;
 			}
-			a.flags |= ix->cfg.drop_prio ? 1u : 0u;
-			nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
-			prof_stop();
-			launch_retry(ix->stream3);
+			if (ix->cfg.drop_tiles) {
+				nxs_launch_scan8(MODE_TOPK, l.nt_bucket, 1u, grid, ix->stream3, a);
+				prof_stop();
+			} else {
+				a.flags |= ix->cfg.drop_prio ? 1u : 0u;
+				nxs_launch_drop_class(l.nt_bucket, grid, ix->stream3, a);
+				prof_stop();
+				launch_retry(ix->stream3);
+			}
 			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
 			continue;
 		}
@@ -474,7 +481,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			}
 		} else if (l.kind == 5) {
 			/* sparse + dense pure OR: top-k pass with the dense lists dropped */
-			if (topk64) {
+			if (topk64 && !ix->cfg.drop_tiles) {
 				nxs_launch_drop_class(l.nt_bucket, grid, ix->stream, a);
 				launch_retry(ix->stream);
 			} else {
@@ -1631,13 +1638,6 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			/* (profile: "replay" is then only what the last class's replay adds
 			 * after the last scan) */
 			sl->n_cls = 0;
-			if (ix->profiling && !sl->ev_cls_ok) {
-				bool ok = true;
-				for (int c = 0; c < NXSGPU_PROF_CLS && ok; c++) {
-					ok = hipEventCreate(&sl->ev_cls[c][0]) == hipSuccess && hipEventCreate(&sl->ev_cls[c][1]) == hipSuccess;
-				}
-				sl->ev_cls_ok = ok;
-			}
 			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL,
 			    ix->profiling ? sl : NULL);
 		}

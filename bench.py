@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--plan-cache", action="store_true",
+                    help="measure `value` with the library's plan cache on (default: off, see plan_cache_qps)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C3")
     ap.add_argument("--docs", type=int, default=None)
     ap.add_argument("--terms", type=int, default=None)
@@ -185,6 +187,12 @@ def main():
     t0 = time.time()
     nxs = N.Nxs(work)
     idx = nxs.open_files(info["terms"], info["dtmap"], algo="BM25")
+    # The library keeps a plan cache (query string -> compiled plan, cleared at every refresh).  The timed
+    # loop rotates a handful of batches, so with the cache on every query would be a hit and the front half
+    # (lex, parse, resolve, compile) would drop out of the measured step: `value` is measured with the
+    # cache OFF -- every step plans its 1024 strings afresh --, `plan_cache_qps` reports the same loop with
+    # it on (a server's repeated head queries).
+    idx.set_plan_cache(args.plan_cache)
     t_load = time.time() - t0
     L = N.lib()
     B = C.CDLL(os.path.join(N.CSRC, "libnxsbench.so"))
@@ -576,6 +584,13 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
     B.nxs_bench_batches(idx._h, p, qarr, nq, 3, 2, C.byref(o))
     B.nxs_bench_batches(idx._h, p, qarr, nq, args.steps, 2, C.byref(o))
     res["repeated_batch_qps"] = round(nq * args.steps / o.seconds, 1)
+    # (2c) the same loop with the plan cache on: every query string has been seen before
+    if not args.plan_cache:
+        idx.set_plan_cache(True)
+        B.nxs_bench_batches(idx._h, p, qarr, nq, 3, 2, C.byref(o))
+        B.nxs_bench_batches(idx._h, p, qarr, nq, args.steps, 2, C.byref(o))
+        res["plan_cache_qps"] = round(nq * args.steps / o.seconds, 1)
+        idx.set_plan_cache(False)
 
     # (3) single-query latency: nxs_index_search(), one term of rank uniform in
     #     [10, 10^4], top-k, n = 1000, timed inside the C consumer

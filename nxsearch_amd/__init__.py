@@ -615,6 +615,12 @@ class Index:
             return list(ids[:n]), list(vis[:n])
         return list(ids[:n])
 
+    def set_plan_cache(self, on=True):
+        """bench: the index's plan cache (query string -> compiled plan) on / off."""
+        L = lib()
+        L.nxs_index_set_plan_cache.argtypes = [C.c_void_p, C.c_int]
+        L.nxs_index_set_plan_cache(self._h, 1 if on else 0)
+
     def set_profiling(self, on=True):
         lib().nxsgpu_set_profiling(self.device, 1 if on else 0)
 

@@ -28,6 +28,9 @@
 #include "nxs_impl.h"
 #include "nxs_hooks.h"
 
+struct plan_cache;
+static void plan_cache_destroy(struct plan_cache *);
+
 /* ---- host worker pool ------------------------------------------------------ */
 
 /*
@@ -1111,6 +1114,7 @@ nxs_index_close(nxs_index_t *idx)
 	free(idx->emu_block);
 	nxs_filters_destroy(idx->filters);
 	nxs_index_unload(idx);
+	plan_cache_destroy(idx->pcache);
 	free(idx->name);
 	free(idx);
 }
@@ -1120,6 +1124,14 @@ struct nxsgpu_index *
 nxs_index_device(nxs_index_t *idx)
 {
 	return idx->dev;
+}
+
+/* bench: plan cache on / off at run time (the environment decides it otherwise, once) */
+void
+nxs_index_set_plan_cache(nxs_index_t *idx, int on)
+{
+	extern void nxs_plan_cache_switch(nxs_index_t *, int);
+	nxs_plan_cache_switch(idx, on);
 }
 #endif
 
@@ -1348,6 +1360,153 @@ get_search_params(nxs_index_t *idx, nxs_params_t *params, search_params_t *sp)
 }
 
 /*
+ * Plan cache.  The reference builds a query_t per call (construct_query, search.c:176-208);
+ * what that yields for a given query string -- tokens, their term ids, the boolean program --
+ * depends only on the string, the `fuzzymatch` flag and the index's dictionary, so the
+ * compiled plan of a string is kept until the index changes (any refresh clears the cache:
+ * new terms change lookups and fuzzy winners).  A server's head queries then cost a hash
+ * lookup and a 424-byte copy instead of lex + parse + resolve + compile (C2: planning was
+ * 60 % of a 1024-query step).  Lookups run on the worker threads (read-only); the batch's
+ * misses are inserted by the caller's thread afterwards.  Only plans that fit
+ * nxsgpu_query_t and queries without errors are kept.  NXS_PLAN_CACHE=0 turns it off.
+ */
+typedef struct {
+	uint64_t	h;
+	char *		key;		/* NULL = empty slot */
+	uint32_t	klen;
+	uint8_t		fuzzy, empty;
+	nxsgpu_query_t	plan;
+} pc_ent_t;
+
+struct plan_cache {
+	pc_ent_t *	e;
+	size_t		cap, n;		/* cap: a power of two */
+	uint64_t	gen;		/* refreshes of the index when the entries were made */
+	bool		off;
+};
+
+#define	PLAN_CACHE_CAP	(1u << 15)
+
+static uint64_t
+pc_hash(const char *s, size_t n, bool fuzzy)
+{
+	uint64_t h = 1469598103934665603ull ^ (fuzzy ? 0x9e3779b97f4a7c15ull : 0);
+
+	for (size_t i = 0; i < n; i++) {
+		h = (h ^ (uint8_t)s[i]) * 1099511628211ull;
+	}
+	return h ? h : 1;
+}
+
+static void
+plan_cache_clear(struct plan_cache *pc)
+{
+	for (size_t i = 0; pc && pc->e && i < pc->cap; i++) {
+		free(pc->e[i].key);
+		pc->e[i].key = NULL;
+	}
+	if (pc) {
+		pc->n = 0;
+	}
+}
+
+static void
+plan_cache_destroy(struct plan_cache *pc)
+{
+	plan_cache_clear(pc);
+	if (pc) {
+		free(pc->e);
+		free(pc);
+	}
+}
+
+/* the cache of the index, valid for its current snapshot (NULL: off / out of memory) */
+static struct plan_cache *
+plan_cache_get(nxs_index_t *idx)
+{
+	const uint64_t gen = idx->n_incremental + idx->n_rebuilds;
+	struct plan_cache *pc = idx->pcache;
+
+	if (!pc) {
+		const char *e = getenv("NXS_PLAN_CACHE");
+
+		if ((pc = calloc(1, sizeof(*pc))) == NULL) {
+			return NULL;
+		}
+		pc->off = e && atoi(e) == 0;
+		pc->cap = PLAN_CACHE_CAP;
+		if (!pc->off && (pc->e = calloc(pc->cap, sizeof(pc_ent_t))) == NULL) {
+			pc->off = true;
+		}
+		pc->gen = gen;
+		idx->pcache = pc;
+	}
+	if (pc->off) {
+		return NULL;
+	}
+	if (pc->gen != gen || pc->n > pc->cap / 2) {
+		plan_cache_clear(pc);
+		pc->gen = gen;
+	}
+	return pc;
+}
+
+void
+nxs_plan_cache_switch(nxs_index_t *idx, int on)
+{
+	(void)plan_cache_get(idx);
+	if (idx->pcache) {
+		plan_cache_clear(idx->pcache);
+		idx->pcache->off = !on;
+		if (on && !idx->pcache->e && (idx->pcache->e = calloc(idx->pcache->cap, sizeof(pc_ent_t))) == NULL) {
+			idx->pcache->off = true;
+		}
+	}
+}
+
+static const pc_ent_t *
+plan_cache_find(const struct plan_cache *pc, const char *q, size_t n, bool fuzzy)
+{
+	const uint64_t h = pc_hash(q, n, fuzzy);
+
+	for (size_t i = h & (pc->cap - 1); pc->e[i].key; i = (i + 1) & (pc->cap - 1)) {
+		const pc_ent_t *e = &pc->e[i];
+		if (e->h == h && e->klen == n && e->fuzzy == (uint8_t)fuzzy && memcmp(e->key, q, n) == 0) {
+			return e;
+		}
+	}
+	return NULL;
+}
+
+static void
+plan_cache_put(struct plan_cache *pc, const char *q, size_t n, bool fuzzy, const qprep_t *p)
+{
+	const uint64_t h = pc_hash(q, n, fuzzy);
+	size_t i = h & (pc->cap - 1);
+
+	if (pc->n >= pc->cap / 2 || n > 4096) {
+		return;
+	}
+	for (; pc->e[i].key; i = (i + 1) & (pc->cap - 1)) {
+		if (pc->e[i].h == h && pc->e[i].klen == n && pc->e[i].fuzzy == (uint8_t)fuzzy &&
+		    memcmp(pc->e[i].key, q, n) == 0) {
+			return;		/* (twice in one batch) */
+		}
+	}
+	if ((pc->e[i].key = malloc(n + 1)) == NULL) {
+		return;
+	}
+	memcpy(pc->e[i].key, q, n);
+	pc->e[i].key[n] = 0;
+	pc->e[i].h = h;
+	pc->e[i].klen = (uint32_t)n;
+	pc->e[i].fuzzy = (uint8_t)fuzzy;
+	pc->e[i].empty = (uint8_t)p->empty;
+	pc->e[i].plan = p->plan;
+	pc->n++;
+}
+
+/*
  * Front half of a batch: parse, build the token sets, resolve (exact on the
  * host, misses through one device BK-tree pass), compile the device plans.
  * prep[i].errcode / .empty tell how query i ended.  Parsing + lookups and the
@@ -1358,6 +1517,7 @@ typedef struct {
 	const search_params_t *	sp;
 	const char *const *	queries;
 	qprep_t *		prep;
+	const struct plan_cache *pc;	/* read-only while the workers run */
 } plan_job_t;
 
 static void
@@ -1368,6 +1528,16 @@ plan_parse_chunk(void *arg, size_t lo, size_t hi)
 	for (size_t i = lo; i < hi; i++) {
 		qprep_t *q = &j->prep[i];
 
+		if (j->pc) {
+			const pc_ent_t *e = plan_cache_find(j->pc, j->queries[i], strlen(j->queries[i]), j->sp->fuzzymatch);
+			if (e) {
+				memset(q, 0, sizeof(*q));
+				q->plan = e->plan;
+				q->empty = e->empty != 0;
+				q->cached = true;
+				continue;
+			}
+		}
 		nxs_query_prepare(j->idx, j->queries[i], q);
 		if (q->errcode) {
 			continue;
@@ -1386,6 +1556,9 @@ plan_compile_chunk(void *arg, size_t lo, size_t hi)
 	const plan_job_t *j = arg;
 
 	for (size_t i = lo; i < hi; i++) {
+		if (j->prep[i].cached) {
+			continue;
+		}
 		if (!j->prep[i].errcode) {
 			(void)nxs_query_compile(&j->prep[i]);
 		}
@@ -1401,7 +1574,8 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 {
 	nxs_t *nxs = idx->nxs;
 	struct nxs_pool *pool = n >= 64 ? nxs_pool_get(nxs) : NULL;
-	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep };
+	struct plan_cache *pc = plan_cache_get(idx);
+	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep, .pc = pc };
 	uint32_t *fz_q = NULL, *fz_t = NULL, *fz_off = NULL, *fz_ids = NULL;
 	uint8_t *fz_bytes = NULL;
 	size_t n_fz = 0, fz_len = 0;
@@ -1464,6 +1638,13 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 		}
 	}
 	pool_run(pool, plan_compile_chunk, &job, n, 32);
+	/* the batch's new plans into the cache (this thread only) */
+	for (size_t i = 0; pc && i < n; i++) {
+		const qprep_t *q = &prep[i];
+		if (!q->cached && !q->errcode && !q->wide) {
+			plan_cache_put(pc, queries[i], strlen(queries[i]), sp->fuzzymatch, q);
+		}
+	}
 	ret = 0;
 out:
 	free(fz_q);

@@ -267,52 +267,57 @@ k_dense_fill(const posting_t *__restrict__ post, uint64_t beg, uint64_t end, uin
 }
 
 /*
- * Block-presence bitmap + rank directory of one list (d_blkmap / d_bmrank rows): a thread takes
- * CH consecutive postings, ORs their block bits into the word it is in and writes that word
- * (atomically: neighbours share words) whenever it changes; a posting that is the first of its
- * 4096-doc word -- its predecessor lies in an earlier word -- records its position for that word
- * and for the empty words in between.
+ * Block-presence bitmap + rank directory of one list (d_blkmap / d_bmrank rows).  A wavefront
+ * reads 64 consecutive postings (coalesced); docs ascend, so the postings of one 4096-doc word
+ * are a RUN of lanes: the run's bits are OR-ed together by a segmented scan across the lanes
+ * and its last lane issues the one atomic (runs continue in the neighbouring wavefronts).  A
+ * posting whose predecessor lies in an earlier word records its position for its word and for
+ * the empty words in between (the rank directory).
  */
 __global__ void
 k_blkmap_fill(const uint64_t *__restrict__ post_dt, const uint64_t *__restrict__ rows_beg,
     const uint64_t *__restrict__ rows_end, uint64_t words, unsigned long long *__restrict__ blkmap,
     uint32_t *__restrict__ bmrank)
 {
-	constexpr uint32_t CH = 16;
 	const uint32_t row = blockIdx.y;
+	const unsigned lane = threadIdx.x & 63;
 	const uint64_t beg = rows_beg[row], end = rows_end[row];
 	unsigned long long *bm = blkmap + (uint64_t)row * words;
 	uint32_t *rk = bmrank + (uint64_t)row * (words + 1);
-	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * CH;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 
-	for (uint64_t i0 = beg + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH; i0 < end; i0 += stride) {
-		const uint64_t i1 = min(i0 + CH, end);
-		uint64_t cw = ~0ull, acc = 0;
-		uint64_t pw = i0 > beg ? (post_dt[i0 - 1] >> 32) >> 12 : ~0ull;	/* word of the predecessor */
-		for (uint64_t i = i0; i < i1; i++) {
-			const uint32_t doc = (uint32_t)(post_dt[i] >> 32);
-			const uint64_t w = doc >> 12;
-			if (w != cw) {
-				if (acc) {
-					atomicOr(&bm[cw], (unsigned long long)acc);
-				}
-				cw = w;
-				acc = 0;
-			}
-			acc |= 1ull << ((doc >> 6) & 63);
-			if (w != pw) {
-				/* first posting of word w: it starts w and every empty word after pw */
-				for (uint64_t e = (pw == ~0ull ? 0 : pw + 1); e <= w; e++) {
-					rk[e] = (uint32_t)(i - beg);
-				}
-				pw = w;
+	for (uint64_t i0 = beg + ((uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); i0 < end; i0 += stride) {
+		const uint64_t i = i0 + lane;
+		const bool valid = i < end;
+		const uint32_t doc = valid ? (uint32_t)(post_dt[i] >> 32) : 0xffffffffu;
+		const uint64_t w = valid ? doc >> 12 : ~0ull;
+		/* word of the predecessor (lane 0: the posting before the window) */
+		uint64_t pw = (uint64_t)__shfl_up((long long)w, 1);
+		if (lane == 0) {
+			pw = i0 > beg ? (post_dt[i0 - 1] >> 32) >> 12 : ~0ull;
+		}
+		unsigned long long acc = valid ? 1ull << ((doc >> 6) & 63) : 0;
+		/* segmented inclusive OR over the run of equal words (runs are contiguous) */
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned long long v = (unsigned long long)__shfl_up((long long)acc, o);
+			const uint64_t wv = (uint64_t)__shfl_up((long long)w, o);
+			if ((int)lane >= o && wv == w) {
+				acc |= v;
 			}
 		}
-		if (acc) {
-			atomicOr(&bm[cw], (unsigned long long)acc);
+		const uint64_t nw = (uint64_t)__shfl_down((long long)w, 1);
+		if (valid && (lane == 63 || nw != w)) {
+			atomicOr(&bm[w], acc);		/* the run's last lane */
 		}
-		if (i1 == end) {
-			for (uint64_t e = pw + 1; e <= words; e++) {
+		if (valid && w != pw) {
+			/* first posting of word w: it starts w and every empty word after pw */
+			for (uint64_t e = (pw == ~0ull ? 0 : pw + 1); e <= w; e++) {
+				rk[e] = (uint32_t)(i - beg);
+			}
+		}
+		if (valid && i + 1 == end) {
+			for (uint64_t e = w + 1; e <= words; e++) {
 				rk[e] = (uint32_t)(end - beg);
 			}
 		}

@@ -22,6 +22,8 @@ void		nxs_index_host_profile(nxs_index_t *, double out[8]);
 /* the device-side handle behind an index (nxs_gpu.h): pre-resolved plans, results left in HBM */
 struct nxsgpu_index;
 struct nxsgpu_index *nxs_index_device(nxs_index_t *);
+/* the plan cache (query string -> compiled plan) on / off at run time */
+void		nxs_index_set_plan_cache(nxs_index_t *, int on);
 
 /* worker pool: every item of every run worked on exactly once */
 size_t		nxs_test_pool(unsigned n_thr, size_t n, unsigned rounds, size_t chunk);

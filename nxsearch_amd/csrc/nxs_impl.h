@@ -119,6 +119,7 @@ struct nxs_index {
 	struct nxs_pend	pend[2];
 	/* tests: the n-th next _begin / exact fix-up of this index fails (0: off) */
 	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv;
+	struct plan_cache *pcache;	/* query string -> compiled plan (nxs_api.c: plan_batch) */
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
 	double		hp_plan, hp_queue, hp_wait, hp_resps, hp_begin, hp_end;
@@ -233,6 +234,7 @@ typedef struct qprep {
 	char *		errmsg;
 	bool		empty;		/* no live tokens: empty result */
 	bool		wide;		/* does not fit nxsgpu_query_t: wplan is its plan */
+	bool		cached;		/* the plan came from the index's plan cache: nothing was parsed */
 	nxsgpu_query_t	plan;
 	nxsgpu_wide_query_t wplan;	/* arrays owned by this object */
 	char **		heap_vals;	/* token values a filter grew beyond the arena's reserve */

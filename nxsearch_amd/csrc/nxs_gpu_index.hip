@@ -106,6 +106,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_prio = !on("NXS_GPU_DROP_NOPRIO");
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 	c.drop_tiles = on("NXS_GPU_DROP_TILES");
+	c.no_straggler = on("NXS_GPU_NOSTRAGGLER");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
 	c.down_inline = on("NXS_GPU_DOWN_INLINE");
 	c.old_replay = on("NXS_GPU_OLDREPLAY");

@@ -135,6 +135,7 @@ struct gpu_cfg_t {
 	uint64_t	drop_minpost;	/* NXS_GPU_DROP_MINPOST: fewest sparse postings for that path */
 	uint64_t	drop_workmul;	/* NXS_GPU_DROP_WORKMUL: range count multiplier of that class */
 	bool		drop_prio, drop_side;	/* !NXS_GPU_DROP_NOPRIO / !NXS_GPU_DROP_NOSIDE */
+	bool		no_straggler;	/* NXS_GPU_NOSTRAGGLER: tiny tile-path OR classes stay launches of their own */
 	bool		drop_tiles;	/* NXS_GPU_DROP_TILES: the sparse + dense class streams its dense lists on the accumulator
 					 * tiles (k_scan8) -- still beside the other classes, on the side stream (experiment) */
 	bool		debug_timing;	/* NXS_GPU_DEBUG_TIMING: per-batch host phases of _begin to stderr */

@@ -49,6 +49,8 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	const bool by_level = cf.by_level;
 	/* (limits > 64 -- big_k -- filter on a histogram threshold: the accumulator tiles,
 	 * k_scanr and k_scan1 have that mode, the mask path and the dense-term class do not) */
+	/* NXS_GPU_NOSTRAGGLER: keep tiny tile-path classes (below) as launches of their own */
+	const bool merge_stragglers = !cf.no_straggler;
 	const bool use_scanm = cf.use_scanm && ix->n_docs < (1ull << 31) && big_k == 0;
 	const bool scanm_general = cf.scanm_general;
 	const uint32_t scanm_minnt = cf.scanm_minnt, scanm_maxnt = cf.scanm_maxnt;
@@ -199,6 +201,29 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 						cls[i] = 7u * 64 + (cls[i] & 16u) + nt_bucket(hq[i].nt);
 					}
 				}
+			}
+		}
+	}
+	/*
+	 * Stragglers.  A pure-OR query whose lists are too dense for the mask path and that
+	 * cannot drop them either (two dense terms, a ceiling too close to the sparse ones)
+	 * takes the accumulator tiles -- a class of ONE or two queries in a C3 batch: a launch
+	 * of its own on the scan stream, 0.1 ms of latency for 8 MB of postings, with nothing
+	 * to run beside.  The mask kernel takes any density (it is merely slower per dense
+	 * posting): up to four such queries join the batch's mask-path class of their shape,
+	 * where their ranges are wavefronts among tens of thousands.
+	 */
+	if (merge_stragglers && use_scanm) {
+		uint32_t n_in[8 * 64] = { 0 };
+		for (uint32_t i = 0; i < nq; i++) {
+			n_in[cls[i] & 511]++;
+		}
+		for (uint32_t i = 0; i < nq; i++) {
+			const uint32_t c = cls[i];
+			const uint32_t to = 4u * 64 + 16u + (c & 15);
+			if ((c >> 6) == 1 && ((c >> 4) & 3) == 1 && (c & 15) >= 2 && n_in[c] <= 4 && n_in[to] >= 32 &&
+			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
+				cls[i] = to;
 			}
 		}
 	}

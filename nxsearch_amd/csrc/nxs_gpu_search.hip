@@ -225,6 +225,11 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
 				cls[i] = to;
 			}
+			/* (the same for a handful of very sparse queries that would take k_scanb: a launch of
+			 * their own only pays with enough of them) */
+			if ((c >> 6) == 6 && n_in[c] < 64 && n_in[c - 2u * 64] >= 32) {
+				cls[i] = c - 2u * 64;
+			}
 		}
 	}
 	/* (limits > 64: a range's own threshold needs well over k matches to form, and

@@ -522,7 +522,11 @@ def pmc_traffic(args, world):
 def class_kernels(key, mode):
     """Kernel names (as rocprofv3 prints them) of a query class; key = kind << 8 | shape << 4 | token bucket
     (nxsgpu_profile_t::cls_key), mode = 0 (limit <= 64) / 3 (MODE_BIG)."""
+    ahead = (key >> 7) & 1          # a launch of the class's top doc ranges, sent ahead of the rest
+    key &= ~0x80
     kind, shape, b = key >> 8, (key >> 4) & 15, key & 15
+    if ahead:
+        return [n + " [top ranges ahead]" for n in class_kernels(key, mode)]
     b3 = 3 if b in (2, 3) else b
     tf = lambda x: "true" if x else "false"
     if kind == 1:

@@ -107,6 +107,9 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_side = !on("NXS_GPU_DROP_NOSIDE");
 	c.drop_tiles = on("NXS_GPU_DROP_TILES");
 	c.no_straggler = on("NXS_GPU_NOSTRAGGLER");
+	c.drop_split = (uint32_t)u64("NXS_GPU_DROP_SPLIT", 1, 0, 64);
+	c.drop_early = !on("NXS_GPU_DROP_NOEARLY");
+	c.drop_b = on("NXS_GPU_DROPB");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
 	c.down_inline = on("NXS_GPU_DOWN_INLINE");
 	c.old_replay = on("NXS_GPU_OLDREPLAY");
@@ -638,6 +641,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 			(void)hipHostFree(sl.h_stage);
 		}
 		if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+		if (sl.ev_ahead) (void)hipEventDestroy(sl.ev_ahead);
 		if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
 		if (sl.ev_res) (void)hipEventDestroy(sl.ev_res);
 		delete_worklist(sl.wl);
@@ -1225,6 +1229,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_ahead, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_res, hipEventDisableTiming));
 		for (int j = 0; j < 3; j++) {

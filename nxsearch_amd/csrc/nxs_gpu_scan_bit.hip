@@ -701,16 +701,21 @@ k_scanb(const scan_args_t A)
 /* ---- launchers ------------------------------------------------------ */
 
 /* k_scanb, top-k filter pass (1 <= k <= 64), 2..5 tokens (build_worklist routes nothing else
- * here); gen: the expression is more than an OR.  (The kernel has a DROP form -- dense terms
- * from their columns, cold_state -- that is not instantiated: the sparse + dense class stays on
- * k_cold + k_scanm<.., DROP>.) */
+ * here); gen: the expression is more than an OR; drop: the sparse + dense class's second kernel
+ * (dense terms from their columns, cold_state from k_cold), NXS_GPU_DROPB */
 void
 nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid_, hipStream_t st, const scan_args_t &a)
 {
 	const dim3 grid(grid_), block(WAVE);
 
-	(void)drop;
-	if (!gen) {
+	if (drop) {
+		/* the sparse + dense class (behind k_cold, which nxs_launch_drop_class has queued) */
+		switch (nt_bucket) {
+		case 2:
+		case 3: hipLaunchKernelGGL((k_scanb<3, false, true>), grid, block, 0, st, a); break;
+		default: hipLaunchKernelGGL((k_scanb<5, false, true>), grid, block, 0, st, a); break;
+		}
+	} else if (!gen) {
 		switch (nt_bucket) {
 		case 2:		/* two tokens: the third slot stays empty */
 		case 3: hipLaunchKernelGGL((k_scanb<3, false, false>), grid, block, 0, st, a); break;

@@ -343,6 +343,22 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 				 * its own: when the others start it has published the 10th best of its
 				 * 4096 postings, and they emit a seventh of that.
 				 */
+				/*
+				 * The sparse + dense class (k_cold + k_scanm<.., DROP>) of a mixed batch is a few
+				 * thousand wavefronts: ALL of them fit the GPU at once, so no range ever finds a
+				 * threshold published by a higher one -- every range walks its cold phase and
+				 * pushes on a weak threshold (8 x the pending docs of the plain class).  The first
+				 * level(s) go ahead in a launch of their own here too.
+				 */
+				if (lev + 1 == cf.drop_split && l.kind == 5 && max_g > cf.drop_split && !big_k && !solo) {
+					launch_t l0 = l;
+					l0.count = (uint32_t)wl.items.size() - l0.first;
+					l0.q_first = o0;
+					l0.q_count = 0;			/* (no replay behind this one) */
+					l0.postings = 0;
+					wl.launches.push_back(l0);
+					l.first = (uint32_t)wl.items.size();
+				}
 				if (lev == 0 && l.kind == 1 && l.nt_bucket == 1 && max_g >= cf.scan1_split && !big_k && !solo) {
 					launch_t l0 = l;
 					l0.count = (uint32_t)wl.items.size() - l0.first;
@@ -396,7 +412,8 @@ launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q
 static void
 launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL,
-    bool replays_aside = false, hipStream_t replay_stream = NULL, nxsgpu_index::dev_slot_t *psl = NULL)
+    bool replays_aside = false, hipStream_t replay_stream = NULL, nxsgpu_index::dev_slot_t *psl = NULL,
+    hipEvent_t ahead_done = NULL)
 {
 	const hipStream_t st_rp = replay_stream ? replay_stream : ix->stream2;
 	bool forked = false, forked3 = false;
@@ -433,7 +450,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		int pc = -1;
 		if (psl && psl->ev_cls_ok && psl->n_cls < NXSGPU_PROF_CLS && MODE_FILTERS(MODE)) {
 			pc = (int)psl->n_cls++;
-			psl->cls_key[pc] = l.kind << 8 | l.nomask << 4 | l.nt_bucket;
+			/* (bit 7: a launch of top levels sent ahead -- no queries end in it) */
+			psl->cls_key[pc] = l.kind << 8 | l.nomask << 4 | l.nt_bucket | (l.q_count == 0 && ra ? 0x80u : 0u);
 			psl->cls_post[pc] = l.postings;
 			psl->cls_q[pc] = l.q_count;
 			(void)hipEventRecord(psl->ev_cls[pc][0], cls_stream);
@@ -446,6 +464,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		/* (k_scang: 32-bit posting indexes) */
 		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) &&
 		    !(l.kind == 5 && a0.dense_col == ix->d_dense_col[NXSGPU_TF_IDF]) ? 4u : 0u;	/* (nor outlier lists) */
+		/* (k_scanb<.., DROP>: up to five tokens, no doc grid) */
+		a.flags |= (l.kind == 5 && ix->cfg.drop_b && l.nt_bucket <= 5 && !(a.flags & 4)) ? 8u : 0u;
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
 		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6);
@@ -468,6 +488,9 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			if (!forked3) {
 				(void)hipEventRecord(ix->ev_fork3, ix->stream);
 				(void)hipStreamWaitEvent(ix->stream3, ix->ev_fork3, 0);
+				if (ahead_done) {
+					(void)hipStreamWaitEvent(ix->stream3, ahead_done, 0);	/* the class's top ranges (upload stream) */
+				}
 				forked3 = true;
 			}
 			if (ix->cfg.drop_tiles) {
@@ -479,7 +502,9 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				prof_stop();
 				launch_retry(ix->stream3);
 			}
-			nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
+			if (l.q_count) {
+				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
+			}
 			continue;
 		}
 		if (l.kind == 0) {
@@ -1643,6 +1668,40 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		set_error("query upload failed");
 		return begin_fail(ix);
 	}
+	/*
+	 * The top doc ranges of the sparse + dense class (build_worklist: a launch of their own,
+	 * one wavefront per query -- 0.3-0.4 ms of pure latency: a cold phase, then a whole
+	 * range on a cold threshold) depend on the plans and the cursors only: they go to the
+	 * upload stream right here, i.e. beside the PREVIOUS batch's scans; when this batch's
+	 * turn comes their thresholds are published and the class's other ranges start warm.
+	 */
+	sl->ahead = false;
+	if (!solo && nq && !big && limit <= WAVE && ix->cfg.drop_early && ix->cfg.drop_side && !ix->cfg.drop_tiles &&
+	    !ix->cfg.one_replay) {
+		size_t n_l = 0;
+		for (const launch_t &l : wl.launches) {
+			n_l += l.count != 0;
+		}
+		for (launch_t &l : wl.launches) {
+			if (l.kind == 5 && l.q_count == 0 && l.count && n_l > 2 &&
+			    !(((ix->cfg.use_grid >> 1) & 1) && ix->n_post < (1ull << 32))) {
+				scan_args_t a = sa;
+				a.item_base = l.first;
+				a.flags |= ix->cfg.drop_prio ? 1u : 0u;
+				a.flags |= (ix->cfg.drop_b && l.nt_bucket <= 5) ? 8u : 0u;
+				a.retry_count = NULL;
+				a.retry_items = NULL;
+				a.retry_cap = 0;
+				nxs_launch_drop_class(l.nt_bucket, l.count, s_up, a);
+				l.count = 0;		/* (launch_scan skips it) */
+				sl->ahead = true;
+			}
+		}
+		if (sl->ahead && hipEventRecord(sl->ev_ahead, s_up) != hipSuccess) {
+			set_error("hipEventRecord failed");
+			return begin_fail(ix);
+		}
+	}
 	tc[2] = now_us();
 	/*
 	 * MODE_BIG, one rank: the replays (milliseconds: thousands of heap insertions
@@ -1669,7 +1728,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			 * after the last scan) */
 			sl->n_cls = 0;
 			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL,
-			    ix->profiling ? sl : NULL);
+			    ix->profiling ? sl : NULL, sl->ahead ? sl->ev_ahead : NULL);
 		}
 	} else if (ix->profiling) {
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);

@@ -503,7 +503,12 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  # terms have one / every term has one / many short ranges / never
                                  {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"},
                                  {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
-                                 {"NXS_GPU_NOBLKMAP": "1"}])
+                                 {"NXS_GPU_NOBLKMAP": "1"},
+                                 # the sparse + dense class on k_cold + k_scanb<.., DROP>; its top ranges not sent ahead
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_DROP_SPLIT": "0"},
+                                 {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_DROP_NOEARLY": "1", "NXS_GPU_DROP_SPLIT": "2"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
     """The tile path (k_scan8), the posting-step path (k_scanh), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
@@ -1143,7 +1148,11 @@ def test_doc_sharded_rank_form_through_rccl(nxs, tmp_path):
                                  # TF-IDF: the dense terms' caps and outlier lists -- few outliers, half of the list, none
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "64"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "2", "NXS_GPU_WAVES": "64"},
-                                 {"NXS_GPU_TFIDF_NODROP": "1"}])
+                                 {"NXS_GPU_TFIDF_NODROP": "1"},
+                                 # the class's second kernel on presence bits (k_scanb<.., DROP>), outlier lists included
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "2", "NXS_GPU_WAVES": "64"}])
 def test_dense_terms_leave_sparse_or_scans(nxs, tmp_path, monkeypatch, env):
     """k_scanm<.., DROP>: pure-OR queries that mix dense terms (8 % of the docs and
     more) with sparse ones.  The dense lists are scanned only until the threshold

@@ -4,7 +4,7 @@
 # workloads (C2, C4, C5, the default limit, sparse doc ids, doc shards) with their own kernel stats and
 # -- C2, C5 -- their own HBM traffic.   Usage: tools/profile_round.sh <tag>   outputs: gpurun_out/<tag>_summary/
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 out=$PWD/gpurun_out
 sum=$out/${tag}_summary
 mkdir -p "$sum"
@@ -55,6 +55,8 @@ for w in C2 C4; do
       --calib "$out/${tag}_pmc_calib" --calib-json "$sum/${tag}_pmc_calib.json"
   python3 bench.py --workload $w --cpu-seconds 10 > "$sum/${tag}_${lw}_bench.json" 2>> "$out/${tag}_bench.err"
 done
+# C2 with the plan cache on (the loop's query strings repeat: planning becomes a hash lookup)
+python3 bench.py --workload C2 --plan-cache --cpu-seconds 0 --no-extras > "$sum/${tag}_c2_plancache_bench.json" 2>> "$out/${tag}_bench.err"
 # the default limit (params == NULL => 1000): MODE_BIG kernels + k_replay_coop
 prof l1000 --limit 1000
 python3 tools/pmc_summary.py --stats "$out/${tag}_l1000_stats" --steps 8 --out-prefix "$sum/${tag}_l1000" --command "$B --limit 1000" --limit 1000

@@ -27,7 +27,12 @@ sets = {
   "C": [" OR ".join(T(r) for r in rng.sample(range(1, 1001), 5)) for _ in range(batch)],
   "E": [" OR ".join(T(r) for r in rng.sample(range(500, 1001), 5)) for _ in range(batch)],
   "K": [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 5)) for _ in range(batch)],
+  "R": [" OR ".join(T(r) for r in [rng.randint(1, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(batch)],
+  "S": [" OR ".join(T(r) for r in [rng.randint(1, 5)] + rng.sample(range(100, 1001), 4)) for _ in range(batch)],
+  "V": [" OR ".join(T(r) for r in [rng.randint(15, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(batch)],
 }
+if os.environ.get("STATS_SETS"):
+    sets = {k: v for k, v in sets.items() if k in os.environ["STATS_SETS"].split(",")}
 L = N.lib()
 L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 L.nxsgpu_debug_stats_grid.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]

@@ -110,6 +110,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.drop_split = (uint32_t)u64("NXS_GPU_DROP_SPLIT", 1, 0, 64);
 	c.drop_early = !on("NXS_GPU_DROP_NOEARLY");
 	c.drop_b = on("NXS_GPU_DROPB");
+	c.and_early = !on("NXS_GPU_AND_NOEARLY");
 	c.debug_timing = on("NXS_GPU_DEBUG_TIMING");
 	c.down_inline = on("NXS_GPU_DOWN_INLINE");
 	c.old_replay = on("NXS_GPU_OLDREPLAY");
@@ -642,6 +643,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 		}
 		if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
 		if (sl.ev_ahead) (void)hipEventDestroy(sl.ev_ahead);
+		if (sl.ev_early) (void)hipEventDestroy(sl.ev_early);
 		if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
 		if (sl.ev_res) (void)hipEventDestroy(sl.ev_res);
 		delete_worklist(sl.wl);
@@ -1230,6 +1232,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_ahead, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_early, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_done, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_res, hipEventDisableTiming));
 		for (int j = 0; j < 3; j++) {

@@ -138,6 +138,8 @@ struct gpu_cfg_t {
 	uint32_t	drop_split;	/* NXS_GPU_DROP_SPLIT (1): this many top levels of the sparse + dense class go ahead in a launch of their own (0: none) */
 	bool		drop_b;		/* NXS_GPU_DROPB: the sparse + dense class's second kernel is k_scanb<.., DROP> (64k-doc tiles:
 					 * a handful of flushes per wavefront, each gathering the dense impacts of ~100 candidates at once) */
+	bool		and_early;	/* !NXS_GPU_AND_NOEARLY: the conjunctive classes (k_scanr, k_scanq) run on the upload stream,
+					 * beside the previous batch's scans */
 	bool		drop_early;	/* !NXS_GPU_DROP_NOEARLY: ... on the upload stream, right behind k_cursors: beside the PREVIOUS batch */
 	bool		no_straggler;	/* NXS_GPU_NOSTRAGGLER: tiny tile-path OR classes stay launches of their own */
 	bool		drop_tiles;	/* NXS_GPU_DROP_TILES: the sparse + dense class streams its dense lists on the accumulator
@@ -192,6 +194,7 @@ struct nxsgpu_index {
 		uint8_t *	h_stage;	/* pinned: uploads, then the overflow flags coming back */
 		size_t		h_stage_len;
 		hipEvent_t	ev_up, ev_done, ev_res, ev_t[3];
+		hipEvent_t	ev_early;	/* the conjunctive classes, run early on the upload stream, and their replays are done */
 		hipEvent_t	ev_ahead;	/* the sparse + dense class's top ranges, run ahead on the upload stream, are done */
 		bool		ahead;		/* ... this batch has such a launch */
 		/* profiling: events around each class's scan kernels, on the class's stream (created on demand) */

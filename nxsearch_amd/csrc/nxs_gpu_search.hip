@@ -413,10 +413,10 @@ static void
 launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_t &wl,
     const replay_args_t *ra = NULL, const uint32_t *d_qorder = NULL, hipEvent_t scans_done = NULL,
     bool replays_aside = false, hipStream_t replay_stream = NULL, nxsgpu_index::dev_slot_t *psl = NULL,
-    hipEvent_t ahead_done = NULL)
+    hipEvent_t ahead_done = NULL, hipStream_t early_stream = NULL, hipEvent_t early_done = NULL)
 {
 	const hipStream_t st_rp = replay_stream ? replay_stream : ix->stream2;
-	bool forked = false, forked3 = false;
+	bool forked = false, forked3 = false, early_any = false;
 	/* where the replay's heap lives: across the lanes (k <= 64) or in LDS (MODE_BIG) */
 	const int heap = a0.k <= WAVE ? HEAP_REG : HEAP_LDS;
 	const size_t heap_lds = heap == HEAP_LDS ? (size_t)a0.k * 8 : 0;
@@ -429,8 +429,20 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	/* the sparse + dense class goes to its own stream when there is something to
 	 * run it beside (top-k pass only: its replay follows it there) */
 	const bool side3 = MODE == MODE_TOPK && ra && n_launches > 1 && a0.k >= 1 && a0.k <= WAVE && ix->cfg.drop_side;
+	/*
+	 * The conjunctive classes of a mixed batch (k_scanr, k_scanq: a few thousand latency-bound
+	 * wavefronts, 0.3 ms on the scan stream with the chip nearly idle) run EARLY: on the upload
+	 * stream, behind this batch's k_cursors -- i.e. beside the previous batch's big scans --, their
+	 * heap replays with them; the batch's end waits for them (early_done).
+	 */
+	size_t n_late = 0;
 	for (const launch_t &l : wl.launches) {
-		if (l.count && !(side3 && l.kind == 5)) {
+		n_late += l.count && !(l.kind == 3 || l.kind == 7);
+	}
+	const bool early_ok = early_stream && early_done && MODE == MODE_TOPK && ra && n_late >= 1 &&
+	    a0.k >= 1 && a0.k <= WAVE;
+	for (const launch_t &l : wl.launches) {
+		if (l.count && !(side3 && l.kind == 5) && !(early_ok && (l.kind == 3 || l.kind == 7))) {
 			last_launch = &l;
 		}
 	}
@@ -446,7 +458,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		}
 		a.item_base = l.first;
 		/* profiling: events around this class's scan kernels, on the stream they go to */
-		const hipStream_t cls_stream = (side3 && l.kind == 5) ? ix->stream3 : ix->stream;
+		const bool early = early_ok && (l.kind == 3 || l.kind == 7);
+		const hipStream_t cls_stream = (side3 && l.kind == 5) ? ix->stream3 : early ? early_stream : ix->stream;
 		int pc = -1;
 		if (psl && psl->ev_cls_ok && psl->n_cls < NXSGPU_PROF_CLS && MODE_FILTERS(MODE)) {
 			pc = (int)psl->n_cls++;
@@ -505,6 +518,21 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			if (l.q_count) {
 				nxs_launch_replay(HEAP_REG, l.q_count, 0, ix->stream3, r);
 			}
+			continue;
+		}
+		if (early) {
+			replay_args_t r = *ra;
+			r.qlist = d_qorder + l.q_first;
+			if (l.kind == 7) {
+				nxs_launch_scanq(l.nt_bucket, grid, early_stream, a);
+			} else {
+				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, early_stream, a);
+			}
+			prof_stop();
+			if (l.q_count) {
+				nxs_launch_replay(heap, l.q_count, heap_lds, early_stream, r);
+			}
+			early_any = true;
 			continue;
 		}
 		if (l.kind == 0) {
@@ -580,6 +608,13 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	}
 	if (scans_done) {
 		(void)hipEventRecord(scans_done, ix->stream);
+	}
+	if (early_any) {
+		(void)hipEventRecord(early_done, early_stream);
+		(void)hipStreamWaitEvent(ix->stream, early_done, 0);
+		if (replays_aside) {
+			(void)hipStreamWaitEvent(st_rp, early_done, 0);		/* the batch ends there */
+		}
 	}
 	/*
 	 * replays_aside (MODE_BIG batches: a replay is thousands of heap insertions on one
@@ -1728,7 +1763,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			 * after the last scan) */
 			sl->n_cls = 0;
 			launch_scan(big ? MODE_BIG : MODE_TOPK, ix, sa, wl, &ra, d_qorder, ix->profiling ? sl->ev_t[1] : NULL, aside, aside ? s_end : NULL,
-			    ix->profiling ? sl : NULL, sl->ahead ? sl->ev_ahead : NULL);
+			    ix->profiling ? sl : NULL, sl->ahead ? sl->ev_ahead : NULL,
+			    (!solo && ix->cfg.and_early) ? s_up : NULL, sl->ev_early);
 		}
 	} else if (ix->profiling) {
 		(void)hipEventRecord(sl->ev_t[1], ix->stream);

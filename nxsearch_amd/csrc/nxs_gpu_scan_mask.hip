@@ -64,9 +64,12 @@
 #ifndef MT_FOLD
 #define	MT_FOLD		0
 #endif
+#ifndef MT_FOLD_DROP
+#define	MT_FOLD_DROP	MT_FOLD		/* the same for the sparse + dense class */
+#endif
 #define	MT_DOCS		(MT_W << MT_FOLD)	/* docs per tile */
 /* quantised score bound of a doc holding every term at its largest impact (+ 2 per term: <= 240, or 2 x 124) */
-#define	QSUM_MAX	(MT_FOLD ? 108 : 224)
+#define	QSUM_MAX_F(f)	((f) ? 108 : 224)
 
 #ifdef NXS_STATS
 /* diagnostic build only (make variant XFLAGS=-DNXS_STATS): k_scanm event counts
@@ -114,7 +117,9 @@ k_scanm(const scan_args_t A)
 {
 	constexpr int RING = SCANM_RING;
 	constexpr uint32_t MTW = DROP ? MT_W_DROP : MT_W;	/* bytes of the map */
-	constexpr uint32_t MTDOCS = MTW << MT_FOLD;
+	constexpr int FOLD = DROP ? MT_FOLD_DROP : MT_FOLD;
+	constexpr uint32_t MTDOCS = MTW << FOLD;
+	constexpr int QSUM_MAX = QSUM_MAX_F(FOLD);
 	__shared__ __attribute__((aligned(16))) uint32_t s_mask[MTW / 4 + WAVE];	/* + one dummy word per lane */
 	/* (DROP pushes on a ceiling and refines in parallel: a longer list, so that a
 	 * burst of pushes does not send the query to the exact two-pass path) */
@@ -467,6 +472,8 @@ k_scanm(const scan_args_t A)
 					}
 				}
 				todo = ballot64(live && (int32_t)(sumq + qd) > thr_q + (int32_t)qU);
+				STAT_ADD(11, __popcll(todo));
+				STAT_ADD(12, __popcll(ballot64(live)));
 			}
 			(void)dcol;
 			while (todo) {
@@ -636,7 +643,7 @@ k_scanm(const scan_args_t A)
 		auto visit = [&](auto tc, uint64_t inm, uint32_t wd, float wi) {
 			constexpr int t = decltype(tc)::value;
 			const bool inl = lane_of(inm);
-			const uint32_t dd = (wd - base) >> MT_FOLD;
+			const uint32_t dd = (wd - base) >> FOLD;
 			const uint32_t sh = (dd & 3) * 8;
 			const uint32_t w = inl ? (dd >> 2) : MTW / 4 + lane;
 			/* floor + 2 >= the exact ceiling whatever the f32 product rounds to */
@@ -680,7 +687,7 @@ k_scanm(const scan_args_t A)
 		{
 			/* (wave-uniform trip count: a lane-dependent one makes the compiler
 			 * treat the enclosing loop's state as divergent) */
-			const uint32_t words = ((((uint32_t)md - base) >> MT_FOLD) + 4) >> 2;
+			const uint32_t words = ((((uint32_t)md - base) >> FOLD) + 4) >> 2;
 			for (uint32_t i0 = 0; i0 < words; i0 += WAVE * 4) {
 				*(uint4 *)&s_mask[i0 + lane * 4] = make_uint4(0, 0, 0, 0);
 			}

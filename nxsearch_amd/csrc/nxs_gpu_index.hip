@@ -87,7 +87,11 @@ cfg_from_env(gpu_cfg_t &c)
 	c.bm_gain = dbl("NXS_GPU_BM_GAIN", 16.0);
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
+#ifdef NXS_EXPERIMENTAL
 	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
+#else
+	c.use_grid = 0;		/* k_scang is an opt-in build */
+#endif
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
 	c.tfidf_drop = !on("NXS_GPU_TFIDF_NODROP");
 	c.outl_share = (uint32_t)u64("NXS_GPU_OUTL_SHARE", 8, 2, 1u << 20);

@@ -34,6 +34,8 @@
 #include "nxs_gpu_int.h"
 #include "nxs_gpu_dev.h"
 
+#ifdef NXS_EXPERIMENTAL	/* opt-in build (round 3: built, bit-exact on the whole tier, level to 2 % behind k_scanm on C3: NOTES.md) */
+
 #ifndef GT_W
 #define	GT_W		8192		/* docs per byte map (and widest part); a power of two */
 #endif
@@ -814,3 +816,4 @@ nxs_launch_scang(uint32_t nt_bucket, bool gen, bool drop, unsigned grid_, hipStr
 		}
 	}
 }
+#endif /* NXS_EXPERIMENTAL */

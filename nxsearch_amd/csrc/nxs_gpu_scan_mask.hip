@@ -980,10 +980,12 @@ nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid_, hipStream_t st, c
 {
 	const dim3 grid(grid_), block(WAVE);
 
+#ifdef NXS_EXPERIMENTAL
 	if (a.flags & 4) {
 		nxs_launch_scang(nt_bucket, gen, false, grid_, st, a);
 		return;
 	}
+#endif
 	if (!gen) {
 		switch (nt_bucket) {
 		case 2:		/* two tokens: the third slot stays empty */
@@ -1028,8 +1030,10 @@ nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid_, hipStream_t st, const 
 		hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, st, a);
 		break;
 	}
+#ifdef NXS_EXPERIMENTAL
 	if (a.flags & 4) {
 		nxs_launch_scang(nt_bucket, false, true, grid_, st, a);
 	}
+#endif
 }
 

@@ -494,9 +494,6 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANB": "1"},
-                                 # the mask path walked over a doc grid (k_scang), with and without dense terms leaving
-                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  # single-token classes: every query's top range in a launch of its own
                                  {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"},
                                  # conjunctions through the block-presence bitmaps (k_scanq): whenever the required
@@ -538,7 +535,6 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
                                  {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_NOSCANB": "1"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
-                                 {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1"},
                                  {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
@@ -1189,7 +1185,8 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
     top-10 scores are the first ten of the top-64 scores, and those the first 64 of the top-200 (the
     lane heap, the LDS heap and the histogram threshold agree); three independent scan algorithms --
     the byte-bound filter (k_scanm / k_scanr), the f32 accumulator tiles alone (NXS_GPU_NOSCANM,
-    NXS_GPU_NOSCANR) and the doc-grid walk (NXS_GPU_GRID) -- return identical ids and score bits;
+    NXS_GPU_NOSCANR), the presence-bit kernel (k_scanb for every eligible query) and the block
+    bitmaps on / off for the conjunctions -- return identical ids and score bits;
     single-term answers are the term's largest impacts; and a sample is checked against the oracle."""
     work = "/dev/shm/nxs_fullsize_%d" % os.getpid()
     try:
@@ -1221,7 +1218,7 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
             assert sc(b)[:len(a)] == sc(a) and sc(cc)[:len(b)] == sc(b)
             assert len(a) == min(10, len(b)) and len(b) == min(64, len(cc))
         # independent scan algorithms, same bits
-        for env in ({"NXS_GPU_NOSCANM": "1", "NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_GRID": "3"},
+        for env in ({"NXS_GPU_NOSCANM": "1", "NXS_GPU_NOSCANR": "1"},
                     {"NXS_GPU_NODROP": "1", "NXS_GPU_WAVES": "8192"},
                     {"NXS_GPU_NOBLKMAP": "1"},                  # conjunctions on k_scanr instead of the bitmaps
                     {"NXS_GPU_BM_GAIN": "0"},                   # ... every one of them on the bitmaps (k_scanq)

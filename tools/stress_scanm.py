@@ -40,8 +40,11 @@ for env in ({}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NX
             {"NXS_GPU_SCANM_DENS": "0.01", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_NODROP": "1"},
             {"NXS_GPU_SCANM_DENS": "1.0"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
             {"NXS_GPU_NOSCANM": "1"},
-            {"NXS_GPU_GRID": "3"}, {"NXS_GPU_GRID": "3", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "256"},
-            {"NXS_GPU_GRID": "3", "NXS_GPU_SCANM_DENS": "1.0"}):
+            # round 4: presence bits for every eligible query, the sparse + dense class on k_scanb, conjunctions
+            # through the block bitmaps always / never, no classes sent ahead
+            {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
+            {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_NOBLKMAP": "1"},
+            {"NXS_GPU_DROP_SPLIT": "0", "NXS_GPU_AND_NOEARLY": "1"}):
     if os.environ.get("STRESS_ONLY") and os.environ["STRESS_ONLY"] not in env:
         continue
     for kk, v in env.items():

@@ -391,6 +391,39 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        # The classes of a step overlap on three streams, so a class's event span above includes the time it
+        # shares the chip with the others.  The same rotated loop once more with every class on ONE stream, one
+        # after the other (nothing beside the scan stream, nothing sent ahead): each kernel's own duration, and
+        # the fraction of the HBM peak its moved bytes make of THAT.
+        if not args.no_extras or os.environ.get("NXS_BENCH_SERIAL"):
+            serial_env = {"NXS_GPU_DROP_NOSIDE": "1", "NXS_GPU_AND_NOEARLY": "1", "NXS_GPU_DROP_NOEARLY": "1",
+                          "NXS_GPU_DROP_SPLIT": "0", "NXS_GPU_REPLAY_JOIN": "1"}
+            os.environ.update(serial_env)
+            idx.reconfigure()
+            run(2)
+            idx.set_profiling(True)
+            idx.profile(reset=True)
+            run(8)
+            sprof = idx.profile(reset=True)
+            idx.set_profiling(False)
+            for kk in serial_env:
+                del os.environ[kk]
+            idx.reconfigure()
+            ser = []
+            for c in sprof.get("classes", []):
+                if not c["launches"] or c["ms"] <= 0:
+                    continue
+                names = class_kernels(c["key"], mode)
+                ms = c["ms"] / c["launches"]
+                moved = sum(traffic_per_kernel.get(n, 0) for n in names) if all(n in traffic_per_kernel for n in names) else None
+                ser.append({"kernel": "+".join(names), "ms": round(ms, 4),
+                            "moved_gbs": round(moved / (ms * 1e-3) / 1e9, 1) if moved else None,
+                            "frac_moved": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if moved else None})
+            ser.sort(key=lambda e: -e["ms"])
+            out["roofline"]["per_kernel_serial"] = ser
+            out["roofline"]["per_kernel_serial_what"] = ("the same loop with every class on one stream, one after the other "
+                                                         "(NXS_GPU_DROP_NOSIDE, NXS_GPU_AND_NOEARLY, NXS_GPU_DROP_NOEARLY, "
+                                                         "NXS_GPU_DROP_SPLIT=0): each kernel alone on the chip")
         if not args.no_extras:
             out.update(side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev))
         if not args.no_extras:

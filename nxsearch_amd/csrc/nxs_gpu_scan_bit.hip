@@ -50,7 +50,8 @@
 #define	SB_WORDS	512		/* bitmap words per tile (2 KB) */
 #endif
 #ifndef SB_FOLD
-#define	SB_FOLD		2		/* log2(docs per bit): 64k docs per tile */
+#define	SB_FOLD		2		/* largest log2(docs per bit): 64k docs per tile.  The fold is chosen per WAVEFRONT (below):
+					 * a range whose lists are dense fills the pool with a 16k-doc tile and keeps one bit per doc */
 #endif
 #define	SB_DOCS		((SB_WORDS * 32u) << SB_FOLD)
 #ifndef SB_PCAP
@@ -537,14 +538,26 @@ k_scanb(const scan_args_t A)
 	const uint32_t d_bot = (uint32_t)min((uint64_t)g * qm.group_docs, A.n_docs);
 	const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
 	    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
-	uint32_t tw;
+	uint32_t tw, fold, tw_max;
 	{
 		const uint32_t cs_left = DROP ? rfl32(cs0[0]) : 0u;
 		const uint32_t rdocs = (DROP && cs_left) ? cs_left - d_bot : d_top - d_bot;
 		const uint64_t cold_w = (uint64_t)SB_COLD_POST * max(rdocs, 1u) / max(npost, 1u);
 		const uint64_t fit_w = (uint64_t)((SB_POOL - NT) * WAVE * 3 / 4) * max(rdocs, 1u) / max(npost, 1u);
 		const uint64_t w = thr > 0.0f ? fit_w : min(cold_w, fit_w);
-		tw = rfl32((uint32_t)min(max(w, (uint64_t)64), (uint64_t)SB_TW_MAX));
+		/*
+		 * Docs per bit: as few as the pool's tile needs.  The bitmap has SB_WORDS x 32 bits; a
+		 * tile is never wider than what fills the pool (fit_w, with room to grow by half), so a
+		 * range of dense lists -- narrow tiles -- keeps one bit per doc and a sparse one folds
+		 * four docs into a bit: a bit that two docs share only adds candidates.
+		 */
+		fold = 0;
+		while (fold < SB_FOLD && ((uint64_t)(SB_WORDS * 32u) << fold) < fit_w + fit_w / 2) {
+			fold++;
+		}
+		fold = rfl32(fold);
+		tw_max = rfl32(min((uint32_t)(SB_WORDS * 32u) << fold, 65534u));
+		tw = rfl32((uint32_t)min(max(w, (uint64_t)64), (uint64_t)tw_max));
 	}
 
 	uint32_t ovf_u = 0;		/* `ovf` as the loop carries it */
@@ -601,7 +614,7 @@ k_scanb(const scan_args_t A)
 					const uint64_t inA = rfl64(vmA[s] & ballot64(Ad[s] >= base));
 					if (inA) {
 						const uint32_t rel = Ad[s] - base;
-						const uint32_t bi = rel >> SB_FOLD;
+						const uint32_t bi = rel >> fold;
 						const uint32_t bit = 1u << (bi & 31);
 						uint32_t old = 0;
 						if (lane_of(inA)) {
@@ -658,7 +671,7 @@ k_scanb(const scan_args_t A)
 
 		/* wipe the tile's bits */
 		{
-			const uint32_t words = ((((uint32_t)md - base) >> SB_FOLD) >> 5) + 1;
+			const uint32_t words = ((((uint32_t)md - base) >> fold) >> 5) + 1;
 			for (uint32_t i0 = 0; i0 < words; i0 += WAVE * 4) {
 				*(uint4 *)&s_bits[i0 + lane * 4] = make_uint4(0, 0, 0, 0);
 			}
@@ -671,7 +684,7 @@ k_scanb(const scan_args_t A)
 			if (!staged || used > SB_POOL * 7 / 8 || n_tile > SB_PCAP / 2) {
 				tw = max(tw - tw / 4, 64u);
 			} else if (n_tile <= 96 && used <= SB_POOL * 5 / 8) {
-				tw = min(tw + tw / 2, (uint32_t)SB_TW_MAX);
+				tw = min(tw + tw / 2, tw_max);
 			}
 		}
 	}

@@ -162,7 +162,8 @@ k_scanm(const scan_args_t A)
 	const posting_t *pt[NT];
 	int32_t ab[NT], lo[NT], hi[NT], pdoc[NT];
 	uint64_t vmA[NT], vmN[NT];
-	uint32_t Ad[NT], Nd[NT], rp[NT];
+	uint32_t Ad[NT], Nd[NT];
+	uint32_t rpc = 0, act = 0;	/* per slot: 2 bits of ring phase / 1 bit "has postings in this range" */
 	float Ai[NT], Ni[NT], tmx[NT];
 	int32_t ldocN[NT];	/* lowest doc of set N if a window lies below it, else 0 */
 	ring_stamps<RING> rst[NT];
@@ -203,9 +204,11 @@ k_scanm(const scan_args_t A)
 		if (ab[t] > lo[t]) {
 			vmN[t] = window_mask(ab[t] - WAVE, lo[t], 0x7fffffff);
 			const posting_t *np = &pt[t][max(ab[t] - (RING + 1) * WAVE + (int32_t)lane, lo[t])];
-			bring_take<t, RING>(rp[t], rst[t].younger(vseq), Nd[t], Ni[t], np);
+			/* ring position = takes so far, mod RING: from ab (one 2-bit constant per slot, rpc) instead
+			 * of a loop-carried scalar per slot -- the kernel's scalar registers are what it runs out of */
+			const uint32_t rpos = ((rpc >> (2 * t)) - (uint32_t)(ab[t] >> 6)) & (RING - 1);
+			bring_take<t, RING>(rpos, rst[t].younger(vseq), Nd[t], Ni[t], np);
 			rst[t].rotate(vseq++);
-			rp[t] = (rp[t] + 1) & (RING - 1);
 		} else {
 			vmN[t] = 0;
 			Nd[t] = 0xffffffffu;	/* no doc */
@@ -237,7 +240,6 @@ k_scanm(const scan_args_t A)
 		lo[t] = hi[t] = ab[t] = 0;
 		pdoc[t] = -1;
 		vmA[t] = vmN[t] = 0;
-		rp[t] = 0;
 		tmx[t] = 0.0f;
 		Ad[t] = 0;
 		Ai[t] = 0.0f;
@@ -271,6 +273,9 @@ k_scanm(const scan_args_t A)
 		}
 		if (hi[t] > lo[t]) {
 			ab[t] = ((hi[t] - 1) >> 6) << 6;
+			/* the first take happens at ab - 64 (shift() decrements first) with ring position 0 */
+			rpc |= (uint32_t)(((ab[t] >> 6) - 1) & (RING - 1)) << (2 * t);
+			act |= 1u << t;
 			/* clamped, unpredicated loads: validity lives in the masks */
 			const int32_t ia = max(ab[t] + (int32_t)lane, lo[t]);
 			const posting_t pa = pt[t][min(ia, hi[t] - 1)];
@@ -493,7 +498,7 @@ k_scanm(const scan_args_t A)
 							pm |= 1u << t;
 						}
 					} else
-					if (hi[t] > lo[t]) {
+					if ((act >> t) & 1) {
 						const uint64_t ma = ballot64(Ad[t] == dj);
 						if (ma) {
 							acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(
@@ -594,7 +599,6 @@ k_scanm(const scan_args_t A)
 			ab[t] = (int32_t)rfl32((uint32_t)ab[t]);
 			pdoc[t] = (int32_t)rfl32((uint32_t)pdoc[t]);
 			ldocN[t] = (int32_t)rfl32((uint32_t)ldocN[t]);
-			rp[t] = rfl32(rp[t]);
 			vmA[t] = rfl64(vmA[t]);
 			vmN[t] = rfl64(vmN[t]);
 		}

@@ -156,7 +156,7 @@ nxs_index_t *	nxs_index_open_files(nxs_t *, const char *terms_path,
  * runs a batch on every shard (each on its own device, `device` < 0 = the
  * NXS_GPU_DEVICE default) and merges the shards' candidates through one more
  * exact heap replay: the responses equal those of the unsharded index, ties
- * included.  limit <= 64; a shard is a static snapshot (no re-sync).  The
+ * included.  limit <= 8000, at most 32 query terms; a shard is a static snapshot (no re-sync).  The
  * shards' passes run concurrently (every shard has its own device / streams).
  *
  * One process per shard (one GPU each): rank r opens shard r of W, attaches a

@@ -2683,9 +2683,14 @@ docshard_search(nxs_index_t *const *local, unsigned n_local, unsigned n_shards, 
 	if (get_search_params(idx0, params, &sp) == -1) {
 		return -1;
 	}
-	if (sp.limit > NXSGPU_FAST_K) {
-		nxs_decl_err(nxs, NXS_ERR_LIMIT, "doc-sharded search takes limit <= %d", NXSGPU_FAST_K);
+	if (sp.limit > NXSGPU_BIG_K) {
+		nxs_decl_err(nxs, NXS_ERR_LIMIT, "doc-sharded search takes limit <= %d", NXSGPU_BIG_K);
 		return -1;
+	}
+	/* a shard's heap accepts ~ k (1 + ln(matches / k)) items: room for that from the start (a log that
+	 * overflows costs a second pass over every shard) */
+	if (!cap0 && sp.limit > NXSGPU_FAST_K) {
+		cap = (uint32_t)(sp.limit * 8 < 32768 ? sp.limit * 8 : 32768);
 	}
 	if (!idx0->global_df_set) {
 		if (!ranks && docshard_set_global_df(local, n_shards) == -1) {

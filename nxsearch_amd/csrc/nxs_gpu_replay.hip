@@ -1099,8 +1099,8 @@ nxsgpu_merge_candidates(int device, uint32_t limit, uint32_t nq, uint32_t n_shar
 	hipStream_t st = NULL;
 	int rc = -1;
 
-	if (limit == 0 || limit > NXSGPU_FAST_K) {
-		set_error("nxsgpu_merge_candidates: limit must be 1..%d", NXSGPU_FAST_K);
+	if (limit == 0 || limit > NXSGPU_BIG_K) {
+		set_error("nxsgpu_merge_candidates: limit must be 1..%d", NXSGPU_BIG_K);
 		return -1;
 	}
 	if (nq == 0) {
@@ -1157,7 +1157,8 @@ nxsgpu_merge_candidates(int device, uint32_t limit, uint32_t nq, uint32_t n_shar
 		ra.out_ids = d_oid;
 		ra.out_sc = d_osc;
 		ra.out_count = d_ocnt;
-		hipLaunchKernelGGL(k_replay<HEAP_REG>, dim3(nq), dim3(WAVE), 0, st, ra);
+		/* the heap across the lanes (limit <= 64) or in LDS, worked on by the whole wavefront (k_replay_coop) */
+		nxs_launch_replay(limit <= NXSGPU_FAST_K ? HEAP_REG : HEAP_LDS, nq, limit <= NXSGPU_FAST_K ? 0 : (size_t)limit * 8, st, ra);
 		if (hipGetLastError() != hipSuccess ||
 		    hipMemcpyAsync(out_ids, d_oid, (size_t)nq * limit * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
 		    hipMemcpyAsync(out_scores, d_osc, (size_t)nq * limit * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

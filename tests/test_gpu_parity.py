@@ -1089,7 +1089,7 @@ def test_doc_sharded_collection_equals_the_whole_index(nxs, tmp_path, n_shards):
     queries = [random_query(rng, vocab[:16]) for _ in range(50)]
     queries += ["w0", "w0 AND w1", "w49 OR w0", "w3 OR w4 OR w5 OR w6 OR w7", "broken AND", "w1 AND NOT w0",
                 "zzzz OR yyyy", "w2 OR ww3"]
-    for limit in (1, 10, 64):
+    for limit in (1, 10, 64, 65, 300, 2000):        # (above 64: the merge's heap lives in LDS, k_replay_coop)
         for algo, name in ((1, "BM25"), (0, "TF-IDF")):
             got = nxs.docshard_search_batch(shards, queries, limit=limit, algo=name)
             for q, g in zip(queries, got):
@@ -1107,8 +1107,10 @@ def test_doc_sharded_collection_equals_the_whole_index(nxs, tmp_path, n_shards):
     qs = corpus.queries_bool5(terms, 48, seed=5, hi=500) + corpus.queries_single(terms, 8, seed=6, lo=1, hi=200)
     for q, g in zip(qs, nxs.docshard_search_batch(sh2, qs, limit=10, fuzzymatch=False)):
         assert_same(g, o2.search(q, limit=10, fuzzymatch=False), q)
+    for q, g in zip(qs[:16], nxs.docshard_search_batch(sh2, qs[:16], limit=1000, fuzzymatch=False)):
+        assert_same(g, o2.search(q, limit=1000, fuzzymatch=False), (q, 1000))
     with pytest.raises(N.NxsError) as e:
-        nxs.docshard_search_batch(sh2, qs[:2], limit=100)
+        nxs.docshard_search_batch(sh2, qs[:2], limit=8001)      # beyond the fixed-size records
     assert e.value.code == 6
     # one process per shard, the ranks played one after the other on this GPU: every
     # rank's candidate block, the blocks laid out as the all-gather would, every rank's

@@ -97,7 +97,8 @@ int		nxs_index_search_batch(nxs_index_t *, nxs_params_t *,
  * _end() waits for the OLDEST batch in flight and builds its responses.  Up to
  * two batches may be in flight, so the host prepares batch i+1 while the GPU
  * runs batch i.  `queries` need not outlive _begin().  The index re-syncs with
- * the files (search.c:309-312) only when no batch is in flight.
+ * the files (search.c:309-312) in every _begin: when they have moved while batches
+ * are in flight, _begin finishes those first (their responses wait for _end).
  */
 int		nxs_index_search_batch_begin(nxs_index_t *, nxs_params_t *,
 		    const char *const *queries, size_t n);
@@ -116,9 +117,11 @@ int		nxs_index_search_batch_end(nxs_index_t *, nxs_resp_t **resps,
  * records over xGMI reassembles the batch, and every rank receives all n
  * responses.  Applies to limit <= 8000 (NXSGPU_BIG_K: fixed-size records); larger
  * limits run replicated (every rank computes the whole batch).  nxs_index_search()
- * (one query) never shards.  With a communicator attached the files are re-read
- * only while no batch is in flight (the ranks would have to agree on the batch at
- * which to drain); a rank that cannot do its share of a batch still contributes an
+ * (one query) never shards.  Re-sync with a communicator attached: a rank that sees
+ * the files move while batches are in flight says so in its record block; all ranks
+ * read that at the batch's _end and finish their batches in flight + re-read the
+ * files in their next _begin (the same one on every rank: two batches after the
+ * change was noticed in a fully pipelined loop).  A rank that cannot do its share of a batch still contributes an
  * "aborted" block, so every rank fails that batch together and the next one is in
  * step -- only a rank that cannot reach the collective at all (device memory for
  * the staging buffer, a dead process) stalls the group, as with any collective.

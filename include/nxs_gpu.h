@@ -274,14 +274,20 @@ int		nxsgpu_fuzzy(nxsgpu_index_t *, const uint8_t *tok_bytes,
  *
  * Record of one query (limit k <= NXSGPU_BIG_K), NXSGPU_REC_BYTES(k) bytes:
  *	u32 count | u32 flags | u64 doc_id[k] | f32 score[k] | pad to 8
- * A rank's BLOCK = n_slots records followed by n_slots u32 status words (the
- * nxs_err_t of a query that never reached the device; padded to 8 bytes).
+ * A rank's BLOCK = n_slots records followed by n_slots + 1 u32 status words:
+ * one per slot (the nxs_err_t of a query that never reached the device) and a
+ * last word of per-rank flags every rank reads after the all-gather
+ * (NXSGPU_BLOCK_CHANGED), padded to 8 bytes.
  * With one rank there is no collective and the block is simply the batch's
  * host copy.
  */
 #define	NXSGPU_REC_BYTES(k)	((8 + 12 * (size_t)(k) + 7) & ~(size_t)7)
+#define	NXSGPU_STATUS_WORDS(n_slots)	((size_t)(n_slots) + 1)
 #define	NXSGPU_BLOCK_BYTES(n_slots, k) \
-	((size_t)(n_slots) * NXSGPU_REC_BYTES(k) + (((size_t)(n_slots) * 4 + 7) & ~(size_t)7))
+	((size_t)(n_slots) * NXSGPU_REC_BYTES(k) + ((NXSGPU_STATUS_WORDS(n_slots) * 4 + 7) & ~(size_t)7))
+/* block flags word: this rank saw the index files move when it planned the batch --
+ * all ranks then re-sync at the same later _begin (nxs.h, "sharded mode") */
+#define	NXSGPU_BLOCK_CHANGED	1u
 #define	NXSGPU_REC_INEXACT	1u	/* flags: the query needs the exact two-pass path (nxsgpu_search) */
 #define	NXSGPU_UID_BYTES	128	/* = NCCL_UNIQUE_ID_BYTES */
 
@@ -322,7 +328,8 @@ typedef struct {
 /*
  * Pipelined host batches (up to two in flight, shared with
  * nxsgpu_search_dev_begin): the result of plans[i] goes to record
- * slot_of_plan[i] of this rank's block; status[n_slots] travels with it.
+ * slot_of_plan[i] of this rank's block; status[NXSGPU_STATUS_WORDS(n_slots)]
+ * (NULL: zeros) travels with it.
  * _begin() queues upload, cursors, scans, heap replays, the all-gather (if
  * `gather` is set and a communicator is attached: every rank must then call
  * with the same n_slots and limit) and the copy to pinned host memory, then

@@ -1850,15 +1850,39 @@ stash_inflight(nxs_index_t *idx)
 static int
 resync_before_batch(nxs_index_t *idx)
 {
-	/* (sharded: the ranks would have to agree on WHICH _begin finishes the batches in
-	 * flight -- their fix-up round is a collective --, so with a communicator attached
-	 * the files are re-read between batches only, as before) */
-	if (pend_oldest(idx) && !idx->comm && nxs_index_changed(idx)) {
+	/*
+	 * Sharded: the fix-up round of a batch in flight is a collective, so the ranks have to
+	 * agree on WHICH _begin finishes the batches in flight.  Each rank says in the flags
+	 * word of its record block whether it saw the files move (NXSGPU_BLOCK_CHANGED, set in
+	 * _begin); every rank reads all flags after the all-gather (batch_end_core) and, if any
+	 * is set, drains at its next _begin -- the same one on every rank, since all of them
+	 * make the same calls in the same order.
+	 */
+	if (pend_oldest(idx)) {
+		if (idx->comm ? !idx->resync_pending : !nxs_index_changed(idx)) {
+			return idx->comm ? 0 : nxs_index_refresh(idx);
+		}
 		if (stash_inflight(idx) == -1) {
 			return -1;
 		}
 	}
+	idx->resync_pending = false;
 	return nxs_index_refresh(idx);
+}
+
+/* any rank's block flags say "my index files moved" (all W blocks present) */
+static bool
+blocks_changed(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k)
+{
+	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
+
+	for (uint32_t r = 0; r < world; r++) {
+		const uint32_t *st = (const uint32_t *)(blocks + (size_t)r * block_bytes + (size_t)n_slots * rec_bytes);
+		if (st[n_slots] & NXSGPU_BLOCK_CHANGED) {
+			return true;
+		}
+	}
+	return false;
 }
 
 /* batches never collected (the caller closes the index instead): wait, drop */
@@ -1960,7 +1984,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	if (sp.limit <= NXSGPU_BIG_K) {
 		plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
 		slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
-		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
+		status = calloc(NXSGPU_STATUS_WORDS(pd->cap), sizeof(uint32_t));
 		if (!plans || !slot_of || !status) {
 			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
 			if (collective) {
@@ -1979,6 +2003,11 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 				slot_of[n_plans] = (uint32_t)i;
 				plans[n_plans++] = q->plan;
 			}
+		}
+		if (collective && nxs_index_changed(idx)) {
+			/* a batch is in flight (else resync_before_batch refreshed just now): tell
+			 * the peers, all ranks drain and re-sync together */
+			status[pd->cap] = NXSGPU_BLOCK_CHANGED;
 		}
 		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
 		    (uint32_t)n_plans, slot_of, status, pd->cap,
@@ -2020,7 +2049,7 @@ abort_collective:
 		nxsgpu_batch_view_t v;
 
 		free(status);
-		status = calloc(pd->cap ? pd->cap : 1, sizeof(uint32_t));
+		status = calloc(NXSGPU_STATUS_WORDS(pd->cap), sizeof(uint32_t));
 		for (uint32_t i = 0; status && i < pd->cap; i++) {
 			status[i] = STATUS_ABORT | (uint32_t)code;
 		}
@@ -2306,6 +2335,9 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "sharded batch came back with %u blocks, not %u",
 			    v.world, W);
 			goto out;
+		}
+		if (all && idx->comm && blocks_changed(blocks, W, v.n_slots, v.k)) {
+			idx->resync_pending = true;	/* (every rank reads the same flags) */
 		}
 		if (all) {
 			nxs_err_t acode;
@@ -3200,6 +3232,20 @@ nxs_test_mark_inexact(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slo
 {
 	(void)n_slots;
 	((uint32_t *)(block + (size_t)slot * NXSGPU_REC_BYTES(k)))[1] = NXSGPU_REC_INEXACT;
+}
+
+/* the block's flags word says "this rank saw the index files move" ... */
+void
+nxs_test_mark_changed(uint8_t *block, uint32_t n_slots, uint32_t k)
+{
+	((uint32_t *)(block + (size_t)n_slots * NXSGPU_REC_BYTES(k)))[n_slots] |= NXSGPU_BLOCK_CHANGED;
+}
+
+/* ... and what every rank reads off the gathered blocks: re-sync at the next _begin? */
+int
+nxs_test_blocks_changed(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k)
+{
+	return blocks_changed(blocks, world, n_slots, k) ? 1 : 0;
 }
 
 /* what every rank reads off the gathered blocks: does the batch need a fix-up round, and which

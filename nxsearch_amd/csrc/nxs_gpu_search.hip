@@ -1514,7 +1514,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	const uint64_t wave_target = ix->cfg.wave_target;
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
 	const size_t stage_need = 32768 + RETRY_LISTS * 4 + 256 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
-	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + (size_t)o.n_slots * 4 + 4096
+	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + NXSGPU_STATUS_WORDS(o.n_slots) * 4 + 4096
 	    + (block_in_ws ? sl->block_bytes : 0);	/* (the record block itself lives in h_blocks) */
 	if (slot_ensure(*sl, 0, stage_need) != 0) {
 		return -1;
@@ -1545,7 +1545,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	uint32_t *h_retry_cnt = carve<uint32_t>(hp, RETRY_LISTS);
 	uint8_t *h_block = carve<uint8_t>(hp, block_in_ws ? sl->block_bytes : 0);
 	const size_t up_len = (size_t)(hp - sl->h_stage);
-	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, o.n_slots);
+	uint32_t *h_status = block_in_ws ? (uint32_t *)(h_block + recs_len) : carve<uint32_t>(hp, NXSGPU_STATUS_WORDS(o.n_slots));
 	if ((size_t)(hp - sl->h_stage) > sl->h_stage_len) {
 		set_error("staging area too small (%zu > %zu)", (size_t)(hp - sl->h_stage), sl->h_stage_len);
 		return -1;
@@ -1585,9 +1585,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			h_status = (uint32_t *)(sl->h_blocks + recs_len);
 		}
 		if (o.status) {
-			memcpy(h_status, o.status, (size_t)o.n_slots * 4);
+			memcpy(h_status, o.status, NXSGPU_STATUS_WORDS(o.n_slots) * 4);
 		} else {
-			memset(h_status, 0, (size_t)o.n_slots * 4);
+			memset(h_status, 0, NXSGPU_STATUS_WORDS(o.n_slots) * 4);
 		}
 	}
 
@@ -1632,8 +1632,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	}
 	if (o.records && !block_in_ws && !block_on_host) {
 		if ((recs_len && hipMemsetAsync(d_myblock, 0, recs_len, s_up) != hipSuccess) ||
-		    (o.n_slots && hipMemcpyAsync(d_myblock + recs_len, h_status, (size_t)o.n_slots * 4,
-		    hipMemcpyHostToDevice, s_up) != hipSuccess)) {
+		    hipMemcpyAsync(d_myblock + recs_len, h_status, NXSGPU_STATUS_WORDS(o.n_slots) * 4,
+		    hipMemcpyHostToDevice, s_up) != hipSuccess) {
 			set_error("record block setup failed");
 			return begin_fail(ix);
 		}

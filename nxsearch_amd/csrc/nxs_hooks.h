@@ -43,6 +43,8 @@ size_t		nxs_test_shard_block(nxs_index_t *, uint8_t *out, size_t cap);
 void		nxs_test_pack_record(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot,
 		    uint32_t count, const uint64_t *ids, const float *scores, uint32_t status);
 void		nxs_test_mark_inexact(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t slot);
+void		nxs_test_mark_changed(uint8_t *block, uint32_t n_slots, uint32_t k);
+int		nxs_test_blocks_changed(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k);
 void		nxs_test_pack_abort(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t code);
 int		nxs_test_fixup_scan(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k,
 		    size_t n, int rank, uint32_t *which, size_t *nw);

@@ -119,6 +119,7 @@ struct nxs_index {
 	struct nxs_pend	pend[2];
 	/* tests: the n-th next _begin / exact fix-up of this index fails (0: off) */
 	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv;
+	bool		resync_pending;	/* sharded: a rank's block flags said its files moved */
 	struct plan_cache *pcache;	/* query string -> compiled plan (nxs_api.c: plan_batch) */
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */

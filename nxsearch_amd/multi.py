@@ -36,7 +36,7 @@ def rec_bytes(k):
 
 
 def block_bytes(n_slots, k):
-    return n_slots * rec_bytes(k) + ((n_slots * 4 + 7) & ~7)
+    return n_slots * rec_bytes(k) + (((n_slots + 1) * 4 + 7) & ~7)
 
 
 def attach(nxs, index, rank, world, dist=None, device=None):
@@ -106,6 +106,23 @@ def mark_inexact(block, n_slots, k, slot):
     buf = C.create_string_buffer(block, len(block))
     L.nxs_test_mark_inexact(buf, n_slots, k, slot)
     return buf.raw[:len(block)]
+
+
+def mark_changed(block, n_slots, k):
+    """tests: the block's flags word says "this rank saw the index files move"."""
+    L = lib()
+    L.nxs_test_mark_changed.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
+    buf = C.create_string_buffer(block, len(block))
+    L.nxs_test_mark_changed(buf, n_slots, k)
+    return buf.raw[:len(block)]
+
+
+def blocks_changed(blocks, world, n_slots, k):
+    """What every rank reads off the gathered blocks: all ranks re-sync at their next _begin."""
+    L = lib()
+    L.nxs_test_blocks_changed.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.nxs_test_blocks_changed.restype = C.c_int
+    return bool(L.nxs_test_blocks_changed(blocks, world, n_slots, k))
 
 
 def fixup_scan(blocks, world, n_slots, k, n, rank):

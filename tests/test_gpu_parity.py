@@ -751,6 +751,66 @@ def test_sharded_single_rank_through_rccl(nxs, tmp_path):
     gidx.close()
 
 
+def test_sharded_resync_in_a_pipelined_loop(nxs, tmp_path):
+    """search.c:309-312 with a communicator attached (one rank, the same code path as N): a pipelined
+    server that never drains still picks up what the indexer publishes.  The rank that notices the
+    moved files says so in the flags word of its record block (NXSGPU_BLOCK_CHANGED); every rank reads
+    all flags at the batch's _end and drains + refreshes at its NEXT _begin -- two batches after the
+    change was noticed, at the same batch on every rank (tests/test_multi_gloo.py has the N = 2 form)."""
+    from nxsearch_amd import multi
+    ev = [("add", i + 1, ["cat", "dog", "w%d" % (i % 7)]) for i in range(300)]
+    timg, dimg, _ = nxsfmt.build_images_log(ev)
+    t, d = str(tmp_path / "nxsterms"), str(tmp_path / "nxsdtmap")
+    open(t, "wb").write(timg + b"\0" * 262144)
+    open(d, "wb").write(dimg + b"\0" * 262144)
+    gidx = nxs.open_files(t, d)
+    multi.attach(nxs, gidx, 0, 1)
+    qs = ["cat", "emu", "dog OR emu", "w3 AND cat", "emu AND cat", "gnu"]
+    import shutil
+    oracles = []
+
+    def snapshot():
+        k = len(oracles)
+        tt, dd = str(tmp_path / ("t%d" % k)), str(tmp_path / ("d%d" % k))
+        shutil.copy(t, tt)
+        shutil.copy(d, dd)
+        oracles.append(O.Index(tt, dd))
+
+    def publish(events):
+        timg, dimg, _ = nxsfmt.build_images_log(events)
+        nxsfmt.publish_in_place(t, d, timg, dimg)
+        snapshot()
+
+    snapshot()
+    # published before _begin(p): noticed by _begin(p) (flag in batch p's block), read at _end(p)
+    # -- which follows _begin(p + 1) --, so _begin(p + 2) drains, refreshes and sees it
+    expect = {}
+    gidx.search_batch_begin(qs, limit=10)
+    expect[0] = 0
+    for step in range(1, 12):
+        if step == 2:
+            ev.append(("add", 1000, ["cat", "emu"]))
+            publish(ev)
+        if step == 7:
+            ev.append(("rm", 1000))
+            ev.append(("add", 1001, ["gnu", "cat", "cat"]))
+            publish(ev)
+        gidx.search_batch_begin(qs, limit=10)
+        expect[step] = 0 if step < 4 else 1 if step < 9 else 2
+        got = gidx.search_batch_end()
+        for q, g in zip(qs, got):
+            assert_same(g, oracles[expect[step - 1]].search(q, limit=10), (step, q))
+    got = gidx.search_batch_end()
+    for q, g in zip(qs, got):
+        assert_same(g, oracles[2].search(q, limit=10), ("last", q))
+    # blocking calls (nothing in flight) re-sync at once, as before
+    ev.append(("add", 1002, ["emu", "emu"]))
+    publish(ev)
+    for q, g in zip(qs, gidx.search_batch(qs, limit=10)):
+        assert_same(g, oracles[3].search(q, limit=10), ("blocking", q))
+    gidx.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_emulated_ranks_reassemble(nxs, tmp_path, monkeypatch, world):
     """Every rank of a W-rank run, one after the other on the one GPU, with the

@@ -87,7 +87,10 @@ def test_record_layout_is_the_documented_one():
     assert len(blk) == 3 * 128 + 16
     assert struct.unpack_from("<IIQQ", blk, 0) == (2, 0, 7, 3)
     assert struct.unpack_from("<ff", blk, 8 + 80) == (1.5, 0.25)
-    assert struct.unpack_from("<III", blk, 3 * 128) == (0, 3, 0)
+    assert struct.unpack_from("<IIII", blk, 3 * 128) == (0, 3, 0, 0)     # 3 status words + the flags word
+    assert multi.block_bytes(2, 10) == 2 * 128 + 16 and multi.block_bytes(0, 10) == 8
+    assert not multi.blocks_changed(blk, 1, 3, 10)
+    assert struct.unpack_from("<I", multi.mark_changed(blk, 3, 10), 3 * 128 + 12) == (1,)
     got = multi.assemble(blk, 1, 3, 10, 3)
     assert got[0] == [(7, 1.5), (3, 0.25)] and got[1].code == 3 and got[2] == []
 
@@ -227,3 +230,51 @@ def test_eight_ranks_fixup_round_and_an_abort_inside_it(tmp_path):
     ret = mgr.dict()
     mp.spawn(_worker8, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
     assert dict(ret) == {r: [True, True, True] for r in range(world)}
+
+
+def _worker_resync(rank, world, port, tdir, n, k, ret):
+    """A pipelined sharded server (one batch always in flight): the indexer's append reaches rank 1's
+    eyes first (it plans batch 2 a moment later than rank 0).  Its block for batch 2 carries the
+    "changed" flag; every rank reads the flags of all blocks when it collects batch 2, so every rank
+    decides to drain and re-read the files at the SAME later _begin -- the drain runs the fix-up round
+    of the batch in flight, a collective, and must not interleave differently on different ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oidx = O.Index(os.path.join(tdir, "nxsterms"), os.path.join(tdir, "nxsdtmap"))
+    queries = QUERIES[:n]
+    lo, hi = multi.shard_slice(n, rank, world)
+    cap = multi.shard_capacity(n, world)
+    mine = [_answer(oidx, q, k) for q in queries[lo:hi]]
+    pending, inflight, log = False, [], []
+    for batch in range(6):
+        # _begin(batch): drain first if the flags of an EARLIER batch said so
+        if pending and inflight:
+            log.append(("drain", batch))
+            pending = False
+        block = multi.pack_block(mine, cap, k)
+        if rank == 1 and batch == 2:
+            block = multi.mark_changed(block, cap, k)
+        send = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+        recv = torch.empty(world * len(block), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)           # queued by _begin
+        inflight.append(recv.numpy().tobytes())
+        if len(inflight) == 2:                            # _end(batch - 1)
+            if multi.blocks_changed(inflight.pop(0), world, cap, k):
+                pending = True
+    ret[rank] = log
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_batch_that_resyncs(tmp_path):
+    world, n, k = 2, 9, 10
+    nxsfmt.write_index(str(tmp_path), "idx", [(d, t.split()) for d, t in DOCS.items()])
+    tdir = str(tmp_path)
+    if not os.path.exists(os.path.join(tdir, "nxsterms")):
+        tdir = os.path.join(tdir, "data", "idx")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_resync, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
+    # batch 2's flags are read at _end(2), which follows _begin(3): both ranks drain in _begin(4)
+    assert dict(ret) == {0: [("drain", 4)], 1: [("drain", 4)]}

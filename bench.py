@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--limit", type=int, default=10)
+    ap.add_argument("--depth", type=int, default=0,
+                    help="batches in flight in the timed loop (default: 3; 4 for limits above 64, whose "
+                         "batches end in milliseconds of heap replay)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget of the CPU-baseline sample (0 = skip)")
@@ -252,9 +255,11 @@ def main():
     qarr_all = c_strings([q for b in batches for q in b])
     params = N._make_params(args.limit, "BM25", fuzzy_on)
 
+    depth = args.depth if args.depth > 0 else (4 if args.limit > 64 else 3)
+
     def run(steps):
         out = BenchOut()
-        if B.nxs_bench_batches_rot(idx._h, params, qarr_all, len(queries), n_sets, steps, 2, C.byref(out)) != 0:
+        if B.nxs_bench_batches_rot(idx._h, params, qarr_all, len(queries), n_sets, steps, depth, C.byref(out)) != 0:
             raise N.NxsError(*nxs.error())
         return out
 
@@ -375,7 +380,7 @@ def main():
                        "in all (sharded by query)" if strong else "per GPU"),
                    "postings": info["postings"],
                    "boundary": "nxs_index_search_batch_begin/_end: query strings in, nxs_resp_t out, "
-                               "two batches in flight",
+                               "%d batches in flight" % depth,
                    "batches_rotated": n_sets, "doc_ids": "sparse random u64" if args.sparse_ids else "1..D",
                    "parallelism": ("query-sharded x%d, index replicated, one RCCL all-gather of "
                                    "record blocks per step" % world) if (world > 1 and sharded) else
@@ -658,15 +663,17 @@ def side_measurements(args, nxs, idx, B, terms, queries, qarr, torch, dev):
     #     pipelined like the headline (candidate filter on a histogram threshold,
     #     MODE_BIG; heap replayed in LDS by the whole wavefront), then the blocking call
     idx.host_profile()
-    B.nxs_bench_batches(idx._h, None, qarr, nq, 2, 2, C.byref(o))
-    B.nxs_bench_batches(idx._h, None, qarr, nq, 8, 2, C.byref(o))
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 4, 4, C.byref(o))
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 48, 4, C.byref(o))
     hp = idx.host_profile()
-    res["default_limit"] = {"queries_per_s": round(nq * 8 / o.seconds, 1), "limit": 1000,
-                            "ms_per_step": round(1e3 * o.seconds / 8, 3),
-                            "results_per_query": round(o.results / (8.0 * nq), 1),
-                            "exact_requeries_per_step": hp["exact_requeries"] / 10.0,
+    res["default_limit"] = {"queries_per_s": round(nq * 48 / o.seconds, 1), "limit": 1000,
+                            "ms_per_step": round(1e3 * o.seconds / 48, 3),
+                            "results_per_query": round(o.results / (48.0 * nq), 1),
+                            "exact_requeries_per_step": hp["exact_requeries"] / 52.0,
                             "what": "the whole batch (%d queries), params == NULL, "
-                                    "nxs_index_search_batch_begin/_end, two batches in flight" % nq}
+                                    "nxs_index_search_batch_begin/_end, four batches in flight" % nq}
+    B.nxs_bench_batches(idx._h, None, qarr, nq, 8, 2, C.byref(o))
+    res["default_limit"]["two_in_flight_queries_per_s"] = round(nq * 8 / o.seconds, 1)
     B.nxs_bench_batches(idx._h, None, qarr, nq, 4, 1, C.byref(o))
     res["default_limit"]["blocking_queries_per_s"] = round(nq * 4 / o.seconds, 1)
     L.nxs_params_release(p)

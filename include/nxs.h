@@ -95,11 +95,14 @@ int		nxs_index_search_batch(nxs_index_t *, nxs_params_t *,
  * The same, split for pipelining (new): _begin() parses, resolves and plans
  * the batch on the host (worker threads), queues it on the device and returns;
  * _end() waits for the OLDEST batch in flight and builds its responses.  Up to
- * two batches may be in flight, so the host prepares batch i+1 while the GPU
- * runs batch i.  `queries` need not outlive _begin().  The index re-syncs with
+ * NXS_BATCHES_INFLIGHT batches may be in flight, so the host prepares batch i+1
+ * while the GPU runs batch i (two hide the host side of a top-10 batch; at the
+ * default limit of 1000 a batch ends in milliseconds of heap replay on a nearly
+ * idle chip, and three or four in flight fill it).  `queries` need not outlive _begin().  The index re-syncs with
  * the files (search.c:309-312) in every _begin: when they have moved while batches
  * are in flight, _begin finishes those first (their responses wait for _end).
  */
+#define	NXS_BATCHES_INFLIGHT	4
 int		nxs_index_search_batch_begin(nxs_index_t *, nxs_params_t *,
 		    const char *const *queries, size_t n);
 int		nxs_index_search_batch_end(nxs_index_t *, nxs_resp_t **resps,

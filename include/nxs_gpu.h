@@ -250,10 +250,14 @@ int		nxsgpu_search_dev(nxsgpu_index_t *, int algo, uint32_t limit,
  * The same, split for pipelining: _begin() plans the batch on the host, sends
  * the plans up and queues the kernels, then returns; _end() waits for the
  * OLDEST batch in flight and returns its status (0 / 1 / -1 as above).  Up to
- * two batches may be in flight, so the host prepares batch i+1 while batch i
- * runs; each needs its own output buffers until its _end().  nxsgpu_search()
- * and nxsgpu_search_dev() refuse to run while a batch is in flight.
+ * NXSGPU_INFLIGHT batches may be in flight, so the host prepares batch i+1 while
+ * batch i runs (two in flight hide the host side of a top-10 batch; limits in the
+ * hundreds end in a heap replay of milliseconds -- one wavefront per query, the
+ * chip nearly idle -- and take three or four to fill the GPU); each needs its own
+ * output buffers until its _end().  nxsgpu_search() and nxsgpu_search_dev()
+ * refuse to run while a batch is in flight.
  */
+#define	NXSGPU_INFLIGHT	4
 int		nxsgpu_search_dev_begin(nxsgpu_index_t *, int algo, uint32_t limit,
 		    const nxsgpu_query_t *queries, uint32_t n_queries,
 		    uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts);
@@ -322,11 +326,11 @@ typedef struct {
 	uint32_t	k;
 	uint32_t	world;		/* blocks */
 	size_t		rec_bytes, block_bytes;
-	const uint8_t *	blocks;		/* host memory, valid until the second-next _begin */
+	const uint8_t *	blocks;		/* host memory, valid until NXSGPU_INFLIGHT more batches have begun */
 } nxsgpu_batch_view_t;
 
 /*
- * Pipelined host batches (up to two in flight, shared with
+ * Pipelined host batches (up to NXSGPU_INFLIGHT in flight, shared with
  * nxsgpu_search_dev_begin): the result of plans[i] goes to record
  * slot_of_plan[i] of this rank's block; status[NXSGPU_STATUS_WORDS(n_slots)]
  * (NULL: zeros) travels with it.

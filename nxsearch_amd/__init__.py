@@ -500,7 +500,7 @@ class Index:
         return out
 
     def search_batch_begin(self, queries, limit=None, algo=None, fuzzymatch=None):
-        """nxs_index_search_batch_begin(): queue a batch (at most two in flight)."""
+        """nxs_index_search_batch_begin(): queue a batch (at most NXS_BATCHES_INFLIGHT = 4 in flight)."""
         L = lib()
         n = len(queries)
         qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
@@ -583,7 +583,7 @@ class Index:
         return r
 
     def search_dev_begin(self, plans, n, limit, algo, d_ids, d_scores, d_counts):
-        """nxsgpu_search_dev_begin(): queue a batch (at most two in flight)."""
+        """nxsgpu_search_dev_begin(): queue a batch (at most NXS_BATCHES_INFLIGHT = 4 in flight)."""
         if lib().nxsgpu_search_dev_begin(self.device, algo, limit, plans, n,
                                          d_ids, d_scores, d_counts) != 0:
             raise NxsError(1, lib().nxsgpu_last_error().decode())

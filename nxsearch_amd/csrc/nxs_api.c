@@ -1774,7 +1774,7 @@ pend_oldest(nxs_index_t *idx)
 {
 	nxs_pend_t *p = NULL;
 
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		if (idx->pend[i].active && (!p || idx->pend[i].seq < p->seq)) {
 			p = &idx->pend[i];
 		}
@@ -1820,7 +1820,7 @@ stash_inflight(nxs_index_t *idx)
 	for (;;) {
 		nxs_pend_t *pd = NULL;
 
-		for (int i = 0; i < 2; i++) {
+		for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 			nxs_pend_t *c = &idx->pend[i];
 			if (c->active && !c->stashed && (!pd || c->seq < pd->seq)) {
 				pd = c;
@@ -1920,14 +1920,14 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	if (get_search_params(idx, params, &sp) == -1) {
 		return -1;
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		if (!idx->pend[i].active) {
 			pd = &idx->pend[i];
 			break;
 		}
 	}
 	if (!pd) {
-		nxs_decl_err(nxs, NXS_ERR_INVALID, "two batches are already in flight");
+		nxs_decl_err(nxs, NXS_ERR_INVALID, "%d batches are already in flight", NXSGPU_INFLIGHT);
 		return -1;
 	}
 	/* search.c:309-312: pick up what other processes appended or removed */

@@ -55,8 +55,8 @@ consume(nxs_resp_t **resps, size_t n, nxs_bench_out_t *o)
  * `steps` batches of n query strings; step s takes batch s mod n_sets of the
  * n_sets * n strings (distinct batches: nothing a step warms up -- term hash
  * lines, cursor searches, dense columns -- is what the next one reads).  depth 1:
- * the blocking nxs_index_search_batch(); depth 2: nxs_index_search_batch_begin /
- * _end with two batches in flight (the host plans batch i+1 while the GPU runs
+ * the blocking nxs_index_search_batch(); depth d >= 2: nxs_index_search_batch_begin /
+ * _end with d batches in flight (the host plans batch i+1 while the GPU runs
  * batch i).  All steps have completed and all responses are consumed on return.
  */
 int
@@ -82,24 +82,57 @@ nxs_bench_batches_rot(nxs_index_t *idx, nxs_params_t *params, const char *const 
 			consume(resps, n, out);
 		}
 	} else {
+		/*
+		 * depth d: d batches in flight.  The responses of batch s are consumed AFTER
+		 * batch s + d has been queued (a server hands the next batch to the GPU before
+		 * it walks the previous one's results): at the default limit that walk is
+		 * half a million results per batch and would otherwise sit between two
+		 * batches' device work.
+		 */
+		nxs_resp_t **held = calloc(n ? n : 1, sizeof(*held));
+		unsigned ended = 0;
+		bool have = false;
+
+		if (!held) {
+			goto out;
+		}
+		if (depth > NXS_BATCHES_INFLIGHT) {
+			depth = NXS_BATCHES_INFLIGHT;
+		}
 		for (unsigned s = 0; s < steps; s++) {
 			const char *const *queries = all_queries + (size_t)(s % n_sets) * n;
 			if (nxs_index_search_batch_begin(idx, params, queries, n) != 0) {
+				free(held);
 				goto out;
 			}
-			if (s) {
-				if (nxs_index_search_batch_end(idx, resps, errs) < 0) {
+			if (have) {
+				consume(held, n, out);
+				have = false;
+			}
+			if (s + 1 >= (unsigned)depth) {
+				if (nxs_index_search_batch_end(idx, held, errs) < 0) {
+					free(held);
 					goto out;
 				}
-				consume(resps, n, out);
+				ended++;
+				have = true;
 			}
 		}
-		if (steps) {
-			if (nxs_index_search_batch_end(idx, resps, errs) < 0) {
+		while (ended < steps) {
+			if (have) {
+				consume(held, n, out);
+			}
+			if (nxs_index_search_batch_end(idx, held, errs) < 0) {
+				free(held);
 				goto out;
 			}
-			consume(resps, n, out);
+			ended++;
+			have = true;
 		}
+		if (have) {
+			consume(held, n, out);
+		}
+		free(held);
 	}
 	out->seconds = now_s() - t0;
 	ret = 0;

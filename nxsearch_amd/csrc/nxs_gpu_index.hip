@@ -636,7 +636,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 			(void)hipEventDestroy(ix->ev[i]);
 		}
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		nxsgpu_index::dev_slot_t &sl = ix->slot[i];
 		if (sl.active && sl.ev_done) {
 			(void)hipEventSynchronize(sl.ev_done);
@@ -678,7 +678,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream2) {
 		(void)hipStreamDestroy(ix->stream2);
 	}
-	if (ix->stream_rp[1]) {	/* ([0] is stream3) */
+	if (ix->stream_rp[1]) {	/* ([0] is stream3, [2] is stream_up) */
 		(void)hipStreamDestroy(ix->stream_rp[1]);
 	}
 	if (ix->stream3) {
@@ -1210,7 +1210,8 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	 *   queue A: stream (scans), stream2 (replays of a class: short), stream_fz
 	 *   queue B: stream3 (dense-term class; limits > 64: replays of batch slot 0),
 	 *            xstream[0], xstream[2]
-	 *   queue C: stream_up (uploads + k_cursors of the NEXT batch), xstream[1]
+	 *   queue C: stream_up (uploads + k_cursors of the NEXT batch; limits > 64: replays of every
+	 *            third batch -- such batches upload on the scan stream), xstream[1]
 	 *   queue D: stream_rp[1] (limits > 64: replays of batch slot 1), stream_down (record
 	 *            blocks of a sharded batch: all-gather + copy, beside the next batch)
 	 */
@@ -1231,9 +1232,13 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[2], hipStreamNonBlocking));
 	ix->stream_rp[0] = ix->stream3;		/* (the dense-term class does not exist for limits > 64) */
+	/* (queue C: MODE_BIG batches send their plans up on the scan stream, so nothing of theirs waits
+	 * behind a replay there.  A stream created here would land on a queue of the runtime's choosing --
+	 * measured: B, behind slot 0's replays) */
+	ix->stream_rp[2] = ix->stream_up;
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork3, hipEventDisableTiming));
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join3, hipEventDisableTiming));
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_up, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_ahead, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&ix->slot[i].ev_early, hipEventDisableTiming));
@@ -1443,7 +1448,7 @@ nxsgpu_index_apply(nxsgpu_index_t *ix, const nxsgpu_index_delta_t *d)
 	};
 	const double t_a0 = now_ms();
 	double t_a1 = t_a0, t_a2 = t_a0;
-	if (ix->slot[0].active || ix->slot[1].active) {
+	if (nxsgpu_batches_in_flight(ix)) {
 		set_error("nxsgpu_index_apply: batches are in flight");
 		return -1;
 	}
@@ -1718,7 +1723,7 @@ nxsgpu_set_profiling(nxsgpu_index_t *ix, int on)
 {
 	ix->profiling = on != 0;
 	/* the per-class events of both batch slots: created here, not inside a timed batch */
-	for (int i = 0; on && i < 2; i++) {
+	for (int i = 0; on && i < NXSGPU_INFLIGHT; i++) {
 		nxsgpu_index::dev_slot_t &sl = ix->slot[i];
 		if (!sl.ev_cls_ok && hipSetDevice(ix->device) == hipSuccess) {
 			bool ok = true;
@@ -1751,7 +1756,7 @@ nxsgpu_synchronize(nxsgpu_index_t *ix)
 extern "C" int
 nxsgpu_index_set_global_df(nxsgpu_index_t *ix, const uint32_t *df, uint32_t n_terms)
 {
-	if (ix->slot[0].active || ix->slot[1].active) {
+	if (nxsgpu_batches_in_flight(ix)) {
 		set_error("nxsgpu_index_set_global_df: batches are in flight");
 		return -1;
 	}

@@ -177,12 +177,12 @@ struct nxsgpu_index {
 					 * while batches are in flight: beside them, not queued behind
 					 * their scans */
 	hipStream_t	stream2;	/* heap replay of a finished query class, beside the next class's scan */
-	hipStream_t	stream_rp[2];	/* MODE_BIG batches (limit > 64): the replays of batch slot i -- milliseconds
-					 * of heap insertions -- run here, beside the other slot's scans AND replays */
+	hipStream_t	stream_rp[3];	/* MODE_BIG batches (limit > 64): the replays of a batch -- milliseconds of heap
+					 * insertions -- run here (batch seq mod 3), beside the next batches' scans AND replays */
 	hipStream_t	stream3;	/* the sparse + dense OR class (k_scanm<.., DROP>): few, latency-bound
 					 * wavefronts that run BESIDE the other classes, not in front of them */
 	hipEvent_t	ev_cls, ev_join, ev_fork3, ev_join3;
-	/* nxsgpu_search_dev_begin/_end: two batches in flight, each with its own
+	/* nxsgpu_search_dev_begin/_end: up to NXSGPU_INFLIGHT batches in flight, each with its own
 	 * device workspace and pinned staging; plans go up on their own stream */
 	hipStream_t	stream_up;
 	hipStream_t	stream_down;	/* record blocks: all-gather (sharded) + copy to pinned memory */
@@ -219,7 +219,7 @@ struct nxsgpu_index {
 		uint32_t *	h_ovf;		/* overflow flags coming back (inside h_stage) */
 		worklist_t *	wl;		/* the slot's work list: its vectors keep their capacity
 						 * (several MB a batch: no mmap / page-fault churn) */
-	}		slot[2];
+	}		slot[NXSGPU_INFLIGHT];
 	uint64_t	slot_seq;
 
 	uint64_t	n_docs, n_post;

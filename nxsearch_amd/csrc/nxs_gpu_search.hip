@@ -439,14 +439,45 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	for (const launch_t &l : wl.launches) {
 		n_late += l.count && !(l.kind == 3 || l.kind == 7);
 	}
-	const bool early_ok = early_stream && early_done && MODE == MODE_TOPK && ra && n_late >= 1 &&
-	    a0.k >= 1 && a0.k <= WAVE;
+	/*
+	 * MODE_BIG, several batches in flight: the scan stream is what a step costs (one batch's scans
+	 * behind the other's; the replays -- milliseconds -- run aside, a stream per batch).  The
+	 * conjunctive classes and their short replays go to the batch's REPLAY stream, in front of the
+	 * other classes' replays: beside this batch's tile scans instead of behind them.
+	 */
+	const bool early_big = MODE == MODE_BIG && replays_aside && replay_stream && ra && n_late >= 1 && ix->cfg.and_early;
+	if (early_big) {
+		early_stream = st_rp;
+	}
+	const bool early_ok = early_big || (early_stream && early_done && MODE == MODE_TOPK && ra && n_late >= 1 &&
+	    a0.k >= 1 && a0.k <= WAVE);
 	for (const launch_t &l : wl.launches) {
 		if (l.count && !(side3 && l.kind == 5) && !(early_ok && (l.kind == 3 || l.kind == 7))) {
 			last_launch = &l;
 		}
 	}
+	std::vector<const launch_t *> seq;
+	seq.reserve(wl.launches.size());
+	if (early_big) {
+		bool any = false;
+		for (const launch_t &l : wl.launches) {
+			if (l.count && (l.kind == 3 || l.kind == 7)) {
+				seq.push_back(&l);
+				any = true;
+			}
+		}
+		if (any) {	/* (behind the cursors, which a MODE_BIG batch runs on the scan stream) */
+			(void)hipEventRecord(ix->ev_fork3, ix->stream);
+			(void)hipStreamWaitEvent(st_rp, ix->ev_fork3, 0);
+		}
+	}
 	for (const launch_t &l : wl.launches) {
+		if (!(early_big && l.count && (l.kind == 3 || l.kind == 7))) {
+			seq.push_back(&l);
+		}
+	}
+	for (const launch_t *lp : seq) {
+		const launch_t &l = *lp;
 		scan_args_t a = a0;
 		const unsigned grid = l.count;
 		/* mask path / dense-term class: top-k filter pass only; the exact passes
@@ -523,7 +554,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		if (early) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
-			if (l.kind == 7) {
+			if (l.kind == 7 && topk64) {
 				nxs_launch_scanq(l.nt_bucket, grid, early_stream, a);
 			} else {
 				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, early_stream, a);
@@ -609,7 +640,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	if (scans_done) {
 		(void)hipEventRecord(scans_done, ix->stream);
 	}
-	if (early_any) {
+	if (early_any && !early_big) {
 		(void)hipEventRecord(early_done, early_stream);
 		(void)hipStreamWaitEvent(ix->stream, early_done, 0);
 		if (replays_aside) {
@@ -1034,7 +1065,7 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	}
 	/* (a re-run beside batches in flight stays out of the per-launch averages: with
 	 * it in, one overflowed query per step halved the "kernel_ms" bench.py prints) */
-	if (fast && ix->profiling && !(ix->slot[0].active || ix->slot[1].active)) {
+	if (fast && ix->profiling && !nxsgpu_batches_in_flight(ix)) {
 		float a = 0, b = 0;
 		(void)hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]);
 		(void)hipEventElapsedTime(&b, ix->ev[1], ix->ev[2]);
@@ -1276,7 +1307,7 @@ nxsgpu_search(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t
 {
 	/* own workspace; with batches in flight, own streams too: a re-run of a few
 	 * overflowed queries must not wait for the next batch's scans (19 ms at C5) */
-	const bool busy = ix->slot[0].active || ix->slot[1].active;
+	const bool busy = nxsgpu_batches_in_flight(ix) != 0;
 	if (busy) {
 		std::swap(ix->stream, ix->xstream[0]);
 		std::swap(ix->stream2, ix->xstream[1]);
@@ -1413,14 +1444,14 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	if (ensure_algo(ix, algo) != 0) {
 		return -1;
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		if (!ix->slot[i].active) {
 			sl = &ix->slot[i];
 			break;
 		}
 	}
 	if (!sl) {
-		set_error("two batches are already in flight");
+		set_error("%d batches are already in flight", NXSGPU_INFLIGHT);
 		return -1;
 	}
 	if (!sl->wl) {
@@ -1455,11 +1486,14 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * their own streams, beside the neighbouring batches' scans.
 	 */
 	bool others = false;
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		others = others || ix->slot[i].active;
 	}
 	const bool solo = nq <= 64 && !others && !gather;
-	hipStream_t s_up = solo ? ix->stream : ix->stream_up;
+	/* (limits > 64: the upload stream's hardware queue carries every third batch's replays --
+	 * milliseconds --, so these batches' plans and cursors go up on the scan stream) */
+	const bool big_b = limit > NXSGPU_FAST_K;
+	hipStream_t s_up = (solo || big_b) ? ix->stream : ix->stream_up;
 	/* the records come down on their own stream only when there is a collective
 	 * to run beside the next batch's scans; a plain 135 KB copy rides the scan
 	 * stream (a separate stream showed sporadic 5-20 ms host stalls in the copy
@@ -1698,7 +1732,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		launch_cursors(ix, sa, d_bnd_q, (uint32_t)(nseg + nq), s_up);
 	}
 	tc[1] = now_us();
-	if (!solo && (hipEventRecord(sl->ev_up, ix->stream_up) != hipSuccess ||
+	if (s_up != ix->stream && (hipEventRecord(sl->ev_up, s_up) != hipSuccess ||
 	    hipStreamWaitEvent(ix->stream, sl->ev_up, 0) != hipSuccess)) {
 		set_error("query upload failed");
 		return begin_fail(ix);
@@ -1750,7 +1784,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	const bool aside = (big || (o.records && short_batch && !ix->cfg.replay_join)) && nq && !gather && !solo && !ix->cfg.one_replay;
 	/* (limits <= 64: the replays of both slots share the replay stream -- they are short, and
 	 * stream_rp[0] is the dense-term class's stream) */
-	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl == &ix->slot[1]] : ix->stream2;
+	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl->seq % 3] : ix->stream2;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	sl->n_cls = 0;
 	if (nq) {
@@ -1865,7 +1899,7 @@ oldest_slot(nxsgpu_index_t *ix)
 {
 	nxsgpu_index::dev_slot_t *sl = NULL;
 
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
 		if (ix->slot[i].active && (!sl || ix->slot[i].seq < sl->seq)) {
 			sl = &ix->slot[i];
 		}
@@ -1973,7 +2007,12 @@ nxsgpu_batch_end(nxsgpu_index_t *ix, nxsgpu_batch_view_t *view)
 extern "C" int
 nxsgpu_batches_in_flight(const nxsgpu_index_t *ix)
 {
-	return (ix->slot[0].active ? 1 : 0) + (ix->slot[1].active ? 1 : 0);
+	int n = 0;
+
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
+		n += ix->slot[i].active ? 1 : 0;
+	}
+	return n;
 }
 
 extern "C" void
@@ -1986,7 +2025,7 @@ extern "C" int
 nxsgpu_search_dev(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *queries,
     uint32_t nq, uint64_t *d_doc_ids, float *d_scores, uint32_t *d_counts)
 {
-	if (ix->slot[0].active || ix->slot[1].active) {
+	if (nxsgpu_batches_in_flight(ix)) {
 		set_error("nxsgpu_search_dev: finish the batches in flight first (nxsgpu_search_dev_end)");
 		return -1;
 	}

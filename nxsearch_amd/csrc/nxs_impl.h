@@ -116,7 +116,7 @@ struct nxs_index {
 
 	/* query sharding (nxs_index_shard) and the batches in flight */
 	nxsgpu_comm_t *	comm;
-	struct nxs_pend	pend[2];
+	struct nxs_pend	pend[NXSGPU_INFLIGHT];
 	/* tests: the n-th next _begin / exact fix-up of this index fails (0: off) */
 	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv;
 	bool		resync_pending;	/* sharded: a rank's block flags said its files moved */

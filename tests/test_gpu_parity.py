@@ -627,8 +627,8 @@ def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch, kern)
 
 
 def test_pipelined_device_batches(nxs, tmp_path):
-    """nxsgpu_search_dev_begin/_end: two batches in flight with their own outputs
-    give what the blocking call gives; a third begin and a stray end are errors."""
+    """nxsgpu_search_dev_begin/_end: batches in flight with their own outputs
+    give what the blocking call gives; a fifth begin and a stray end are errors."""
     import torch
     c = corpus.write_corpus(str(tmp_path), 200_000, 8000, seed=41)
     terms = corpus.term_strings(8000, seed=41)
@@ -645,10 +645,19 @@ def test_pipelined_device_batches(nxs, tmp_path):
         gidx.search_dev_end()                      # nothing in flight
     gidx.search_dev_begin(plans[0], 48, k, N.BM25, *ptrs(outs[0]))
     gidx.search_dev_begin(plans[1], 48, k, N.BM25, *ptrs(outs[1]))
+    spare = [(torch.zeros((48, k), dtype=torch.int64, device=dev), torch.zeros((48, k), dtype=torch.float32, device=dev),
+              torch.zeros((48,), dtype=torch.int32, device=dev)) for _ in range(3)]
+    gidx.search_dev_begin(plans[0], 48, k, N.BM25, *ptrs(spare[0]))
+    gidx.search_dev_begin(plans[1], 48, k, N.BM25, *ptrs(spare[1]))
     with pytest.raises(N.NxsError):
-        gidx.search_dev_begin(plans[2], 48, k, N.BM25, *ptrs(outs[2]))   # two is the limit
+        gidx.search_dev_begin(plans[2], 48, k, N.BM25, *ptrs(spare[2]))  # NXSGPU_INFLIGHT = 4 is the limit
     with pytest.raises(N.NxsError):
         gidx.search_batch(batches[2], limit=k, fuzzymatch=False)         # blocking API refuses meanwhile
+    assert gidx.search_dev_end() == 0 and gidx.search_dev_end() == 0     # batches 0 and 1 ...
+    assert gidx.search_dev_end() == 0 and gidx.search_dev_end() == 0     # ... and their repeats
+    assert torch.equal(spare[0][0], outs[0][0]) and torch.equal(spare[1][1], outs[1][1])
+    gidx.search_dev_begin(plans[0], 48, k, N.BM25, *ptrs(outs[0]))
+    gidx.search_dev_begin(plans[1], 48, k, N.BM25, *ptrs(outs[1]))
     assert gidx.search_dev_end() == 0              # batch 0
     gidx.search_dev_begin(plans[2], 48, k, N.BM25, *ptrs(outs[2]))
     assert gidx.search_dev_end() == 0              # batch 1
@@ -675,9 +684,6 @@ def test_pipelined_string_batches(nxs, tmp_path):
     gidx.search_batch_begin(batches[0], limit=10, fuzzymatch=False)
     gidx.search_batch_begin(batches[1], limit=10, fuzzymatch=False)
     with pytest.raises(N.NxsError):
-        gidx.search_batch_begin(batches[2], limit=10, fuzzymatch=False)   # two is the limit
-    gidx._pending = gidx._pending[:2]
-    with pytest.raises(N.NxsError):
         gidx.search_batch(batches[2], limit=10, fuzzymatch=False)         # blocking call refuses meanwhile
     outs = []
     for i in range(2, len(batches)):
@@ -698,6 +704,24 @@ def test_pipelined_string_batches(nxs, tmp_path):
     gidx.search_batch_begin(batches[0][:9], limit=200, fuzzymatch=False)
     for q, g in zip(batches[0][:9], gidx.search_batch_end()):
         assert_same(g, oidx.search(q, limit=200, fuzzymatch=False), q)
+    # NXS_BATCHES_INFLIGHT = 4 in flight, limits mixed (MODE_BIG batches replay on alternating streams);
+    # a fifth is refused and leaves the four intact; results come back oldest first
+    plan = [(batches[0], 10), (batches[1], 300), (batches[3], 1000), (batches[4], 10), (batches[5], 100), (batches[0], 1000)]
+    for b, k in plan[:4]:
+        gidx.search_batch_begin(b, limit=k, fuzzymatch=False)
+    with pytest.raises(N.NxsError) as e:
+        gidx.search_batch_begin(batches[5], limit=10, fuzzymatch=False)
+    assert "already in flight" in e.value.msg
+    gidx._pending = gidx._pending[:4]
+    nxt = 4
+    for b, k in plan:
+        got = gidx.search_batch_end()
+        if nxt < len(plan):
+            gidx.search_batch_begin(plan[nxt][0], limit=plan[nxt][1], fuzzymatch=False)
+            nxt += 1
+        assert len(got) == len(b)
+        for q, g in zip(b, got):
+            assert_same(g, oracle_memo("pipe4", oidx, q, limit=k, fuzzymatch=False), (q, k))
     gidx.close()
 
 

@@ -153,6 +153,7 @@ struct gpu_cfg_t {
 	bool		use_blkmap;	/* !NXS_GPU_NOBLKMAP: block-presence bitmaps for the longer lists; conjunctions whose
 					 * required terms all have one intersect THOSE first (k_scanq) */
 	uint64_t	bm_share;	/* NXS_GPU_BM_SHARE (1024): a term gets a bitmap if it holds >= n_docs / this docs */
+	double		bigq_em;	/* NXS_GPU_BIGQ_EM (16): limits > 64 take k_scanq only for queries that expect fewer matches (it emits them all) */
 	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */

@@ -635,13 +635,16 @@ k_scanr(const scan_args_t A)
  *     threshold, and waits in an LDS list; a round's matches are sorted by descending doc,
  *     emitted, and fed to the top-k register.
  * Every token counts towards a doc's score whatever its role (search.c:240-253); only the
- * REQUIRED ones take part in steps 1 and 2.  Top-k filter pass (k <= 64) only; the other
- * passes of these queries take k_scanr.
+ * REQUIRED ones take part in steps 1 and 2.  Filter passes only (top-k, k <= 64; limits above that
+ * when a handful of matches is expected: BIG); the exact passes of these queries take k_scanr.
  */
 #define	SQ_CAP	64		/* surviving blocks per round: one per lane */
 #define	SQ_MCAP	128		/* matches of a round */
 
-template <int NT>
+/* BIG (limits > 64): every match is emitted -- the host sends a query here only if it expects a handful
+ * (build_worklist) --, nothing is tracked or published: the histogram threshold of the other MODE_BIG
+ * kernels needs >= k emitted docs before it says anything */
+template <int NT, bool BIG = false>
 __global__ void __launch_bounds__(WAVE)
 k_scanq(const scan_args_t A)
 {
@@ -719,9 +722,9 @@ k_scanq(const scan_args_t A)
 	};
 
 	float top = -INFINITY;
-	const float hint = range_hint(A, qm, g);
+	const float hint = BIG ? 0.0f : range_hint(A, qm, g);	/* (0: scores are > 0, like the top range's bigk_hint) */
 	float thr = hint;
-	const uint32_t kidx = A.k - 1;		/* 1 <= k <= 64 (host) */
+	const uint32_t kidx = BIG ? 0u : A.k - 1;	/* 1 <= k <= 64 (host) */
 	uint32_t n_out = 0;
 	bool ovf = false;
 	const uint64_t out_base = seg * A.seg_cap;
@@ -895,7 +898,7 @@ k_scanq(const scan_args_t A)
 							A.cand_sc[o] = sc;
 						}
 						n_out += ne;
-						while (bal) {
+						while (!BIG && bal) {
 							const int L = __builtin_ctzll(bal);
 							bal &= bal - 1;
 							const float v = __shfl(sc, L);
@@ -912,7 +915,7 @@ k_scanq(const scan_args_t A)
 			}
 		}
 	}
-	if (!ovf) {
+	if (!BIG && !ovf) {
 		range_publish(A, seg, __shfl(top, kidx));
 	}
 	if (lane == 0) {
@@ -1298,6 +1301,15 @@ nxs_launch_scanq(uint32_t nt_bucket, unsigned grid_, hipStream_t st, const scan_
 {
 	const dim3 grid(grid_), block(WAVE);
 
+	if (a.k > WAVE) {
+		switch (nt_bucket) {
+		case 2: hipLaunchKernelGGL((k_scanq<2, true>), grid, block, 0, st, a); break;
+		case 3: hipLaunchKernelGGL((k_scanq<3, true>), grid, block, 0, st, a); break;
+		case 5: hipLaunchKernelGGL((k_scanq<5, true>), grid, block, 0, st, a); break;
+		default: hipLaunchKernelGGL((k_scanq<8, true>), grid, block, 0, st, a); break;
+		}
+		return;
+	}
 	switch (nt_bucket) {
 	case 2: hipLaunchKernelGGL((k_scanq<2>), grid, block, 0, st, a); break;
 	case 3: hipLaunchKernelGGL((k_scanq<3>), grid, block, 0, st, a); break;

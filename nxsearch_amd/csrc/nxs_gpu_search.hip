@@ -182,8 +182,9 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 				 * block holds term t with probability 1 - (1 - df_t / N)^64) against what
 				 * the driver list would cost k_scanr.
 				 */
-				if (cf.use_blkmap && hq[i].n_req >= 2 && big_k == 0 && ix->n_post < (1ull << 32)) {
+				if (cf.use_blkmap && hq[i].n_req >= 2 && ix->n_post < (1ull << 32)) {
 					double surv = (double)ix->n_docs / 64.0;
+					double em = (double)ix->n_docs;		/* expected docs holding every required term */
 					bool all = true;
 					for (uint32_t t = 0; t < hq[i].nt; t++) {
 						if (!((hq[i].req >> t) & 1)) {
@@ -192,8 +193,11 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 						all = all && hq[i].bm_col[t] != 0xffffffffu;
 						const double rho = (double)(hq[i].pend[t] - hq[i].pbeg[t]) / (double)std::max<uint64_t>(ix->n_docs, 1);
 						surv *= 1.0 - std::pow(1.0 - std::min(rho, 1.0), 64.0);
+						em *= std::min(rho, 1.0);
 					}
-					if (all && surv * cf.bm_gain < (double)dfd) {
+					/* (limits > 64: k_scanq<.., BIG> emits EVERY match -- for queries that expect a
+					 * handful; more than a range's candidate list holds sends the query to the exact path) */
+					if (all && surv * cf.bm_gain < (double)dfd && (big_k == 0 || em < cf.bigq_em)) {
 						total -= work[i];
 						/* the bitmaps' words + the surviving blocks (a lane each), in posting units */
 						work[i] = (uint64_t)(ix->n_docs / 256 + surv * 64.0) + 1;
@@ -554,7 +558,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		if (early) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
-			if (l.kind == 7 && topk64) {
+			if (l.kind == 7 && (topk64 || MODE == MODE_BIG)) {
 				nxs_launch_scanq(l.nt_bucket, grid, early_stream, a);
 			} else {
 				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, early_stream, a);
@@ -602,7 +606,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				nxs_launch_scan8(MODE, l.nt_bucket, 1u, grid, ix->stream, a);
 			}
 		} else if (l.kind == 3 || l.kind == 7) {
-			if (l.kind == 7 && topk64) {
+			if (l.kind == 7 && (topk64 || MODE == MODE_BIG)) {
 				nxs_launch_scanq(l.nt_bucket, grid, ix->stream, a);
 			} else {
 				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, ix->stream, a);

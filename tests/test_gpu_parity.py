@@ -907,7 +907,13 @@ def test_default_limit_batch_on_a_larger_corpus(nxs, tmp_path):
                                  # candidate segments too small: the overflowed queries take the exact passes
                                  {"NXS_GPU_SEGCAP_BIG": "96", "NXS_GPU_BIG_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANR": "1", "NXS_GPU_NOSCAN1": "1"}, {"NXS_GPU_OLDSCAN": "1"},
-                                 {"NXS_GPU_ONEREPLAY": "1"}])
+                                 {"NXS_GPU_ONEREPLAY": "1"},
+                                 # every conjunctive query with bitmaps on k_scanq<.., BIG>, however many matches it expects
+                                 # (more than a range's candidate list holds: the exact path), with many short ranges, and none
+                                 {"NXS_GPU_BIGQ_EM": "1e18", "NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1000000"},
+                                 {"NXS_GPU_BIGQ_EM": "1e18", "NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1000000",
+                                  "NXS_GPU_BIG_MINPOST": "0", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_BIGQ_EM": "0"}, {"NXS_GPU_AND_NOEARLY": "1"}])
 def test_limits_above_64_ride_the_candidate_filter(nxs, tmp_path, monkeypatch, env):
     """64 < limit <= 8000 (the API's default is 1000, nxs_impl.h:39): the scan
     kernels filter on a histogram lower bound of the k-th best score (MODE_BIG) and

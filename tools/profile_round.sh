@@ -11,6 +11,9 @@ mkdir -p "$sum"
 export TMPDIR=/tmp
 note() { echo "[profile_round $(date +%T)] $*"; }
 
+# PARTS=a: C3 + C2 + C4 + default limit + sparse ids + doc shards; PARTS=b: C5 (two gpurun calls of <= 20 min each)
+PARTS=${PARTS:-ab}
+if [ "${PARTS#*a}" != "$PARTS" ]; then
 # (1) the driver's command, as the driver runs it
 note "default bench"
 python3 bench.py > "$sum/${tag}_bench.json" 2> "$out/${tag}_bench.err"
@@ -66,8 +69,13 @@ python3 bench.py --sparse-ids --cpu-seconds 10 --no-extras > "$sum/${tag}_sparse
 # doc shards (N4) on one GPU
 note "doc shards"
 python3 bench.py --docshard 4 --steps 10 --warmup 2 --cpu-seconds 10 > "$sum/${tag}_docshard4_c3_bench.json" 2>> "$out/${tag}_bench.err"
-# C5 on one GPU: bench line, kernel stats, traffic
+fi
+if [ "${PARTS#*b}" != "$PARTS" ]; then
+# C5 on one GPU: bench line, kernel stats, traffic (the calibration of part a is reused if its summary is there)
 note "C5"
+if [ ! -d "$out/${tag}_pmc_calib" ]; then
+  rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_calib" -o run -- python3 tools/pmc_calib.py > "$sum/${tag}_pmc_calib.json" 2> "$out/${tag}_pmc_calib.log"
+fi
 python3 bench.py --workload C5 --steps 8 --warmup 2 --cpu-seconds 10 --no-extras > "$sum/${tag}_c5_1gpu_bench.json" 2>> "$out/${tag}_bench.err"
 prof c5 --workload C5
 pmc c5 fetch FETCH_SIZE -- --workload C5
@@ -76,6 +84,7 @@ python3 tools/pmc_summary.py --stats "$out/${tag}_c5_stats" --pmc "$out/${tag}_c
     --steps 8 --out-prefix "$sum/${tag}_c5" --command "$B --workload C5" --name C5 --docs 50000000 --terms 2000000 --batch 8192 \
     --calib "$out/${tag}_pmc_calib" --calib-json "$sum/${tag}_pmc_calib.json"
 python3 bench.py --workload C5 --docshard 4 --steps 5 --warmup 1 --cpu-seconds 0 > "$sum/${tag}_docshard4_c5_bench.json" 2>> "$out/${tag}_bench.err"
+fi
 # the raw rocpd databases are ~10 MB each: gpurun merges at most 64 MiB back
 rm -rf "$out/${tag}"_*_stats "$out/${tag}"_*_pmc_* "$out/${tag}_pmc_calib"
 note "done"

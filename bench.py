@@ -578,7 +578,7 @@ def class_kernels(key, mode):
     if kind == 6:
         return ["k_scanb<%d, %s, false>" % (b3 if b3 != 8 else 5, tf(shape != 1))]
     if kind == 7:
-        return ["k_scanq<%d>" % b] if mode == 0 else ["k_scanr<%d, %d, %s>" % (mode, b, tf(shape == 1))]
+        return ["k_scanq<%d, %s>" % (b, tf(mode != 0))]
     return ["k_scan<%d, false>" % mode]
 
 

@@ -11,13 +11,6 @@ mkdir -p "$sum"
 export TMPDIR=/tmp
 note() { echo "[profile_round $(date +%T)] $*"; }
 
-# PARTS=a: C3 + C2 + C4 + default limit + sparse ids + doc shards; PARTS=b: C5 (two gpurun calls of <= 20 min each)
-PARTS=${PARTS:-ab}
-if [ "${PARTS#*a}" != "$PARTS" ]; then
-# (1) the driver's command, as the driver runs it
-note "default bench"
-python3 bench.py > "$sum/${tag}_bench.json" 2> "$out/${tag}_bench.err"
-
 # (2) C3: kernel stats + counters.  8 steps = every one of the 4 rotated batches twice
 B="python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras"
 prof() { # prefix, workload args..., then the counters come from the caller
@@ -35,6 +28,13 @@ pmc() { # name, dir suffix, counters..., -- workload args
   rocprofv3 --pmc "${ctrs[@]}" -d "$out/${tag}_${name}_pmc_${sfx}" -o run -- python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras "$@" \
       > /dev/null 2> "$out/${tag}_${name}_pmc_${sfx}.log"
 }
+# PARTS=a: C3 + C2 + C4 + default limit + sparse ids + doc shards; PARTS=b: C5 (two gpurun calls of <= 20 min each)
+PARTS=${PARTS:-ab}
+if [ "${PARTS#*a}" != "$PARTS" ]; then
+# (1) the driver's command, as the driver runs it
+note "default bench"
+python3 bench.py > "$sum/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+
 prof c3
 pmc c3 fetch FETCH_SIZE --
 pmc c3 write WRITE_SIZE --

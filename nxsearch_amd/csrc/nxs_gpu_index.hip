@@ -666,6 +666,11 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->stream_down) {
 		(void)hipStreamDestroy(ix->stream_down);
 	}
+	for (int i = 0; i < 3; i++) {
+		if (ix->down_spare[i]) {
+			(void)hipStreamDestroy(ix->down_spare[i]);
+		}
+	}
 	if (ix->stream_fz) {
 		(void)hipStreamSynchronize(ix->stream_fz);
 		(void)hipStreamDestroy(ix->stream_fz);
@@ -1363,6 +1368,7 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	}
 
 	warm_streams(ix);
+	pick_record_stream(ix);
 done_partial:
 	(void)hipFree(d_keys_in);
 	(void)hipFree(d_keys);
@@ -1951,6 +1957,92 @@ warm_streams(nxsgpu_index_t *ix)
 	(void)hipFree(d_buf);
 	if (h_buf) {
 		(void)hipHostFree(h_buf);
+	}
+}
+
+/*
+ * Which hardware queue a stream lands on is the runtime's choice (the creation order only decides it for the
+ * first four streams: traced, stream_down shared the SCAN stream's queue).  For the record stream of sharded
+ * batches that matters: it holds a device-side wait for the batch's last replay, and a wait at the head of a
+ * hardware queue blocks every stream behind it -- the next batch's scans.  So: measure.  A bounded spin kernel
+ * (150 us) on a reference stream, a trivial kernel on the candidate; if the candidate's kernel is done while
+ * the spin still runs, the two do not share a queue.  The first candidate -- stream_down itself, then up to
+ * three spare streams -- that runs beside the scan stream, the dense-term stream AND the upload stream
+ * becomes stream_down; with none, sharded batches keep the records on the scan stream (down_inline).
+ */
+__global__ void __launch_bounds__(64)
+k_queue_probe(uint32_t ticks, uint32_t *sink)
+{
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();	/* 100 MHz */
+	while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+		__builtin_amdgcn_s_sleep(32);
+	}
+	if (ticks == 0xffffffffu) {
+		*sink = 1;
+	}
+}
+
+static bool
+runs_beside(hipStream_t ref, hipStream_t x, hipEvent_t e_ref, hipEvent_t e_x, uint32_t *d_sink)
+{
+	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, ref, 15000u, d_sink);
+	(void)hipEventRecord(e_ref, ref);
+	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, x, 0u, d_sink);
+	(void)hipEventRecord(e_x, x);
+	(void)hipEventSynchronize(e_x);
+	const bool beside = hipEventQuery(e_ref) == hipErrorNotReady;
+	(void)hipEventSynchronize(e_ref);
+	return beside;
+}
+
+void
+pick_record_stream(nxsgpu_index_t *ix)
+{
+	hipEvent_t e_ref = NULL, e_x = NULL;
+	uint32_t *d_sink = NULL;
+	const hipStream_t refs[3] = { ix->stream, ix->stream3, ix->stream_up };
+
+	if (ix->cfg.down_inline || hipMalloc((void **)&d_sink, 4) != hipSuccess) {
+		return;
+	}
+	if (hipEventCreateWithFlags(&e_ref, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&e_x, hipEventDisableTiming) != hipSuccess) {
+		goto out;
+	}
+	for (int c = 0; c <= 3; c++) {
+		hipStream_t cand = ix->stream_down;
+		bool ok = true;
+
+		if (c > 0) {
+			if (hipStreamCreateWithFlags(&ix->down_spare[c - 1], hipStreamNonBlocking) != hipSuccess) {
+				ix->down_spare[c - 1] = NULL;
+				break;
+			}
+			cand = ix->down_spare[c - 1];
+			hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, cand, 0u, d_sink);	/* (binds its queue) */
+			(void)hipStreamSynchronize(cand);
+		}
+		for (int r = 0; r < 3 && ok; r++) {
+			/* (twice: a slow first launch must not pass for "beside") */
+			ok = runs_beside(refs[r], cand, e_ref, e_x, d_sink) && runs_beside(refs[r], cand, e_ref, e_x, d_sink);
+		}
+		if (ok) {
+			if (c > 0) {
+				std::swap(ix->stream_down, ix->down_spare[c - 1]);
+			}
+			ix->down_probe = c;
+			goto out;
+		}
+	}
+	ix->down_probe = -1;
+	ix->cfg.down_inline = true;	/* no stream runs beside all three: the records ride the scan stream */
+out:
+	(void)hipGetLastError();
+	if (e_ref) (void)hipEventDestroy(e_ref);
+	if (e_x) (void)hipEventDestroy(e_x);
+	(void)hipFree(d_sink);
+	if (ix->cfg.debug_timing) {
+		fprintf(stderr, "[nxsgpu] record stream: candidate %d\n", ix->down_probe);
 	}
 }
 

@@ -187,6 +187,8 @@ struct nxsgpu_index {
 	 * device workspace and pinned staging; plans go up on their own stream */
 	hipStream_t	stream_up;
 	hipStream_t	stream_down;	/* record blocks: all-gather (sharded) + copy to pinned memory */
+	hipStream_t	down_spare[3];	/* pick_record_stream: candidates that were not taken (or the original stream_down) */
+	int		down_probe;	/* ... which candidate was (0 = stream_down as created, -1 = none: down_inline) */
 	hipStream_t	stream_fz;	/* BK-tree searches: beside the batches in flight, not behind them */
 	struct nxsgpu_comm *comm;	/* attached communicator (query sharding) or NULL */
 	struct dev_slot_t {
@@ -471,6 +473,7 @@ int	rebuild_impacts(nxsgpu_index_t *ix, unsigned only = 3);	/* bit a: ranking fu
 /* materialise the impacts of `algo` (first search with the non-default function) */
 int	ensure_algo(nxsgpu_index_t *ix, int algo);
 void	warm_streams(nxsgpu_index_t *ix);
+void	pick_record_stream(nxsgpu_index_t *ix);
 
 /* ---- nxs_gpu_fuzzy.hip ---- */
 void	bk_aux_free(nxsgpu_index_t *ix);

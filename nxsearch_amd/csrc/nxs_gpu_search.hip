@@ -1785,10 +1785,14 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	/* (limits <= 64: only where the tail is a visible share of the step -- short batches; a C5 batch scans
 	 * for 35 ms, its host side is nearly as long, and ending it on the replay stream cost 7 %) */
 	const bool short_batch = total_post < (1ull << 32);
-	const bool aside = (big || (o.records && short_batch && !ix->cfg.replay_join)) && nq && !gather && !solo && !ix->cfg.one_replay;
+	/* (sharded batches too: the all-gather, on its own stream, waits for the batch's replay stream instead of
+	 * the scan stream waiting for the replays; MODE_BIG: the record stream shares hardware queue D with stream_rp[1], which
+	 * these batches leave alone -- a collective queued behind another batch's 7 ms replay would end its batch late) */
+	const bool aside = (big || (o.records && short_batch && !ix->cfg.replay_join)) && nq && (!gather || own_down) &&
+	    !solo && !ix->cfg.one_replay;
 	/* (limits <= 64: the replays of both slots share the replay stream -- they are short, and
 	 * stream_rp[0] is the dense-term class's stream) */
-	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[sl->seq % 3] : ix->stream2;
+	hipStream_t s_end = !aside ? ix->stream : big ? ix->stream_rp[gather ? (sl->seq & 1) * 2 : sl->seq % 3] : ix->stream2;
 	if (ix->profiling) (void)hipEventRecord(sl->ev_t[0], ix->stream);
 	sl->n_cls = 0;
 	if (nq) {
@@ -1825,7 +1829,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 		 * per batch, sharded runs only) and the copy to pinned memory overlap the
 		 * next batch's scans instead of sitting in front of them.
 		 */
-		if (own_down && (hipEventRecord(sl->ev_res, ix->stream) != hipSuccess ||
+		if (own_down && (hipEventRecord(sl->ev_res, aside ? s_end : ix->stream) != hipSuccess ||
 		    hipStreamWaitEvent(s_down, sl->ev_res, 0) != hipSuccess)) {
 			set_error("event failed");
 			return begin_fail(ix);
@@ -1844,7 +1848,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			set_error("copy failed");
 			return begin_fail(ix);
 		}
-		if (hipEventRecord(sl->ev_done, aside ? s_end : s_down) != hipSuccess) {
+		if (hipEventRecord(sl->ev_done, (aside && !gather) ? s_end : s_down) != hipSuccess) {
 			set_error("event failed");
 			return begin_fail(ix);
 		}
@@ -2023,6 +2027,9 @@ extern "C" void
 nxsgpu_index_reconfigure(nxsgpu_index_t *ix)
 {
 	cfg_from_env(ix->cfg);
+	if (ix->down_probe < 0) {
+		ix->cfg.down_inline = true;	/* (pick_record_stream found no stream of its own for the records) */
+	}
 }
 
 extern "C" int

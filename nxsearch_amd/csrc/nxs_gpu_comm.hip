@@ -211,7 +211,7 @@ nxsgpu_comm_allgather(nxsgpu_comm_t *c, const void *send, void *recv, size_t byt
 extern "C" int
 nxsgpu_index_set_comm(nxsgpu_index_t *ix, nxsgpu_comm_t *c)
 {
-	if (ix->slot[0].active || ix->slot[1].active) {
+	if (nxsgpu_batches_in_flight(ix)) {
 		set_error("nxsgpu_index_set_comm: batches are in flight");
 		return -1;
 	}

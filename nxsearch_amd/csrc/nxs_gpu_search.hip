@@ -400,6 +400,16 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	}
 }
 
+/* the gathered record blocks, device -> mapped pinned host memory (8-byte words; blocks are multiples of 8) */
+__global__ void __launch_bounds__(256)
+k_records_out(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint64_t n8)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+		dst[i] = src[i];
+	}
+}
+
 static void
 launch_cursors(nxsgpu_index_t *ix, const scan_args_t &a, const uint32_t *d_bnd_q, uint32_t n_bnd,
     hipStream_t stream = NULL)
@@ -1841,8 +1851,13 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			if (comm_allgather_dev(ix->comm, d_myblock, sl->d_blocks, sl->block_bytes, s_down) != 0) {
 				return begin_fail(ix);
 			}
-			if (hipMemcpyAsync(sl->h_blocks, sl->d_blocks, (size_t)world * sl->block_bytes,
-			    hipMemcpyDeviceToHost, s_down) != hipSuccess) {
+			/* (a kernel, not a copy command: the gathered blocks go to the mapped pinned buffer as posted
+			 * writes.  hipMemcpyAsync on this stream stalled the HOST for ~7 ms once or twice per run
+			 * -- one batch in eight at worst -- which was the whole gap between a sharded and a plain step) */
+			const uint64_t n8 = ((uint64_t)world * sl->block_bytes) / 8;
+			hipLaunchKernelGGL(k_records_out, dim3((unsigned)std::min<uint64_t>((n8 + 255) / 256, 2048)), dim3(256), 0, s_down,
+			    (const uint64_t *)sl->d_blocks, (uint64_t *)sl->h_blocks_dev, n8);
+			if (hipGetLastError() != hipSuccess) {
 				set_error("copy failed");
 				return begin_fail(ix);
 			}

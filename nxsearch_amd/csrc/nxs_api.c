@@ -64,6 +64,14 @@ struct nxs_pool {
 	 */
 	_Atomic uint64_t next;
 	atomic_size_t	done;		/* items of the current run completed */
+	/*
+	 * gen as the workers may read it without the lock: a worker that has just finished a run
+	 * polls it for POOL_SPIN_NS before it goes to sleep -- a batch's front half is two runs
+	 * (parse, compile) a few dozen microseconds apart, and a pipelined server's next batch is
+	 * a millisecond away: the second run finds its workers awake instead of paying the wake-up.
+	 */
+	_Atomic uint64_t gen_pub;
+	long long	spin_ns;	/* NXS_POOL_SPIN_US (120; 0: sleep at once), read when the pool is created */
 };
 #define	POOL_GEN_SHIFT	40
 
@@ -106,6 +114,22 @@ pool_main(void *arg)
 
 	pthread_mutex_lock(&p->mu);
 	for (;;) {
+		if (seen && p->spin_ns && p->gen == seen && !p->stop) {
+			struct timespec t0, t1;
+
+			pthread_mutex_unlock(&p->mu);
+			clock_gettime(CLOCK_MONOTONIC, &t0);
+			while (atomic_load_explicit(&p->gen_pub, memory_order_acquire) == seen) {
+				for (int i = 0; i < 64; i++) {
+					__builtin_ia32_pause();
+				}
+				clock_gettime(CLOCK_MONOTONIC, &t1);
+				if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > p->spin_ns) {
+					break;
+				}
+			}
+			pthread_mutex_lock(&p->mu);
+		}
 		while (p->gen == seen && !p->stop) {
 			pthread_cond_wait(&p->cv_work, &p->mu);
 		}
@@ -134,6 +158,11 @@ pool_create(unsigned n_thr)
 	if (!p) {
 		return NULL;
 	}
+	{
+		const char *e = getenv("NXS_POOL_SPIN_US");
+		const long v = e ? strtol(e, NULL, 10) : 120;
+		p->spin_ns = (v < 0 ? 0 : v > 5000 ? 5000 : v) * 1000ll;
+	}
 	pthread_mutex_init(&p->mu, NULL);
 	pthread_cond_init(&p->cv_work, NULL);
 	pthread_cond_init(&p->cv_done, NULL);
@@ -155,6 +184,7 @@ pool_destroy(struct nxs_pool *p)
 	}
 	pthread_mutex_lock(&p->mu);
 	p->stop = true;
+	atomic_store_explicit(&p->gen_pub, ~0ull, memory_order_release);
 	pthread_cond_broadcast(&p->cv_work);
 	pthread_mutex_unlock(&p->mu);
 	for (unsigned i = 0; i < p->n_thr; i++) {
@@ -187,6 +217,7 @@ pool_run(struct nxs_pool *p, pool_fn_t fn, void *arg, size_t n, size_t chunk)
 	gen = ++p->gen;
 	atomic_store(&p->done, 0);
 	atomic_store(&p->next, (gen & 0xffffff) << POOL_GEN_SHIFT);
+	atomic_store_explicit(&p->gen_pub, gen, memory_order_release);
 	pthread_cond_broadcast(&p->cv_work);
 	pthread_mutex_unlock(&p->mu);
 	pool_work(p, gen, fn, arg, n, chunk);

@@ -376,6 +376,11 @@ eval_prog(const uint8_t *prog, uint32_t len, uint32_t m)
 #ifndef SCAN8_RING_MAX
 #define	SCAN8_RING_MAX	2		/* prefetch ring depth of the one-window tile path */
 #endif
+#ifndef SCAN8_RING_BIG
+#define	SCAN8_RING_BIG	1		/* ... of its MODE_BIG instantiations: 92 + 20 registers are four wavefronts per SIMD, 82 + 10
+					 * five -- a default-limit C3 batch, three alternating runs: 272.7 / 272.8 / 272.7 k queries/s
+					 * at depth 2, 277.0 / 278.0 / 278.6 at 1, 252 at 4 */
+#endif
 #ifndef SCANR_RING
 #define	SCANR_RING	4		/* prefetch ring depth of the required-term path (span rounds: 1, 2, 4 measured equal; whole-window rounds rotate the driver every round: 1 -> 4 = 1.22 -> 1.19 ms per C3 step) */
 #endif

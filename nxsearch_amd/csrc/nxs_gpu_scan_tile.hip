@@ -383,7 +383,7 @@ k_scan8(const scan_args_t A)
 	constexpr bool AP = K == 1 && !ANDM;
 	/* AP: windows in flight per term below set A, and the ring position of the
 	 * oldest (bring_take) */
-	constexpr int RING = SCAN8_RING_MAX;
+	constexpr int RING = MODE == MODE_BIG ? SCAN8_RING_BIG : SCAN8_RING_MAX;
 	uint32_t rp[NT];
 	ring_stamps<RING> rst[NT];	/* issue stamps of the ring loads (vm_wait_younger) */
 	uint32_t vseq = 0;

@@ -423,6 +423,7 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
         pytest.skip("llvm binutils not present")
     src = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu_dev.h")).read()
     ring8 = int(re.search(r"#define\s+SCAN8_RING_MAX\s+(\d+)", src).group(1))
+    ring8b = int(re.search(r"#define\s+SCAN8_RING_BIG\s+(\d+)", src).group(1))      # MODE_BIG (= 3) instantiations
     ringm = int(re.search(r"#define\s+SCANM_RING\s+(\d+)", src).group(1))
     ringr = int(re.search(r"#define\s+SCANR_RING\s+(\d+)", src).group(1))
     srcb = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu_scan_bit.hip")).read()
@@ -436,13 +437,13 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
     seen = 0
     for m in re.finditer(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count:).)*?\.name:\s+(\S+)", notes, re.S):
         agpr, name = int(m.group(1)), m.group(2)
-        k8 = re.match(r"_Z7k_scan8ILi\d+ELi(\d+)ELi(\d+)EE", name)
+        k8 = re.match(r"_Z7k_scan8ILi(\d+)ELi(\d+)ELi(\d+)EE", name)
         kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)ELb[01]EE", name)
         km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]ELb[01]EE", name)
         kb = re.match(r"_Z7k_scanbILi(\d+)ELb[01]ELb[01]EE", name)
         if k8:
-            nt, mm = int(k8.group(1)), int(k8.group(2))
-            want = 2 * ring8 * nt if (nt >= 3 and mm != 2) else 0
+            mode, nt, mm = int(k8.group(1)), int(k8.group(2)), int(k8.group(3))
+            want = 2 * (ring8b if mode == 3 else ring8) * nt if (nt >= 3 and mm != 2) else 0
         elif kr:
             want = 2 * ringr * int(kr.group(1))
         elif km:

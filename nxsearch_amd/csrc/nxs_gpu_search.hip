@@ -192,7 +192,9 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 						}
 						all = all && hq[i].bm_col[t] != 0xffffffffu;
 						const double rho = (double)(hq[i].pend[t] - hq[i].pbeg[t]) / (double)std::max<uint64_t>(ix->n_docs, 1);
-						surv *= 1.0 - std::pow(1.0 - std::min(rho, 1.0), 64.0);
+						double e64 = 1.0 - std::min(rho, 1.0);	/* ^64 by squaring (std::pow: 2 500 calls a batch) */
+						e64 *= e64; e64 *= e64; e64 *= e64; e64 *= e64; e64 *= e64; e64 *= e64;
+						surv *= 1.0 - e64;
 						em *= std::min(rho, 1.0);
 					}
 					/* (limits > 64: k_scanq<.., BIG> emits EVERY match -- for queries that expect a
@@ -1555,8 +1557,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	 * block and fills the status words itself before the launch.
 	 */
 	/* (the block as part of the batch's one upload -- zeroed and filled on the host, the all-gather's send buffer where
-	 * it lies in the workspace: measured for sharded batches, 770k -> 650k queries/s -- zeroing 135 KB of PINNED memory
-	 * costs the host 0.3 ms per batch; the device-side memset stays) */
+	 * it lies in the workspace: measured for sharded batches, 770k -> 650k queries/s, `_begin` 0.3 ms longer -- not the
+	 * host's writes (pinned memory zeroes at 117 GB/s here, like pageable); the device-side memset stays) */
 	const bool block_in_ws = false;
 	const bool block_on_host = o.records && !gather;
 
@@ -1575,6 +1577,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	if (fill_dev_queries(ix, algo, queries, nq, h_q, total_post, !big) != 0) {
 		return -1;
 	}
+	const double tb_fill = now_us();
 	build_worklist(ix, h_q, nq, wl, solo, big ? limit : 0);
 	tb1 = now_us();
 	const uint64_t nseg = wl.n_segs;
@@ -1875,9 +1878,9 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sl->active = true;
 	if (ix->cfg.debug_timing) {
 		tb3 = now_us();
-		fprintf(stderr, "[nxsgpu begin #%llu] plan+worklist %.0f us, staging+alloc %.0f us, enqueue %.0f us "
+		fprintf(stderr, "[nxsgpu begin #%llu] (fill %.0f us) plan+worklist %.0f us, staging+alloc %.0f us, enqueue %.0f us "
 		    "(upload %.0f, cursors %.0f, fork %.0f, scans+replays %.0f, tail %.0f)\n",
-		    (unsigned long long)sl->seq, tb1 - tb0, tb2 - tb1, tb3 - tb2,
+		    (unsigned long long)sl->seq, tb_fill - tb0, tb1 - tb0, tb2 - tb1, tb3 - tb2,
 		    tc[0] - tb2, tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tb3 - tc[3]);
 	}
 	return 0;

@@ -102,7 +102,7 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_comm_unique_id", "nxsgpu_comm_create", "nxsgpu_comm_destroy",
     "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_allgather",
     "nxsgpu_index_set_comm", "nxsgpu_batch_begin", "nxsgpu_batch_end",
-    "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_hbm_read_gbs",
+    "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_index_set_parallel", "nxsgpu_hbm_read_gbs",
     "nxsgpu_hbm_calibrate",
     "nxsgpu_index_apply", "nxsgpu_index_set_bk", "nxsgpu_index_set_global_df",
     "nxsgpu_search_candidates", "nxsgpu_merge_candidates",

@@ -272,6 +272,15 @@ nxs_test_pool(unsigned n_thr, size_t n, unsigned rounds, size_t chunk)
 #endif /* NXS_TEST_HOOKS */
 
 /* the pool of an instance: NXS_HOST_THREADS (read once), else min(cores, 16) */
+static struct nxs_pool *nxs_pool_get(nxs_t *nxs);
+
+/* nxsgpu_parallel_t: the device layer's per-query host work on this nxs_t's pool */
+static void
+api_parallel(void *ctx, nxsgpu_body_t body, void *arg, size_t n, size_t chunk)
+{
+	pool_run(nxs_pool_get((nxs_t *)ctx), body, arg, n, chunk);
+}
+
 static struct nxs_pool *
 nxs_pool_get(nxs_t *nxs)
 {
@@ -2035,6 +2044,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 				plans[n_plans++] = q->plan;
 			}
 		}
+		nxsgpu_index_set_parallel(idx->dev, api_parallel, nxs);
 		if (collective && nxs_index_changed(idx)) {
 			/* a batch is in flight (else resync_before_batch refreshed just now): tell
 			 * the peers, all ranks drain and re-sync together */

@@ -39,6 +39,7 @@
 #include <cstdarg>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <time.h>
 #include <type_traits>
@@ -191,6 +192,8 @@ struct nxsgpu_index {
 	int		down_probe;	/* ... which candidate was (0 = stream_down as created, -1 = none: down_inline) */
 	hipStream_t	stream_fz;	/* BK-tree searches: beside the batches in flight, not behind them */
 	struct nxsgpu_comm *comm;	/* attached communicator (query sharding) or NULL */
+	nxsgpu_parallel_t par_run;	/* the caller's worker threads (nxsgpu_index_set_parallel) or NULL */
+	void *		par_ctx;
 	struct dev_slot_t {
 		void *		ws;
 		size_t		ws_len;

@@ -885,7 +885,13 @@ fill_dev_queries(const nxsgpu_index_t *ix, int algo, const nxsgpu_query_t *queri
 	J.total_post.store(0);
 	J.bad.store(0);
 	J.bad_term.store(0);
-	if (ix->par_run && nq >= 128) {
+	/* (waking the workers costs 50-100 us: only for batches with enough tokens to pay for it -- a C2 batch of
+	 * 1024 single-term queries is 20 us of this work on one thread) */
+	uint64_t n_tok = 0;
+	for (uint32_t i = 0; i < nq; i++) {
+		n_tok += queries[i].n_tokens;
+	}
+	if (ix->par_run && nq >= 128 && n_tok >= 3 * (uint64_t)nq) {
 		ix->par_run(ix->par_ctx, fill_dev_chunk, &J, nq, 32);
 	} else if (nq) {
 		fill_dev_chunk(&J, 0, nq);

@@ -1965,7 +1965,7 @@ warm_streams(nxsgpu_index_t *ix)
  * first four streams: traced, stream_down shared the SCAN stream's queue).  For the record stream of sharded
  * batches that matters: it holds a device-side wait for the batch's last replay, and a wait at the head of a
  * hardware queue blocks every stream behind it -- the next batch's scans.  So: measure.  A bounded spin kernel
- * (150 us) on a reference stream, a trivial kernel on the candidate; if the candidate's kernel is done while
+ * (400 us) on a reference stream, a trivial kernel on the candidate; if the candidate's kernel is done while
  * the spin still runs, the two do not share a queue.  The first candidate -- stream_down itself, then up to
  * three spare streams -- that runs beside the scan stream, the dense-term stream AND the upload stream
  * becomes stream_down; with none, sharded batches keep the records on the scan stream (down_inline).
@@ -1985,7 +1985,7 @@ k_queue_probe(uint32_t ticks, uint32_t *sink)
 static bool
 runs_beside(hipStream_t ref, hipStream_t x, hipEvent_t e_ref, hipEvent_t e_x, uint32_t *d_sink)
 {
-	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, ref, 15000u, d_sink);
+	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, ref, 40000u, d_sink);	/* 400 us: a busy host must not make the candidate look late */
 	(void)hipEventRecord(e_ref, ref);
 	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, x, 0u, d_sink);
 	(void)hipEventRecord(e_x, x);

@@ -1580,12 +1580,23 @@ plan_parse_chunk(void *arg, size_t lo, size_t hi)
 		}
 		nxs_query_prepare(j->idx, j->queries[i], q);
 		if (q->errcode) {
+			nxs_query_release_scratch(q);	/* (what the second pass would do for it) */
+			q->compiled = true;
 			continue;
 		}
 		/* idxterm_lookup for every token (tokenizer.c:171-176) */
+		bool miss = false;
 		for (size_t k = 0; k < q->n_tokens; k++) {
 			qtok_t *t = &q->tokens[k];
 			t->term_id = nxs_term_lookup(j->idx, (const uint8_t *)t->value, t->len);
+			miss = miss || !t->term_id;
+		}
+		/* nothing of this query waits for the fuzzy search: compile it here and now -- a batch without
+		 * misses (or with fuzzymatch off) is ONE run over the worker threads, not two */
+		if (!miss || !j->sp->fuzzymatch) {
+			(void)nxs_query_compile(q);
+			nxs_query_release_scratch(q);
+			q->compiled = true;
 		}
 	}
 }
@@ -1596,7 +1607,7 @@ plan_compile_chunk(void *arg, size_t lo, size_t hi)
 	const plan_job_t *j = arg;
 
 	for (size_t i = lo; i < hi; i++) {
-		if (j->prep[i].cached) {
+		if (j->prep[i].cached || j->prep[i].compiled) {
 			continue;
 		}
 		if (!j->prep[i].errcode) {
@@ -1627,7 +1638,7 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 	for (size_t i = 0; sp->fuzzymatch && i < n; i++) {
 		const qprep_t *q = &prep[i];
 
-		for (size_t j = 0; !q->errcode && j < q->n_tokens; j++) {
+		for (size_t j = 0; !q->errcode && !q->compiled && !q->cached && j < q->n_tokens; j++) {
 			if (!q->tokens[j].term_id) {
 				n_fz++;
 				fz_len += q->tokens[j].len;
@@ -1648,7 +1659,7 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 		}
 		for (size_t i = 0; i < n; i++) {
 			qprep_t *q = &prep[i];
-			if (q->errcode) {
+			if (q->errcode || q->compiled || q->cached) {
 				continue;
 			}
 			for (size_t j = 0; j < q->n_tokens; j++) {
@@ -1677,7 +1688,13 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 			prep[fz_q[k]].tokens[fz_t[k]].term_id = fz_ids[k];
 		}
 	}
-	pool_run(pool, plan_compile_chunk, &job, n, 32);
+	bool second = n_fz != 0;
+	for (size_t i = 0; !second && i < n; i++) {
+		second = !prep[i].cached && !prep[i].compiled;
+	}
+	if (second) {
+		pool_run(pool, plan_compile_chunk, &job, n, 32);
+	}
 	/* the batch's new plans into the cache (this thread only) */
 	for (size_t i = 0; pc && i < n; i++) {
 		const qprep_t *q = &prep[i];

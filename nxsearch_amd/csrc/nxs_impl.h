@@ -236,6 +236,7 @@ typedef struct qprep {
 	bool		empty;		/* no live tokens: empty result */
 	bool		wide;		/* does not fit nxsgpu_query_t: wplan is its plan */
 	bool		cached;		/* the plan came from the index's plan cache: nothing was parsed */
+	bool		compiled;	/* plan_batch: compiled in the first pass already (no token waits for the fuzzy search) */
 	nxsgpu_query_t	plan;
 	nxsgpu_wide_query_t wplan;	/* arrays owned by this object */
 	char **		heap_vals;	/* token values a filter grew beyond the arena's reserve */

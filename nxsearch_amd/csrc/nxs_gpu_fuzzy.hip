@@ -673,14 +673,31 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	const uint64_t ccap = qcap * FZ_NQ;
 	const uint64_t mcap = std::max<uint64_t>(1024, ccap / 4);
 	const size_t need = 16384 + FZ_NQ * FZ_CSTRIDE * 4 + (ccap + mcap) * sizeof(fz_item_t) + (size_t)n_tok * (256 * 8 + 8 + 4 + 4 + 4) + 64 + blen + 16 +
-	    ((size_t)n_tok + 1) * 4 + (NXS_MYERS_MAXPAT + 4) * 4 + 16 * 256;
-	uint32_t h_cnt[4] = { 0, 0, 0, 0 };
+	    ((size_t)n_tok + 1) * 4 + (NXS_MYERS_MAXPAT + 4) * 4 + 16 * 256 + 256;
 	std::vector<uint32_t> h_qcnt(FZ_NQ * FZ_CSTRIDE);
-	unsigned long long h_evals[2] = { 0, 0 };
-	/* one upload: token offsets, rank of every token in the length-sorted order,
-	 * first rank of every length */
-	std::vector<uint32_t> up((size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2);
-	uint32_t *roff = up.data(), *rank = roff + n_tok + 1, *len_off = rank + n_tok;
+	/* ONE upload from pinned memory -- token offsets, rank of every token in the length-sorted order, first
+	 * rank of every length, then the tokens' bytes -- and ONE copy back (term ids, counters, evaluation counts):
+	 * a copy to or from pageable memory is staged by the runtime and costs the host 20-40 us apiece, and the
+	 * caller (plan_batch) sits waiting for this pass */
+	const size_t up_words = (size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2;
+	const size_t up_bytes = (up_words * 4 + 15) & ~(size_t)15;
+	const size_t dn_bytes = ((size_t)n_tok * 4 + 15 & ~(size_t)15) + 16 + 16;
+	const size_t pin_need = up_bytes + blen + 16 + dn_bytes + 64;
+	if (ix->fz_pin_len < pin_need) {
+		if (ix->fz_pin) {
+			(void)hipHostFree(ix->fz_pin);
+			ix->fz_pin = NULL;
+			ix->fz_pin_len = 0;
+		}
+		if (hipHostMalloc((void **)&ix->fz_pin, pin_need + pin_need / 2, hipHostMallocDefault) != hipSuccess) {
+			set_error("hipHostMalloc(%zu) for the fuzzy staging failed", pin_need);
+			return -1;
+		}
+		ix->fz_pin_len = pin_need + pin_need / 2;
+	}
+	uint32_t *const up = (uint32_t *)ix->fz_pin;
+	uint8_t *const h_dn = ix->fz_pin + up_bytes + ((blen + 16 + 15) & ~(size_t)15);
+	uint32_t *roff = up, *rank = roff + n_tok + 1, *len_off = rank + n_tok;
 
 	if (ix->fz_len < need) {
 		if (ix->fz) {
@@ -697,15 +714,20 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	uint8_t *p = (uint8_t *)ix->fz;
 	fz_item_t *d_cand = carve<fz_item_t>(p, ccap);
 	fz_item_t *d_match = carve<fz_item_t>(p, mcap);
-	uint32_t *d_cnt = carve<uint32_t>(p, 4);		/* -, matches, overflow, (seed's count) */
-	uint32_t *d_qcnt = carve<uint32_t>(p, FZ_NQ * FZ_CSTRIDE);	/* survivors per sub-queue */
-	unsigned long long *d_evals = carve<unsigned long long>(p, 2);	/* distance evaluations, pairs compared */
+	/* (what comes back, in one piece: term ids | counters | evaluation counts; the sub-queue counters behind
+	 * them are zeroed with the same memset) */
+	uint8_t *d_dn = carve<uint8_t>(p, dn_bytes + FZ_NQ * FZ_CSTRIDE * 4);
+	uint32_t *d_tids = (uint32_t *)d_dn;
+	uint32_t *d_cnt = (uint32_t *)(d_dn + (((size_t)n_tok * 4 + 15) & ~(size_t)15));	/* -, matches, overflow, (seed's count) */
+	unsigned long long *d_evals = (unsigned long long *)(d_cnt + 4);	/* distance evaluations, pairs compared */
+	uint32_t *d_qcnt = (uint32_t *)(d_evals + 2);		/* survivors per sub-queue */
 	uint64_t *d_peq = carve<uint64_t>(p, (size_t)n_tok * 256);
 	uint2 *d_tokf = carve<uint2>(p, (size_t)n_tok + 4);
 	uint32_t *d_best = carve<uint32_t>(p, n_tok);
-	uint32_t *d_tids = carve<uint32_t>(p, n_tok);
-	uint8_t *d_bytes = carve<uint8_t>(p, blen + 16);
-	uint32_t *d_up = carve<uint32_t>(p, up.size());
+	/* (what goes up, in one piece: the offset / rank / length words, then the bytes) */
+	uint8_t *d_upb = carve<uint8_t>(p, up_bytes + blen + 16);
+	uint32_t *d_up = (uint32_t *)d_upb;
+	uint8_t *d_bytes = d_upb + up_bytes;
 	uint32_t *d_off = d_up, *d_rank = d_up + n_tok + 1, *d_len_off = d_rank + n_tok;
 	hipStream_t st = ix->stream_fz;
 	fz_args_t fa;
@@ -729,11 +751,9 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 			rank[i] = next[roff[i + 1] - roff[i]]++;
 		}
 	}
-	if (hipMemcpyAsync(d_bytes, tok_bytes + tok_off[0], blen, hipMemcpyHostToDevice, st) != hipSuccess ||
-	    hipMemcpyAsync(d_up, up.data(), up.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-	    hipMemsetAsync(d_cnt, 0, 16, st) != hipSuccess ||
-	    hipMemsetAsync(d_qcnt, 0, FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
-	    hipMemsetAsync(d_evals, 0, 16, st) != hipSuccess ||
+	memcpy(ix->fz_pin + up_bytes, tok_bytes + tok_off[0], blen);
+	if (hipMemcpyAsync(d_upb, ix->fz_pin, up_bytes + blen, hipMemcpyHostToDevice, st) != hipSuccess ||
+	    hipMemsetAsync(d_cnt, 0, 16 + 16 + FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
 	    hipMemsetAsync(d_tokf + n_tok, 0xff, 4 * sizeof(uint2), st) != hipSuccess) {
 		set_error("fuzzy upload failed");
 		return -1;
@@ -770,14 +790,15 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 		set_error("fuzzy kernel launch failed");
 		return -1;
 	}
-	if (hipMemcpyAsync(term_ids, d_tids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-	    hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	if (hipMemcpyAsync(h_dn, d_dn, dn_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
 	    (ix->profiling && hipMemcpyAsync(h_qcnt.data(), d_qcnt, h_qcnt.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-	    hipMemcpyAsync(h_evals, d_evals, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
 	    hipStreamSynchronize(st) != hipSuccess) {
 		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
 		return -1;
 	}
+	const uint32_t *const h_cnt = (const uint32_t *)(h_dn + (((size_t)n_tok * 4 + 15) & ~(size_t)15));
+	const unsigned long long *const h_evals = (const unsigned long long *)(h_cnt + 4);
+	memcpy(term_ids, h_dn, (size_t)n_tok * 4);
 	if (ix->profiling) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);

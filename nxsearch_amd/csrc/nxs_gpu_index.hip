@@ -632,6 +632,9 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->h_pin) {
 		(void)hipHostFree(ix->h_pin);
 	}
+	if (ix->fz_pin) {
+		(void)hipHostFree(ix->fz_pin);
+	}
 	for (int i = 0; i < 4; i++) {
 		if (ix->ev[i]) {
 			(void)hipEventDestroy(ix->ev[i]);

@@ -309,6 +309,8 @@ struct nxsgpu_index {
 	/* fuzzy workspaces */
 	void *		fz;
 	size_t		fz_len;
+	uint8_t *	fz_pin;		/* pinned staging of the match-first pass: one copy up, one down */
+	size_t		fz_pin_len;
 
 	bool		profiling;
 	hipEvent_t	ev[4];

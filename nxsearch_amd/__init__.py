@@ -668,14 +668,14 @@ def compile_query(q, words, lowercase=False):
     return code, err.value.decode(), bool(empty.value), plan
 
 
-def filter_token(s, basedir=None, stopwords=False):
+def filter_token(s, basedir=None, stopwords=False, stemmer=False):
     """The query-token filter pipeline on one string -> (action, result):
     action 1 keep, 0 discarded (stop word), -1 error."""
     L = lib()
     L.nxs_test_filter.restype = C.c_void_p
     L.nxs_test_filter.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     act = C.c_int()
-    r = L.nxs_test_filter(os.fsencode(basedir) if basedir else None, 1 if stopwords else 0,
+    r = L.nxs_test_filter(os.fsencode(basedir) if basedir else None, (1 if stopwords else 0) | (2 if stemmer else 0),
                           _b(s), C.byref(act))
     return act.value, _take(r)
 

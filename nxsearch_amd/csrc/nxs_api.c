@@ -3383,14 +3383,19 @@ nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint3
 	return failed;
 }
 
-/* the "normalizer" stage (+ optional stop words from `basedir`) on one string:
+/* the "normalizer" stage (+ stop words from `basedir`: bit 0 of `stages`, + the
+ * English stemmer: bit 1) on one string:
  * -> malloc'd result, NULL if discarded or on error (*act tells which) */
 char *
-nxs_test_filter(const char *basedir, int stopwords, const char *s, int *act)
+nxs_test_filter(const char *basedir, int stages, const char *s, int *act)
 {
-	static const char *const names[] = { "normalizer", "stopwords" };
+	const char *names[3] = { "normalizer" };
+	size_t n = 1;
 	const char *err = NULL;
-	nxs_filters_t *f = nxs_filters_create(basedir, names, stopwords ? 2 : 1, "en", &err);
+	nxs_filters_t *f;
+	if (stages & 1) names[n++] = "stopwords";
+	if (stages & 2) names[n++] = "stemmer";
+	f = nxs_filters_create(basedir, names, n, "en", &err);
 	char *val = strdup(s);
 	size_t len = strlen(s);
 

@@ -15,9 +15,11 @@
  *               {basedir}/filters/stopwords/{lang} are DISCARDED (only "en" is
  *               ever loaded, :89); a discarded token leaves its leaf without a
  *               token => the empty set (search.c:140)
- *   stemmer     filters_builtin.c:203-245: Snowball (libstemmer) -- not in this
- *               image: an index that lists it cannot be opened here (loud
- *               failure instead of silently unstemmed lookups)
+ *   stemmer     filters_builtin.c:203-245: sb_stemmer_stem() of the index's
+ *               "lang" (default "en", nxs.c:271-276).  libstemmer is not in this
+ *               image: English is the hand-written Porter2 of nxs_stem_en.c; an
+ *               index of another language cannot be opened here (loud failure
+ *               instead of silently unstemmed lookups)
  *
  * ICU is the same library the reference links (src/Makefile:86).  Pure-ASCII
  * tokens -- every token of the synthetic corpora -- take a fast path that is
@@ -39,7 +41,7 @@
 
 #define	NORM_BUF_MULTI	3	/* utf8.c:33 */
 
-enum { F_NORMALIZER = 1, F_STOPWORDS = 2 };
+enum { F_NORMALIZER = 1, F_STOPWORDS = 2, F_STEMMER = 3 };
 
 struct nxs_filters {
 	unsigned		stage[4];
@@ -169,10 +171,16 @@ nxs_filters_create(const char *basedir, const char *const *names, size_t n,
 			if (f->n_stages < 4) f->stage[f->n_stages++] = F_STOPWORDS;
 			sw_load(f, basedir, lang ? lang : "en");
 		} else if (strcmp(names[i], "stemmer") == 0) {
-			*err = "the index uses the `stemmer' filter, which this build cannot "
-			    "apply to query tokens (libstemmer is not available)";
-			nxs_filters_destroy(f);
-			return NULL;
+			/* sb_stemmer_new(lang, NULL): libstemmer's names of the English stemmer */
+			const char *l = lang ? lang : "en";
+			if (strcmp(l, "en") != 0 && strcmp(l, "eng") != 0 && strcmp(l, "english") != 0) {
+				*err = "the index uses the `stemmer' filter for a language other than "
+				    "English, which this build cannot apply to query tokens "
+				    "(libstemmer is not available; only \"en\" is built in)";
+				nxs_filters_destroy(f);
+				return NULL;
+			}
+			if (f->n_stages < 4) f->stage[f->n_stages++] = F_STEMMER;
 		} else {
 			*err = "the index uses a filter this build does not provide";
 			nxs_filters_destroy(f);
@@ -313,6 +321,10 @@ nxs_filters_run(nxs_filters_t *f, char **val, size_t *len)
 			if (sw_has(f, *val, *len)) {
 				return 0;
 			}
+		} else if (f->stage[s] == F_STEMMER) {
+			/* stemmer_filter: filters_builtin.c:219-238 (in place: never longer) */
+			*len = nxs_stem_en(*val, *len);
+			(*val)[*len] = '\0';
 		}
 	}
 	return 1;

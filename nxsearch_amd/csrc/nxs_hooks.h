@@ -34,7 +34,7 @@ int		nxs_test_compile(const char *query, const char *const *words, uint32_t n_wo
 int		nxs_test_compile_wide(const char *query, const char *const *words, uint32_t n_words,
 		    int *wide, uint32_t *n_tokens, uint32_t *term_ids, uint32_t cap_t,
 		    uint32_t *prog_len, uint16_t *prog, uint32_t cap_p);
-char *		nxs_test_filter(const char *basedir, int stopwords, const char *s, int *act);
+char *		nxs_test_filter(const char *basedir, int stages, const char *s, int *act);
 int		nxs_test_bk_image(const char *const *words, uint32_t n_words, nxs_bkimage_t *out);
 int		nxs_test_levdist(const uint8_t *a, size_t n, const uint8_t *b, size_t m);
 /* query sharding without a second GPU: one emulated rank, record blocks, the fix-up protocol */

@@ -191,6 +191,8 @@ nxs_filters_t *nxs_filters_create(const char *basedir, const char *const *names,
 	    const char *lang, const char **err);
 void	nxs_filters_destroy(nxs_filters_t *);
 int	nxs_filters_run(nxs_filters_t *, char **val, size_t *len);
+/* the English Snowball stemmer (Porter2) on a UTF-8 token, in place -> new length (nxs_stem_en.c) */
+size_t	nxs_stem_en(char *w, size_t len);
 
 /* ---- query ----------------------------------------------------------- */
 

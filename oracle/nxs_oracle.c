@@ -751,6 +751,7 @@ struct orc_index {
 	uint64_t	dt_count;
 
 	bool		lowercase;	/* "normalizer" stand-in: ASCII only */
+	bool		stemmer;	/* the `stemmer' filter, lang "en" */
 	uint64_t	last_pairs;
 };
 
@@ -1019,6 +1020,7 @@ orc_index_load(const char *terms_path, const char *dtmap_path,
 	smap_init(&idx->term_map);
 	idx->term_bkt.distfunc = idxterm_levdist;
 	idx->lowercase = false;
+	idx->stemmer = false;
 
 	if ((idx->tmap = map_file(terms_path, &idx->tmap_len)) == NULL) {
 		snprintf(err, errlen, "could not open terms index");
@@ -1069,6 +1071,12 @@ void
 orc_index_set_lowercase(orc_index_t *idx, bool on)
 {
 	idx->lowercase = on;
+}
+
+void
+orc_index_set_stemmer(orc_index_t *idx, bool on)
+{
+	idx->stemmer = on;
 }
 
 static oterm_t *
@@ -1794,13 +1802,20 @@ orc_search(orc_index_t *idx, const char *query, int algo, uint64_t limit,
 			/* tokenize_value: tokenizer.c:205-227; filter pipeline
 			 * reduced to the ASCII part of the normalizer */
 			size_t len = strlen(expr->value);
-			char *val = strdup(expr->value);
+			char *val = malloc(len + 2);
+			memcpy(val, expr->value, len + 1);
 			if (idx->lowercase) {
 				for (size_t i = 0; i < len; i++) {
 					if (val[i] >= 'A' && val[i] <= 'Z') {
 						val[i] += 'a' - 'A';
 					}
 				}
+			}
+			if (idx->stemmer) {	/* stemmer_filter: filters_builtin.c:219-238 */
+				char *st = malloc(len + 2);
+				len = orc_stem_en(val, len, st, len + 2);
+				free(val);
+				val = st;
 			}
 			expr->token = tokenset_add(&tokens, val, len);
 			free(val);

@@ -94,6 +94,10 @@ orc_index_t *orc_index_load(const char *terms_path, const char *dtmap_path,
 void	orc_index_free(orc_index_t *);
 /* ASCII lower-casing of query tokens (stand-in for the "normalizer" filter) */
 void	orc_index_set_lowercase(orc_index_t *, bool);
+/* the `stemmer' filter (filters_builtin.c:203-245) on query tokens, lang "en": orc_stem_en.c */
+void	orc_index_set_stemmer(orc_index_t *, bool);
+/* sb_stemmer_stem() of libstemmer's English stemmer, restated (orc_stem_en.c); `out` holds len + 2 bytes */
+size_t	orc_stem_en(const char *in, size_t len, char *out, size_t cap);
 
 uint32_t orc_index_term_count(const orc_index_t *);
 uint64_t orc_index_dt_count(const orc_index_t *);	/* live docs loaded */

@@ -90,7 +90,7 @@ def build_images(docs, removed=()):
             term_ids)
 
 
-def write_index(basedir, name, docs, removed=(), algo="BM25", filters=()):
+def write_index(basedir, name, docs, removed=(), algo="BM25", filters=(), lang="en"):
     """Create {basedir}/data/{name}/{nxsterms,nxsdtmap,params.db}
     (layout: reference src/core/nxs.c:282-288,421-446)."""
     d = os.path.join(basedir, "data", name)
@@ -102,7 +102,7 @@ def write_index(basedir, name, docs, removed=(), algo="BM25", filters=()):
         f.write(dimg)
     flt = ",".join('"%s"' % x for x in filters)
     with open(os.path.join(d, "params.db"), "w") as f:
-        f.write('{"algo":"%s","lang":"en","filters":[%s]}' % (algo, flt))
+        f.write('{"algo":"%s","lang":"%s","filters":[%s]}' % (algo, lang, flt))
     return (os.path.join(d, "nxsterms"), os.path.join(d, "nxsdtmap"), term_ids)
 
 

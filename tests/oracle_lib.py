@@ -63,6 +63,9 @@ def lib():
     L.orc_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.orc_index_free.argtypes = [C.c_void_p]
     L.orc_index_set_lowercase.argtypes = [C.c_void_p, C.c_bool]
+    L.orc_index_set_stemmer.argtypes = [C.c_void_p, C.c_bool]
+    L.orc_stem_en.restype = C.c_size_t
+    L.orc_stem_en.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     for name, rt in (("orc_index_term_count", C.c_uint32),
                      ("orc_index_dt_count", C.c_uint64),
                      ("orc_index_doc_count", C.c_uint32),
@@ -169,13 +172,14 @@ class SearchError(Exception):
 class Index:
     """Oracle-side index over an nxsterms/nxsdtmap file pair."""
 
-    def __init__(self, terms_path, dtmap_path, lowercase=False):
+    def __init__(self, terms_path, dtmap_path, lowercase=False, stemmer=False):
         err = C.create_string_buffer(256)
         self.h = lib().orc_index_load(os.fsencode(terms_path),
                                       os.fsencode(dtmap_path), err, 256)
         if not self.h:
             raise RuntimeError(err.value.decode())
         lib().orc_index_set_lowercase(self.h, lowercase)
+        lib().orc_index_set_stemmer(self.h, stemmer)
 
     @property
     def term_count(self):

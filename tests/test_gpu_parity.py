@@ -91,6 +91,33 @@ def test_reference_scoring_vectors(golden, nxs, tmp_path):
         gidx.close()
 
 
+def test_default_filters_raw_text_scoring(golden, tmp_path):
+    """N2 / boundary (b): an index as the reference creates it by DEFAULT -- params.db lists
+    normalizer, stopwords, stemmer, lang "en" (nxs.c:87-89,263-276) -- opens by name, and
+    t_scoring.c:16-163 runs with the reference's RAW texts: the documents are indexed as their stemmed
+    token streams (the oracle's stemmer stands in for the indexer), the raw QUERY goes through the
+    product's filter pipeline (`cats` -> `cat`, `Foxes` -> `fox`).  Scores to the reference's 1e-4,
+    and bit-identical to the oracle with its own stemmer."""
+    from test_oracle_golden import stem_docs
+    g = golden["scoring_raw"]
+    base = tmp_path / "b"
+    with N.Nxs(str(base)) as n2:
+        for n, c in enumerate(g["cases"]):
+            items = [(int(k), v.split()) for k, v in stem_docs(c["docs"]).items()]
+            t, d, _ = nxsfmt.write_index(str(base), "raw%d" % n, items,
+                                         filters=["normalizer", "stopwords", "stemmer"])
+            gidx = n2.open_index("raw%d" % n)
+            oidx = O.Index(t, d, lowercase=True, stemmer=True)
+            for q in (c["query"], c["query"].upper(), c["query"].replace("fox", "Foxes").replace("dog", "dogs")):
+                for algo, name in ((0, "TF-IDF"), (1, "BM25")):
+                    res = gidx.search(q, algo=name)
+                    assert {dd for dd, _ in res} == {int(k) for k in c["scores"]}, q
+                    for dd, sc in res:
+                        assert abs(sc - c["scores"][str(dd)][algo]) < g["tolerance"]
+                    assert_same(res, oidx.search(q, algo=algo), q)
+            gidx.close()
+
+
 def test_reference_querylogic_vectors(golden, nxs, tmp_path):
     g = golden["querylogic"]
     gidx, oidx, _ = open_pair(nxs, tmp_path, g["docs"], lowercase=True)

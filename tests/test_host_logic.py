@@ -200,7 +200,7 @@ def test_query_token_filters(golden, tmp_path):
     """N2: the normalizer stage (ICU NFKC_Casefold + the diacritics transform of
     src/utils/utf8.c:30-31) on the reference's own known answers
     (src/tests/t_utf8.c:85-150), stop words (filters_builtin.c:88-199), and the
-    loud refusal of the stemmer."""
+    English stemmer, and the loud refusal of a stemmer for another language."""
     for src, want in golden["utf8"]["normalize"]:
         assert N.filter_token(src) == (1, want)
     # the filter runs utf8_normalize THEN utf8_subs_diacritics (filters_builtin.c:56-76):
@@ -216,12 +216,73 @@ def test_query_token_filters(golden, tmp_path):
     assert N.filter_token("The", basedir=str(tmp_path), stopwords=True) == (0, None)
     assert N.filter_token("Then", basedir=str(tmp_path), stopwords=True) == (1, "then")
     assert N.filter_token("the", basedir=str(tmp_path), stopwords=False) == (1, "the")
-    # an index whose params.db lists the stemmer cannot be served here: say so
-    nxsfmt.write_index(str(tmp_path), "stemmed", [(1, ["cat"])], filters=["normalizer", "stopwords", "stemmer"])
+    # the stemmer stage runs after the normalizer (nxs.c:87-89: normalizer, stopwords, stemmer)
+    assert N.filter_token("Foxes", stemmer=True) == (1, "fox")
+    assert N.filter_token("JUMPED", stemmer=True) == (1, "jump")
+    assert N.filter_token("Ⅷ", stemmer=True) == (1, "viii")
+    # a stemmer for another language cannot be provided here (libstemmer absent): say so at open.
+    # (lang "en" -- the default-created index -- passes this stage; without a GPU the open then
+    # stops at the device, the GPU tier opens one: test_default_filters_raw_text_scoring)
+    nxsfmt.write_index(str(tmp_path), "stemmed_de", [(1, ["cat"])], filters=["normalizer", "stopwords", "stemmer"],
+                       lang="de")
+    nxsfmt.write_index(str(tmp_path), "stemmed_en", [(1, ["cat"])], filters=["normalizer", "stopwords", "stemmer"])
     with N.Nxs(str(tmp_path)) as nxs:
         with pytest.raises(N.NxsError) as e:
-            nxs.open_index("stemmed")
-        assert e.value.code == 3 and "stemmer" in e.value.msg
+            nxs.open_index("stemmed_de")
+        assert e.value.code == 3 and "stemmer" in e.value.msg and "English" in e.value.msg
+        if N.lib().nxsgpu_device_count() <= 0:
+            with pytest.raises(N.NxsError) as e:
+                nxs.open_index("stemmed_en")
+            assert "stemmer" not in e.value.msg
+
+
+def test_english_stemmer_product_vs_oracle(golden):
+    """N2: the product's Porter2 (csrc/nxs_stem_en.c) and the oracle's (oracle/orc_stem_en.c) are two
+    constructions of the published algorithm: both give the published sample vocabulary and the
+    description's worked examples, the stems the reference's own tests imply (t_scoring.c: the
+    pre-stemmed token streams of golden `scoring` are the raw texts of `scoring_raw` stemmed), and
+    agree on 60k generated words (suffix chains, the special prefixes, apostrophes, non-ASCII)."""
+    import json
+    import random
+    import oracle_lib as O
+
+    def orc(w):
+        b = w.encode()
+        out = C.create_string_buffer(len(b) + 2)
+        n = O.lib().orc_stem_en(b, len(b), out, len(b) + 2)
+        return out.raw[:n].decode()
+
+    def prod(w):
+        act, r = N.filter_token(w, stemmer=True)
+        assert act == 1
+        return r
+
+    pub = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "porter2_published.json")))
+    for w, want in pub["sample"] + pub["rules"]:
+        assert (orc(w), prod(w)) == (want, want), w
+    for raw, st in zip(golden["scoring_raw"]["cases"], golden["scoring"]["cases"]):
+        for k, text in raw["docs"].items():
+            assert [orc(t.lower()) for t in text.split()] == st["docs"][k].split()
+            assert [prod(t) for t in text.split()] == st["docs"][k].split()
+    rng = random.Random(7)
+    sufs = ["", "s", "es", "ed", "ing", "ly", "edly", "ingly", "eed", "eedly", "ies", "ied", "sses", "'s", "'s'", "'",
+            "ational", "tional", "enci", "anci", "abli", "entli", "izer", "ization", "ation", "ator", "alism", "aliti",
+            "alli", "fulness", "ousli", "ousness", "iveness", "iviti", "biliti", "bli", "ogi", "logi", "fulli", "lessli",
+            "li", "alize", "icate", "iciti", "ical", "ful", "ness", "ative", "al", "ance", "ence", "er", "ic", "able",
+            "ible", "ant", "ement", "ment", "ent", "ism", "ate", "iti", "ous", "ive", "ize", "ion", "sion", "tion", "e",
+            "l", "ll", "y", "ey", "ay", "us", "ss", "at", "bl", "iz", "bb", "tt", "д", "яy", "y's", "дe", "яs", "дies"]
+    letters = "aeiouybcdfghklmnprstvwxzдя"
+    heads = ["gener", "commun", "arsen", "y", "'", "д", "sk", "succ", "proc", "exc", "inn", "out", "cann", "herr", "earr"]
+    n = 0
+    while n < 60000:
+        w = "".join(rng.choice(letters) for _ in range(rng.randint(0, 6)))
+        if rng.random() < 0.1:
+            w = rng.choice(heads) + w
+        w += rng.choice(sufs) + (rng.choice(sufs) if rng.random() < 0.3 else "")
+        if not w:
+            continue
+        n += 1
+        assert prod(w) == orc(N.filter_token(w)[1]), w
 
 
 def _eval_wide(prog, present):

@@ -99,6 +99,37 @@ def test_scoring_known_answers(golden, tmp_path):
         idx.close()
 
 
+def stem_docs(docs):
+    """What the reference's indexer makes of a raw text with its default filters
+    (normalizer, stopwords -- no stop-word file in the tests' basedir --, stemmer) on
+    these ASCII, punctuation-free texts: split, lower-case, stem (the ORACLE's stemmer)."""
+    import ctypes as C
+    out = {}
+    for k, text in docs.items():
+        toks = []
+        for w in text.lower().split():
+            b = w.encode()
+            buf = C.create_string_buffer(len(b) + 2)
+            n = O.lib().orc_stem_en(b, len(b), buf, len(b) + 2)
+            toks.append(buf.raw[:n].decode())
+        out[k] = " ".join(toks)
+    return out
+
+
+def test_scoring_known_answers_from_raw_text(golden, tmp_path):
+    """t_scoring.c:16-163 with the reference's RAW documents and queries (`foxes` must meet `fox`,
+    the query `cats` the term `cat`): the oracle's stemmer on both sides."""
+    g = golden["scoring_raw"]
+    for n, c in enumerate(g["cases"]):
+        idx, _ = make_index(tmp_path / str(n), stem_docs(c["docs"]), lowercase=True, stemmer=True)
+        for algo in (O.TF_IDF, O.BM25):
+            res = dict(idx.search(c["query"], algo=algo))
+            assert set(res) == {int(k) for k in c["scores"]}, (c["query"], res)
+            for doc, exp in c["scores"].items():
+                assert abs(res[int(doc)] - exp[algo]) < g["tolerance"], (c["query"], doc, algo, res)
+        idx.close()
+
+
 def test_querylogic_known_answers(golden, tmp_path):
     g = golden["querylogic"]
     idx, _ = make_index(tmp_path, g["docs"], lowercase=True)

@@ -64,6 +64,7 @@ struct nxs_pool {
 	 */
 	_Atomic uint64_t next;
 	atomic_size_t	done;		/* items of the current run completed */
+	atomic_flag	busy;		/* a run is under way (pool_run takes one caller at a time) */
 	/*
 	 * gen as the workers may read it without the lock: a worker that has just finished a run
 	 * polls it for POOL_SPIN_NS before it goes to sleep -- a batch's front half is two runs
@@ -203,7 +204,9 @@ pool_run(struct nxs_pool *p, pool_fn_t fn, void *arg, size_t n, size_t chunk)
 {
 	uint64_t gen;
 
-	if (!p || p->n_thr == 0 || n <= chunk || n >= (1ull << POOL_GEN_SHIFT)) {
+	/* (one run at a time: a second caller -- there should be none -- works its items itself) */
+	if (!p || p->n_thr == 0 || n <= chunk || n >= (1ull << POOL_GEN_SHIFT) ||
+	    atomic_flag_test_and_set_explicit(&p->busy, memory_order_acquire)) {
 		if (n) {
 			fn(arg, 0, n);
 		}
@@ -235,6 +238,7 @@ pool_run(struct nxs_pool *p, pool_fn_t fn, void *arg, size_t n, size_t chunk)
 		p->waiting = false;
 		pthread_mutex_unlock(&p->mu);
 	}
+	atomic_flag_clear_explicit(&p->busy, memory_order_release);
 }
 
 #ifdef NXS_TEST_HOOKS	/* (nxs_hooks.h: test hooks and bench accessors are not part of the production ABI) */
@@ -2061,15 +2065,19 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 				plans[n_plans++] = q->plan;
 			}
 		}
-		nxsgpu_index_set_parallel(idx->dev, api_parallel, nxs);
 		if (collective && nxs_index_changed(idx)) {
 			/* a batch is in flight (else resync_before_batch refreshed just now): tell
 			 * the peers, all ranks drain and re-sync together */
 			status[pd->cap] = NXSGPU_BLOCK_CHANGED;
 		}
-		if (nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
+		/* the worker threads are lent for THIS call only (the pool takes one run at a time: the doc-shard
+		 * entry runs a host thread per shard through the same device layer and must never find it set) */
+		nxsgpu_index_set_parallel(idx->dev, api_parallel, nxs);
+		const int brc = nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
 		    (uint32_t)n_plans, slot_of, status, pd->cap,
-		    idx->comm != NULL && pd->world >= 1 && !idx->emu_world) != 0) {
+		    idx->comm != NULL && pd->world >= 1 && !idx->emu_world);
+		nxsgpu_index_set_parallel(idx->dev, NULL, NULL);
+		if (brc != 0) {
 			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
 			    nxsgpu_last_error());
 			if (collective) {

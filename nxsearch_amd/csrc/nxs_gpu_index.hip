@@ -86,6 +86,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.bm_share = u64("NXS_GPU_BM_SHARE", 1024, 1, 1u << 30);
 	c.bm_gain = dbl("NXS_GPU_BM_GAIN", 16.0);
 	c.bigq_em = dbl("NXS_GPU_BIGQ_EM", 16.0);
+	c.use_scans = !on("NXS_GPU_NOSCANS");
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
 #ifdef NXS_EXPERIMENTAL

@@ -12,6 +12,10 @@
  *  nxs_gpu_scan_mask.hip  k_scanm / k_cold: OR-like queries of sparse terms, a
  *                         quantised score bound per doc in LDS, exact sums only
  *                         for the docs that can beat the threshold
+ *  nxs_gpu_scan_stripe.hip k_scans: the same class on doc STRIPES cut out of the lists by the rank
+ *                         directories -- no per-term window state, all terms' postings of a stripe as
+ *                         one flat run of lanes, candidates scored lane-parallel (the default where
+ *                         every term has a directory)
  *  nxs_gpu_scan_bit.hip   k_scanb: the same class on one presence BIT per doc pair (64k-doc tiles),
  *                         candidates scored one per lane by lower-bound searches (the default)
  *  nxs_gpu_scan_grid.hip  k_scang: the mask path over a doc grid (all terms' postings of a
@@ -156,6 +160,8 @@ struct gpu_cfg_t {
 	uint64_t	bm_share;	/* NXS_GPU_BM_SHARE (1024): a term gets a bitmap if it holds >= n_docs / this docs */
 	double		bigq_em;	/* NXS_GPU_BIGQ_EM (16): limits > 64 take k_scanq only for queries that expect fewer matches (it emits them all) */
 	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
+	bool		use_scans;	/* !NXS_GPU_NOSCANS: the mask path on doc stripes cut out of the lists by the rank directories
+					 * (k_scans) for the queries whose terms all have one */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
@@ -499,6 +505,8 @@ void	nxs_launch_scan_generic(int mode, bool wide_mask, unsigned grid, hipStream_
 void	nxs_launch_scan8(int mode, uint32_t nt_bucket, uint32_t mm, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
+/* the mask path on doc stripes (k_scans: rank directories instead of per-term register windows) */
+void	nxs_launch_scans(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the mask path on presence bits, candidates scored one per lane (k_scanb) */
 void	nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the same two on the doc grid (k_scang; scan_args_t::flags bit 2 routes the launchers above here) */

@@ -121,6 +121,17 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 				if (cf.use_scanb && hq[i].nt <= 5 && (double)w <= cf.scanb_dens * (double)ix->n_docs) {
 					cls[i] += 2u * 64;
 				}
+				/* ... on doc stripes (k_scans) when every term has a rank directory: the stripes'
+				 * slices of the lists are table lookups, no per-term window state */
+				if ((cls[i] >> 6) == 4 && cf.use_scans && ix->n_post < (1ull << 32) && ix->d_bmrank) {
+					bool all = true;
+					for (uint32_t t = 0; t < hq[i].nt; t++) {
+						all = all && hq[i].bm_col[t] != 0xffffffffu;
+					}
+					if (all) {
+						cls[i] += 4u * 64;
+					}
+				}
 			} else if (tile && or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
 				/*
@@ -220,21 +231,35 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	 * where their ranges are wavefronts among tens of thousands.
 	 */
 	if (merge_stragglers && use_scanm) {
-		uint32_t n_in[8 * 64] = { 0 };
+		uint32_t n_in[16 * 64] = { 0 };
 		for (uint32_t i = 0; i < nq; i++) {
-			n_in[cls[i] & 511]++;
+			n_in[cls[i] & 1023]++;
 		}
+		/* (the batch's mask-path class of a shape: on doc stripes -- k_scans -- if the query's terms all have
+		 * a rank directory and that class is the populated one, else on register windows) */
+		auto mask_class = [&](uint32_t i, uint32_t shape) -> uint32_t {
+			bool all = cf.use_scans && ix->n_post < (1ull << 32) && ix->d_bmrank;
+			for (uint32_t t = 0; all && t < hq[i].nt; t++) {
+				all = hq[i].bm_col[t] != 0xffffffffu;
+			}
+			return (all && n_in[8u * 64 + shape] >= 32) ? 8u * 64 + shape : 4u * 64 + shape;
+		};
 		for (uint32_t i = 0; i < nq; i++) {
 			const uint32_t c = cls[i];
-			const uint32_t to = 4u * 64 + 16u + (c & 15);
-			if ((c >> 6) == 1 && ((c >> 4) & 3) == 1 && (c & 15) >= 2 && n_in[c] <= 4 && n_in[to] >= 32 &&
+			if ((c >> 6) == 1 && ((c >> 4) & 3) == 1 && (c & 15) >= 2 && n_in[c] <= 4 &&
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
-				cls[i] = to;
+				const uint32_t to = mask_class(i, 16u + (c & 15));
+				if (n_in[to] >= 32) {
+					cls[i] = to;
+				}
 			}
 			/* (the same for a handful of very sparse queries that would take k_scanb: a launch of
 			 * their own only pays with enough of them) */
-			if ((c >> 6) == 6 && n_in[c] < 64 && n_in[c - 2u * 64] >= 32) {
-				cls[i] = c - 2u * 64;
+			if ((c >> 6) == 6 && n_in[c] < 64) {
+				const uint32_t to = mask_class(i, c & 63);
+				if (n_in[to] >= 32) {
+					cls[i] = to;
+				}
 			}
 		}
 	}
@@ -246,7 +271,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
 	/* (the sparse + dense class leads: it runs on a stream of its own, beside the rest) */
-	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 4 ? 64 + (c & 63) : (c >> 6) == 6 ? 128 + (c & 63) : c + 256; };
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 8 ? 64 + (c & 63) : (c >> 6) == 4 ? 128 + (c & 63) : (c >> 6) == 6 ? 192 + (c & 63) : c + 256; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
 		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
@@ -531,7 +556,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		a.flags |= (l.kind == 5 && ix->cfg.drop_b && l.nt_bucket <= 5 && !(a.flags & 4)) ? 8u : 0u;
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
-		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6);
+		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6 || l.kind == 8);
 		a.retry_count = retry ? a0.retry_count + li : NULL;
 		a.retry_items = retry ? a0.retry_items + li * RETRY_CAP : NULL;
 		a.retry_cap = retry ? RETRY_CAP : 0;
@@ -595,9 +620,11 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, l.nt_bucket == 1 ? 0u : l.nomask, grid, ix->stream, a);
 			}
-		} else if (l.kind == 4 || l.kind == 6) {
+		} else if (l.kind == 4 || l.kind == 6 || l.kind == 8) {
 			if (topk64) {
-				if (l.kind == 6) {
+				if (l.kind == 8) {
+					nxs_launch_scans(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);
+				} else if (l.kind == 6) {
 					nxs_launch_scanb(l.nt_bucket, l.nomask != 1, false, grid, ix->stream, a);
 				} else {
 					nxs_launch_scanm(l.nt_bucket, l.nomask != 1, grid, ix->stream, a);

@@ -521,6 +521,13 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANB": "1"},
+                                 # the byte map on doc stripes (k_scans: the default where every term has a rank directory)
+                                 # for every density / with many short ranges / off (k_scanm's register windows) / with
+                                 # directories for every term
+                                 {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1"},
+                                 {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_NOSCANS": "1"}, {"NXS_GPU_NOSCANS": "1", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1"},
+                                 {"NXS_GPU_BM_SHARE": "1073741824", "NXS_GPU_NOSCANB": "1"},
                                  # single-token classes: every query's top range in a launch of its own
                                  {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"},
                                  # conjunctions through the block-presence bitmaps (k_scanq): whenever the required
@@ -560,7 +567,9 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
 @pytest.mark.parametrize("env", [{}, {"NXS_GPU_WAVES": "16"}, {"NXS_GPU_NOSCANR2": "1"}, {"NXS_GPU_NOSCANR": "1"},
                                  {"NXS_GPU_NOSCANM": "1"}, {"NXS_GPU_SCANM_DENS": "1.0"},
                                  {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0"},
-                                 {"NXS_GPU_NOSCANB": "1"},
+                                 {"NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_NOSCANS": "1"},
+                                 {"NXS_GPU_NOSCANS": "1", "NXS_GPU_NOSCANB": "1"},
+                                 {"NXS_GPU_NOSCANB": "1", "NXS_GPU_BM_SHARE": "1073741824"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
                                  {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
@@ -594,9 +603,10 @@ def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
 ])
 def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, vocab_n, max_len):
     """The mask path -- k_scanb (a presence bit per four docs, the windows' docs staged
-    in LDS, candidates scored by lower-bound searches there; 2..5 tokens) and
-    k_scanm (quantised score bounds in a byte per doc + exact scores from the
-    register windows) -- forced for every pure-OR query of 2..8 tokens, whatever
+    in LDS, candidates scored by lower-bound searches there; 2..5 tokens), k_scans (quantised
+    score bounds in a byte per doc over doc stripes cut out of the lists by the rank directories)
+    and k_scanm (the same bytes + exact scores from per-term register windows) -- forced for
+    every pure-OR query of 2..8 tokens, whatever
     the density of its terms: identical ids, order and score bits.  (One corpus, one
     oracle; the index is opened once per kernel: the switches are read at open.)"""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
@@ -615,9 +625,12 @@ def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, voc
         queries.append(" OR ".join(rng.sample(vocab[:max(hi, n)], n)))
     queries += [" ".join(vocab[:4]), "%s OR %s OR %s" % (vocab[-1], vocab[-2], vocab[0])]
     want = {}
-    for kern in ("scanb", "scanm"):
-        if kern == "scanm":
+    monkeypatch.setenv("NXS_GPU_BM_SHARE", "1073741824")     # a rank directory for every term
+    for kern in ("scanb", "scans", "scanm"):
+        if kern != "scanb":
             monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
+        if kern == "scanm":
+            monkeypatch.setenv("NXS_GPU_NOSCANS", "1")
         gidx = nxs.open_files(t, d)
         for limit in (1, 3, 10, 64):
             for algo, name in ((1, "BM25"), (0, "TF-IDF")):
@@ -630,15 +643,18 @@ def test_mask_path_pure_or_queries(nxs, tmp_path, monkeypatch, seed, n_docs, voc
         gidx.close()
 
 
-@pytest.mark.parametrize("kern", ["scanb", "scanm"])
+@pytest.mark.parametrize("kern", ["scanb", "scans", "scanm"])
 def test_mask_path_pending_overflow_falls_back(nxs, tmp_path, monkeypatch, kern):
     """The highest docs all hold every query term: the cold-start tile pushes
     more docs than the pending list takes, the query is flagged and re-run on
     the exact two-pass path."""
     monkeypatch.setenv("NXS_GPU_SCANM_DENS", "1.0")
     monkeypatch.setenv("NXS_GPU_SCANB_DENS", "1.0")
-    if kern == "scanm":
+    monkeypatch.setenv("NXS_GPU_BM_SHARE", "1073741824")
+    if kern != "scanb":
         monkeypatch.setenv("NXS_GPU_NOSCANB", "1")
+    if kern == "scanm":
+        monkeypatch.setenv("NXS_GPU_NOSCANS", "1")
     rng = random.Random(5)
     vocab = ["w%d" % i for i in range(50)]
     docs = random_corpus(rng, 4000, vocab, max_len=6)

@@ -52,6 +52,7 @@ sets = {
   "U": ("2 dense (1..27) + 3 sparse OR", [" OR ".join(T(r) for r in rng.sample(range(1, 28), 2) + rng.sample(range(100, 1001), 3)) for _ in range(a.batch)]),
   "V": ("1 dense (15..27) + 4 sparse OR", [" OR ".join(T(r) for r in [rng.randint(15, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(a.batch)]),
   "W": ("1 dense (1..27) + 4 sparse (500..1000) OR", [" OR ".join(T(r) for r in [rng.randint(1, 27)] + rng.sample(range(500, 1001), 4)) for _ in range(a.batch)]),
+  "X": ("5-term OR rank 28..1000 (C3 plain class)", [" OR ".join(T(r) for r in rng.sample(range(28, 1001), 5)) for _ in range(a.batch)]),
   "J": ("2-term AND rank 1..50 (dense)", [" AND ".join(T(r) for r in rng.sample(range(1, 51), 2)) for _ in range(a.batch)]),
 }
 for name in a.sets.split(","):

@@ -575,8 +575,10 @@ def class_kernels(key, mode):
         return ["k_scanm<%d, %s, false>" % (b3, tf(shape != 1))] if mode == 0 else ["k_scan8<%d, %d, %d>" % (mode, b, 1 if shape == 1 else 0)]
     if kind == 5:
         return ["k_cold<%d, false>" % b3, "k_scanm<%d, false, true>" % b3] if mode == 0 else ["k_scan8<%d, %d, 1>" % (mode, b)]
+    if kind == 9:
+        return ["k_cold<%d, false>" % b3, "k_scans<%d, false, true>" % b3] if mode == 0 else ["k_scan8<%d, %d, 1>" % (mode, b)]
     if kind == 8:
-        return ["k_scans<%d, %s>" % (b3, tf(shape != 1))] if mode == 0 else ["k_scan8<%d, %d, %d>" % (mode, b, 1 if shape == 1 else 0)]
+        return ["k_scans<%d, %s, false>" % (b3, tf(shape != 1))] if mode == 0 else ["k_scan8<%d, %d, %d>" % (mode, b, 1 if shape == 1 else 0)]
     if kind == 6:
         return ["k_scanb<%d, %s, false>" % (b3 if b3 != 8 else 5, tf(shape != 1))]
     if kind == 7:

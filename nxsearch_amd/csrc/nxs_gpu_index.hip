@@ -87,6 +87,7 @@ cfg_from_env(gpu_cfg_t &c)
 	c.bm_gain = dbl("NXS_GPU_BM_GAIN", 16.0);
 	c.bigq_em = dbl("NXS_GPU_BIGQ_EM", 16.0);
 	c.use_scans = !on("NXS_GPU_NOSCANS");
+	c.use_scans_drop = on("NXS_GPU_SCANS_DROP");
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
 #ifdef NXS_EXPERIMENTAL

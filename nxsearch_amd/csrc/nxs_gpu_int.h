@@ -162,6 +162,9 @@ struct gpu_cfg_t {
 	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
 	bool		use_scans;	/* !NXS_GPU_NOSCANS: the mask path on doc stripes cut out of the lists by the rank directories
 					 * (k_scans) for the queries whose terms all have one */
+	bool		use_scans_drop;	/* NXS_GPU_SCANS_DROP: ... also as the sparse + dense class's second kernel (k_scans<.., DROP>): opt-in --
+					 * level with k_scanm<.., DROP> on big batches, 1.6x slower where the class's few thousand
+					 * wavefronts all start cold at once (a C3 batch: NOTES.md) */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
 	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
@@ -372,7 +375,8 @@ struct scan_args_t {
 						 * best score, j = 0..5 (bigk_publish / bigk_hint) */
 	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class);
 						 * bit 1 (k_scan8): the work items are the retry list's;
-						 * bit 2: the mask path walks the doc grid (k_scang) */
+						 * bit 2: the mask path walks the doc grid (k_scang);
+						 * bit 4: the sparse + dense class's second kernel is k_scans<.., DROP> */
 	/*
 	 * Ranges whose pending list overflowed on the mask path (k_scanm: a burst of docs
 	 * above a still-weak threshold -- it depends on when higher ranges publish theirs,
@@ -507,6 +511,9 @@ void	nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t s
 void	nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the mask path on doc stripes (k_scans: rank directories instead of per-term register windows) */
 void	nxs_launch_scans(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t st, const scan_args_t &a);
+/* ... the sparse + dense class's second kernel on stripes (k_scans<.., DROP>; scan_args_t::flags bit 4 makes
+ * nxs_launch_drop_class launch it behind k_cold) */
+void	nxs_launch_scans_drop(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the mask path on presence bits, candidates scored one per lane (k_scanb) */
 void	nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the same two on the doc grid (k_scang; scan_args_t::flags bit 2 routes the launchers above here) */

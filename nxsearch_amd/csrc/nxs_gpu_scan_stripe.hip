@@ -50,23 +50,17 @@
 #ifndef ST_FLUSH
 #define	ST_FLUSH	48		/* score the pending docs of finished stripes once this many wait */
 #endif
-#ifndef ST_CH
-#define	ST_CH		4		/* posting windows in flight while a stripe is walked in sub-ranges (cold start) */
-#endif
 #ifndef ST_RING
 #define	ST_RING		6		/* posting windows in flight once stripes are taken whole (across stripe ends) */
 #endif
 #ifndef ST_UNR
-#define	ST_UNR		4		/* scoring rounds whose searches run side by side */
+#define	ST_UNR		3		/* scoring rounds whose searches run side by side */
 #endif
 #ifndef ST_ADV_SCALAR
 #define	ST_ADV_SCALAR	0		/* the window's lists by scalar tests (else: a compare / select per term and lane) */
 #endif
-#ifndef ST_REDO
-#define	ST_REDO		1		/* a sub-range that overfills the pending list is walked again, narrower */
-#endif
-#ifndef ST_PROC_FAST
-#define	ST_PROC_FAST	0		/* full windows without lane masks */
+#ifndef ST_GO
+#define	ST_GO		96		/* cold start ends when a whole stripe is expected to push at most this many docs */
 #endif
 #define	ST_W0		64		/* cold-start sub-range */
 #ifndef ST_W_HINTED
@@ -94,10 +88,21 @@ nxsgpu_debug_stats_stripe(unsigned long long *out, int reset)
 #define	SSTAT_CLK()	0ull
 #endif
 
-template <int NT, bool GEN>
+/*
+ * DROP (the sparse + dense class, see k_scanm<.., DROP> / k_cold in nxs_gpu_scan_mask.hip): the dense
+ * terms are not streamed; k_cold has walked the range's top until the threshold passed what they can add
+ * together (U) and hands over threshold, top-k scores, output count and the sparse terms' cursors.  Here
+ * the stripes hold the SPARSE terms' postings only, a doc is pushed if its byte bound plus the quantised
+ * U can beat the threshold, and in the flush a dropped term's lane takes the candidate's impact from the
+ * term's column (one load, no search) -- the gathers of the dense impacts are batched across stripes with
+ * everything else (k_scanm<.., DROP>: one dependent gather per tile, 19-23 per wavefront).  Queries whose
+ * dropped terms have outlier lists (TF-IDF) stay on k_scanm<.., DROP>: those lists have no directory.
+ */
+template <int NT, bool GEN, bool DROP = false>
 __global__ void __launch_bounds__(WAVE)
 k_scans(const scan_args_t A)
 {
+	static_assert(!(GEN && DROP), "the sparse + dense class is pure OR");
 	static_assert(ST_WORDS == 1 || ST_WORDS == 2 || ST_WORDS == 4, "stripe width");
 	constexpr int NTP = NT <= 2 ? 2 : NT <= 3 ? 3 : NT <= 4 ? 4 : NT <= 5 ? 5 : 8;	/* lanes per candidate in the flush */
 	constexpr int CPR = WAVE / NTP;				/* candidates per scoring round */
@@ -107,6 +112,7 @@ k_scans(const scan_args_t A)
 	constexpr int R = ST_RING, UNR = ST_UNR;
 	__shared__ __attribute__((aligned(16))) uint32_t s_map[ST_DOCS / 4];
 	__shared__ uint32_t s_pend[ST_PEND];
+	__shared__ uint8_t s_psum[DROP ? ST_PEND : 4];		/* DROP: the byte bound a doc was pushed with */
 	__shared__ uint32_t s_truth[GEN ? 8 : 1];
 
 	const unsigned lane = threadIdx.x;
@@ -131,6 +137,13 @@ k_scans(const scan_args_t A)
 		return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 	};
 
+	/* DROP: what the range's cold phase (k_cold) left: docs below cs_left, for the sparse terms only */
+	const uint32_t dmask = DROP ? rfl32(Q->drop_mask) : 0u;
+	const uint32_t *cs = A.cold_state + seg * 16;
+	const uint32_t cs_left = DROP ? rfl32(cs[0]) : 0u;		/* 0: range used up */
+	const uint32_t cs_nout = DROP ? rfl32(cs[1]) : 0u;
+	const float cs_thr = DROP ? __uint_as_float(rfl32(cs[2])) : 0.0f;
+	const uint32_t cs_ovf = DROP ? rfl32(cs[3]) : 0u;
 	/* per term (wave-uniform): list start as a posting index, the range's slice [lo, hi) of the list */
 	uint32_t pb[NT], lo[NT], hi[NT], e[NT];
 	float tsum = 0.0f;
@@ -143,23 +156,50 @@ k_scans(const scan_args_t A)
 			lo[t] = rfl32(A.cursors[cb]);
 			hi[t] = rfl32(A.cursors[cb + NXSGPU_MAX_TOKENS]);
 			tsum += Q->tmax[t];
+			if (DROP) {
+				if (((dmask >> t) & 1) || cs_left == 0) {
+					hi[t] = lo[t];		/* no postings as far as the stripes are concerned */
+				} else {
+					hi[t] = max(min(hi[t], rfl32(cs[4 + t])), lo[t]);
+				}
+			}
 		}
 		e[t] = hi[t];
 	});
 	/* the lanes' roles: directory fetch -- term lane / G, stripe lane % G of the group;
 	 * flush -- term lane % NTP of candidate lane / NTP */
 	const uint32_t ft = lane / G, fj = lane % G;
-	const uint32_t f_row = (ft < nt && ft < (uint32_t)NT) ? Q->bm_col[ft] * (uint32_t)(A.bm_words + 1) : 0u;
+	const uint32_t f_row = (ft < nt && ft < (uint32_t)NT && !(DROP && ((dmask >> ft) & 1))) ?
+	    Q->bm_col[ft] * (uint32_t)(A.bm_words + 1) : 0u;
 	const uint32_t mc = lane / NTP, mt = lane % NTP;	/* (lanes >= CPR * NTP idle in the flush) */
 	const bool m_on = mt < nt && mt < (uint32_t)NT && mc < (uint32_t)CPR;
-	const uint32_t m_row = m_on ? Q->bm_col[mt] * (uint32_t)(A.bm_words + 1) : 0u;
+	const bool m_drop = DROP && m_on && ((dmask >> mt) & 1);	/* my term's impacts come from its column */
+	const uint32_t m_row = (m_on && !m_drop) ? Q->bm_col[mt] * (uint32_t)(A.bm_words + 1) : 0u;
 	const uint32_t m_pb = m_on ? (uint32_t)Q->pbeg[mt] : 0u;
+	const uint64_t m_col = m_drop ? (uint64_t)Q->drop_col[mt] * A.dense_stride : 0ull;
 
 	const uint32_t d_bot = (uint32_t)min((uint64_t)g * qm.group_docs, A.n_docs);
-	const uint32_t d_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
+	const uint32_t d_top = DROP ? cs_left : (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs :
 	    (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
 	const int32_t w_bot = (int32_t)(d_bot >> SH);
 	const int32_t w_top = d_top > d_bot ? (int32_t)((d_top - 1) >> SH) : w_bot - 1;
+#if defined(NXS_STATS) || defined(NXS_CHECK_HANDOVER)
+	{	/* (diagnostic build: the hand-over from k_cold must describe a part of this range) */
+		const uint32_t r_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs : (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
+		bool bad = d_top > r_top || (d_top && d_top < d_bot);
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			bad = bad || hi[t] < lo[t];
+		});
+		if (bad) {
+			if (lane == 0) {
+				printf("k_scans<%d,%d>: bad hand-over q %u g %u: d_bot %u d_top %u r_top %u cs %u %u %u %u\n", NT, (int)DROP, q, g,
+				    d_bot, d_top, r_top, cs[0], cs[1], cs[2], cs[3]);
+			}
+			return;
+		}
+	}
+#endif
 
 	/* the stripes' lower boundaries in every list: G stripes x NT terms per load */
 	auto fetch_dir = [&](int32_t wg) -> uint32_t {
@@ -172,20 +212,39 @@ k_scans(const scan_args_t A)
 	};
 
 	float hint = range_hint(A, qm, g);		/* 0 = nothing published yet */
-	float top = -INFINITY;
-	float thr = hint;				/* scores are > 0: 0 passes everything */
+	float top = DROP ? A.cold_top[seg * 64 + lane] : -INFINITY;
+	float thr = DROP ? fmaxf(hint, cs_thr) : hint;	/* scores are > 0: 0 passes everything */
 	const uint32_t kidx = A.k - 1;			/* 1 <= k <= 64 (host) */
-	uint32_t n_out = 0, n_pend = 0, ovf = 0;
+	uint32_t n_out = cs_nout, n_pend = 0, ovf = cs_ovf, flood = 0;
 	const uint64_t out_base = seg * A.seg_cap;
 
 	/* Quantisation: as k_scanm's (q(x) = floor(x * qs) + 2, a doc's byte <= QSUM_MAX + 2 NT <= 240;
 	 * a doc can only beat thr if its byte exceeds floor(thr * qs) - 1) */
 	const float qs = tsum > 0.0f ? (float)QSUM_MAX / tsum : 0.0f;
+	/* DROP: what the dense tokens can add to a score in byte-map units (part of every doc's bound from
+	 * the start: the threshold the bytes are compared with is lowered by it), and the largest share of one
+	 * sparse posting */
+	uint32_t qU = 0, q1max = 0;
+	if constexpr (DROP) {
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			if (t < (int)nt) {
+				if ((dmask >> t) & 1) {
+					qU += (uint32_t)(Q->tcap[t] * qs) + 2;
+				} else {
+					q1max = max(q1max, (uint32_t)(Q->tmax[t] * qs) + 2);
+				}
+			}
+		});
+		qU = rfl32(qU);
+		q1max = rfl32(q1max);
+	}
 	auto thr_quant = [&](float th) -> int32_t {
-		return __builtin_amdgcn_readfirstlane(th > 0.0f ? (int32_t)min(th * qs, 1.0e6f) - 1 : -1);
+		return __builtin_amdgcn_readfirstlane(th > 0.0f ? (int32_t)min(th * qs, 1.0e6f) - 1 : -1) - (int32_t)qU;
 	};
 	int32_t thr_q = thr_quant(thr);
-	uint32_t tw = thr_q >= 0 ? (uint32_t)ST_W_HINTED : (uint32_t)ST_W0;
+	/* (DROP: mature once a single sparse posting no longer passes on its own) */
+	uint32_t tw = (DROP ? thr_q >= (int32_t)q1max : thr_q >= 0) ? (uint32_t)ST_W_HINTED : (uint32_t)ST_W0;
 
 	/*
 	 * Flush of the first `np` pending docs (all of them lie above every doc that is still to come):
@@ -207,17 +266,21 @@ k_scans(const scan_args_t A)
 		SSTAT_ADD(4, 1);
 		SSTAT_ADD(5, np);
 		const uint32_t nch = (np + WAVE - 1) / WAVE;
-		/* what was pushed after the np: to the front afterwards (few: one or two stripes' worth) */
+		/* what was pushed after the np -- the stripes in progress -- goes to the front afterwards */
 		const uint32_t rest = np + lane < n_pend ? s_pend[np + lane] : 0;
-		if (n_pend - np > WAVE) {
-			ovf = 1;
+		const uint32_t rest2 = np + WAVE + lane < n_pend ? s_pend[np + WAVE + lane] : 0;
+		const uint32_t rsum = (DROP && np + lane < n_pend) ? s_psum[np + lane] : 0;
+		const uint32_t rsum2 = (DROP && np + WAVE + lane < n_pend) ? s_psum[np + WAVE + lane] : 0;
+		if (n_pend - np > 2 * WAVE) {
+			flood = 1;		/* (the caller starts the stripes in progress again, in sub-ranges) */
 			SSTAT_ADD(14, 1);
 		}
-		uint32_t pd[PC], rk[PC];
+		uint32_t pd[PC], rk[PC], ps[PC];
 #pragma unroll
 		for (int c = 0; c < PC; c++) {
 			const uint32_t ei = c * WAVE + lane;
 			pd[c] = ei < np ? s_pend[ei] : 0;
+			ps[c] = (DROP && ei < np) ? s_psum[ei] : 0;
 			rk[c] = 0;
 		}
 		WAVE_SYNC();
@@ -243,6 +306,9 @@ k_scans(const scan_args_t A)
 			const uint32_t ei = c * WAVE + lane;
 			if (ei < np) {
 				s_pend[rk[c]] = pd[c];
+				if (DROP) {
+					s_psum[rk[c]] = (uint8_t)ps[c];
+				}
 			}
 		}
 		WAVE_SYNC();
@@ -254,10 +320,40 @@ k_scans(const scan_args_t A)
 			const uint32_t d = valid ? s_pend[ei] : 0;
 			const uint32_t before = (uint32_t)__shfl_up((int)d, 1);
 			const bool dup = valid && (lane ? before == d : prev_last == d);
-			const uint64_t m = ballot64(valid && !dup);
+			bool keep = valid && !dup;
+			if constexpr (DROP) {
+				/*
+				 * The docs were pushed on the CEILING of the dense terms (qU); with their real
+				 * dense impacts -- one load per doc and dropped term, all lanes at once -- the
+				 * bound is redone and only what can still beat the threshold is scored.  A doc
+				 * is pushed once per posting that found it above the threshold (adjacent after
+				 * the sort, at most one per term): its complete byte bound is the LARGEST of them.
+				 */
+				uint32_t sumq = keep ? s_psum[ei] : 0u;
+#pragma unroll
+				for (int kk = 1; kk < NT; kk++) {
+					if (keep && ei + kk < np && s_pend[ei + kk] == d) {
+						sumq = max(sumq, (uint32_t)s_psum[ei + kk]);
+					}
+				}
+				uint32_t qd = 0;
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					if ((dmask >> t) & 1) {
+						const uint64_t cbase = (uint64_t)rfl32(Q->drop_col[t]) * A.dense_stride;
+						const uint32_t xb = A.dense_col[cbase + (keep ? d : 0u)];
+						if (xb != 0xffffffffu) {
+							qd += (uint32_t)(__uint_as_float(xb) * qs) + 2;
+						}
+					}
+				});
+				keep = keep && (int32_t)(sumq + qd) > thr_q + (int32_t)qU;
+				SSTAT_ADD(14, __popcll(ballot64(keep)));
+			}
+			const uint64_t m = ballot64(keep);
 			prev_last = (uint32_t)__builtin_amdgcn_readlane((int)d, 63);
 			WAVE_SYNC();
-			if (valid && !dup) {
+			if (keep) {
 				s_pend[nu + lanes_below(m)] = d;
 			}
 			nu += (uint32_t)__popcll(m);
@@ -267,7 +363,8 @@ k_scans(const scan_args_t A)
 		SSTAT_ADD(6, nu);
 
 		for (uint32_t c0 = 0; c0 < nu; c0 += CPR * UNR) {
-			uint32_t doc[UNR], sl[UNR], sh_[UNR], se[UNR];
+			uint32_t doc[UNR], sl[UNR], sh_[UNR], hdoc[UNR];
+			float himp[UNR];
 			bool inr[UNR];
 			SSTAT_ADD(7, 1);
 #pragma unroll
@@ -278,10 +375,31 @@ k_scans(const scan_args_t A)
 				/* (lanes without a term or a candidate search an empty run of list 0) */
 				const uint64_t ri = (uint64_t)m_row + (doc[u] >> 12);
 				const uint32_t a = A.bmrank[ri], b = A.bmrank[ri + 1];
-				const bool act = inr[u] && m_on;
+				const bool act = inr[u] && m_on && !m_drop;
 				sl[u] = act ? a : 0u;
-				sh_[u] = se[u] = act ? b : 0u;
+				sh_[u] = act ? b : 0u;
+				hdoc[u] = 0xffffffffu;		/* the posting at sh_, once a probe has put sh_ there */
+				himp[u] = 0.0f;
+				if constexpr (DROP) {
+					/* a dense term that left the scan: its impact for this doc from the term's column
+					 * (lanes of other terms read a valid word of column 0) */
+#ifdef NXS_DBG_CLAMP
+					const uint32_t xb = A.dense_col[m_col + min(doc[u], (uint32_t)A.n_docs - 1)];
+#else
+					const uint32_t xb = A.dense_col[m_col + doc[u]];
+#endif
+					if (m_drop && inr[u] && xb != 0xffffffffu) {
+						hdoc[u] = doc[u];
+						himp[u] = __uint_as_float(xb);
+					}
+				}
 			}
+			/*
+			 * Lower bound of the doc in [sl, sh_), four-ary: three probes per step, all rounds' probes
+			 * in flight together -- a run of 330 postings (a term holding 8 % of the docs) takes 5
+			 * dependent steps instead of 9, and the posting the bound lands on has been fetched by the
+			 * probe that moved sh_ there (no load after the search).
+			 */
 			for (;;) {
 				bool more = false;
 #pragma unroll
@@ -292,32 +410,40 @@ k_scans(const scan_args_t A)
 					break;
 				}
 				SSTAT_ADD(8, 1);
-				uint32_t v[UNR], mid[UNR];
+				posting_t pr[UNR][3];
+				uint32_t qp[UNR][3];
 #pragma unroll
-				for (int u = 0; u < UNR; u++) {	/* (unconditional, clamped: the probes of all rounds in flight together) */
-					mid[u] = sl[u] + ((sh_[u] - sl[u]) >> 1);
-					v[u] = A.post[(uint64_t)(m_pb + mid[u])].doc;
+				for (int u = 0; u < UNR; u++) {	/* (unconditional: a finished lane probes sl == sh_, a valid address) */
+					const uint32_t len = sh_[u] - sl[u];
+					qp[u][0] = sl[u] + (len >> 2);
+					qp[u][1] = sl[u] + (len >> 1);
+					qp[u][2] = sl[u] + (len >> 1) + (len >> 2);
+#pragma unroll
+					for (int k = 0; k < 3; k++) {
+						pr[u][k] = A.post[(uint64_t)(m_pb + qp[u][k])];
+					}
 				}
 #pragma unroll
 				for (int u = 0; u < UNR; u++) {
 					if (sl[u] < sh_[u]) {
-						if (v[u] < doc[u]) {
-							sl[u] = mid[u] + 1;
+						if (pr[u][0].doc >= doc[u]) {
+							sh_[u] = qp[u][0]; hdoc[u] = pr[u][0].doc; himp[u] = pr[u][0].imp;
+						} else if (pr[u][1].doc >= doc[u]) {
+							sl[u] = qp[u][0] + 1;
+							sh_[u] = qp[u][1]; hdoc[u] = pr[u][1].doc; himp[u] = pr[u][1].imp;
+						} else if (pr[u][2].doc >= doc[u]) {
+							sl[u] = qp[u][1] + 1;
+							sh_[u] = qp[u][2]; hdoc[u] = pr[u][2].doc; himp[u] = pr[u][2].imp;
 						} else {
-							sh_[u] = mid[u];
+							sl[u] = qp[u][2] + 1;
 						}
 					}
 				}
 			}
-			posting_t fp[UNR];
 #pragma unroll
 			for (int u = 0; u < UNR; u++) {
-				fp[u] = A.post[(uint64_t)(m_pb + sl[u])];
-			}
-#pragma unroll
-			for (int u = 0; u < UNR; u++) {
-				const bool hit = sl[u] < se[u] && fp[u].doc == doc[u];
-				const float x = hit ? fp[u].imp : 0.0f;
+				const bool hit = hdoc[u] == doc[u];
+				const float x = hit ? himp[u] : 0.0f;
 				/* the candidate's tokens, token order, from 0.0f (an absent token adds +0.0f: the same bits) */
 				const uint32_t gb = mc * NTP;
 				const uint32_t pm = (uint32_t)(ballot64(hit) >> min(gb, 63u)) & ((1u << NTP) - 1);
@@ -366,8 +492,17 @@ k_scans(const scan_args_t A)
 		if (np + lane < n_pend) {
 			s_pend[lane] = rest;
 		}
+		if (np + WAVE + lane < n_pend) {
+			s_pend[WAVE + lane] = rest2;
+		}
+		if (DROP && np + lane < n_pend) {
+			s_psum[lane] = (uint8_t)rsum;
+		}
+		if (DROP && np + WAVE + lane < n_pend) {
+			s_psum[WAVE + lane] = (uint8_t)rsum2;
+		}
 		WAVE_SYNC();
-		n_pend = min(n_pend - np, (uint32_t)WAVE);
+		n_pend = min(n_pend - np, 2u * WAVE);
 		thr_q = thr_quant(thr);
 		SSTAT_ADD(10, SSTAT_CLK() - fclk);
 	};
@@ -378,11 +513,14 @@ k_scans(const scan_args_t A)
 	 * with c[t] <= i and is posting i + dsel[t] of the posting array.
 	 */
 	uint32_t c[NT], dsel[NT], ddel[NT], n_ld = 0, i0_ld = 0;
+	uint32_t ddv[NT];	/* ddel[] once more, in vector registers: the per-window select chain takes them as they are
+				 * (from scalar registers every select needs a copy first: four per window) */
 	int32_t w_ld = w_top + 1, j_ld = -1;
 	uint32_t rkv = fetch_dir(w_top), rk_next = fetch_dir(w_top - G);
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		c[t] = dsel[t] = ddel[t] = 0;
+		ddv[t] = 0;
 	});
 	auto next_stripe = [&]() __attribute__((always_inline)) -> bool {
 		for (;;) {
@@ -408,6 +546,9 @@ k_scans(const scan_args_t A)
 				c[t] = n;
 				dsel[t] = pb[t] + s - n;
 				ddel[t] = t ? dsel[t] - dsel[t ? t - 1 : 0] : 0u;
+				/* (the asm keeps the copy from being folded back into a scalar operand) */
+				ddv[t] = ddel[t];
+				asm volatile("" : "+v"(ddv[t]));
 				n += et - s;
 				e[t] = s;
 			});
@@ -420,24 +561,13 @@ k_scans(const scan_args_t A)
 			}
 		}
 	};
-	/* window [i0, i0 + 64) of the loader's stripe (i0 < n_ld): clamped, unpredicated */
-	auto load_window = [&](uint32_t i0) __attribute__((always_inline)) -> posting_t {
-		const uint32_t ic = min(i0 + lane, n_ld - 1);
-		/* (sums of selected differences: a chain of selects over dsel[] is turned into an indexed
-		 * load from a stack array by the optimiser -- scratch memory) */
-		uint32_t dv = ic + dsel[0];
-		static_for<NT>([&](auto tc) {
-			constexpr int t = decltype(tc)::value;
-			if (t > 0) {
-				dv += ic >= c[t] ? ddel[t] : 0u;
-			}
-		});
-		return A.post[(uint64_t)dv];
-	};
-	auto push = [&](uint64_t cm, uint32_t doc) __attribute__((always_inline)) {
+	auto push = [&](uint64_t cm, uint32_t doc, uint32_t sum) __attribute__((always_inline)) {
 		const uint32_t np = (uint32_t)__popcll(cm);
 		if (n_pend + np <= ST_PEND && lane_of(cm)) {
 			s_pend[n_pend + lanes_below(cm)] = doc;
+			if (DROP) {
+				s_psum[n_pend + lanes_below(cm)] = (uint8_t)sum;
+			}
 		}
 		n_pend += np;
 	};
@@ -450,19 +580,34 @@ k_scans(const scan_args_t A)
 		WAVE_SYNC();
 	};
 
-	/* ---- cold start: stripes in doc sub-ranges, until a sub-range is a whole stripe ---- */
+	/*
+	 * ---- cold start: stripes in doc sub-ranges, until a sub-range is a whole stripe ----
+	 * A sub-range [rlo, rhi) of the stripe is, in every list, the postings right below the ones the
+	 * sub-range above it took: a cursor per term (cur[t], moving down from the stripe's upper end) and
+	 * plain 64-posting windows under it, taken while they still hold docs >= rlo -- the lanes at or
+	 * above rlo are a suffix of the window (docs ascend), their count moves the cursor.  A sub-range
+	 * costs what it holds, whatever the stripe holds (a pass over ALL the stripe's windows with a doc
+	 * filter made a redone sub-range of a dense stripe a millisecond's work: the kernel's tail).
+	 */
+	for (;;) {
 	while (tw < (uint32_t)ST_DOCS && !ovf) {
 		tw = rfl32(tw);
 		ovf = rfl32(ovf);
 		if (!next_stripe()) {
 			break;
 		}
-		const uint32_t n = n_ld;
+		/* the stripe's runs, list-relative: [low[t], cur[t]) */
+		uint32_t low[NT], cur[NT], cur0[NT];
+		static_for<NT>([&](auto tc) {
+			constexpr int t = decltype(tc)::value;
+			low[t] = dsel[t] - pb[t] + c[t];
+			cur[t] = low[t] + ((t + 1 < NT ? c[t + 1 < NT ? t + 1 : t] : n_ld) - c[t]);
+		});
 		uint32_t rhi = ST_DOCS;		/* docs of the stripe still to take: rel < rhi */
 		while (rhi > 0 && !ovf) {
 			rhi = rfl32(rhi);
 			n_pend = rfl32(n_pend);
-			if (ST_REDO && n_pend > ST_PEND - 64 && n_pend) {	/* (room for a sub-range's pushes: a burst is then the sub-range's own) */
+			if (n_pend > ST_PEND - 64 && n_pend) {	/* (room for a sub-range's pushes: a burst is then the sub-range's own) */
 				WAVE_SYNC();
 				flush(n_pend);
 			}
@@ -471,63 +616,84 @@ k_scans(const scan_args_t A)
 			const uint32_t rlo = rhi > tw ? rhi - tw : 0;
 			const uint32_t n_before = n_pend;
 			SSTAT_ADD(2, 1);
-			SSTAT_ADD(3, (n + WAVE - 1) / WAVE);
-			for (uint32_t i0 = 0; i0 < n; i0 += WAVE * ST_CH) {
-				posting_t p[ST_CH];
-#pragma unroll
-				for (int k = 0; k < ST_CH; k++) {
-					p[k].doc = 0;
-					p[k].imp = 0.0f;
-					if (i0 + k * WAVE < n) {	/* wave-uniform */
-						p[k] = load_window(i0 + k * WAVE);
+			/* (every term's first window under its cursor: requested together, one memory latency for all) */
+			posting_t pw[NT];
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				cur[t] = rfl32(cur[t]);
+				cur0[t] = cur[t];
+				pw[t].doc = 0;
+				pw[t].imp = 0.0f;
+				if (cur[t] > low[t]) {
+					const uint32_t wb = cur[t] > low[t] + WAVE ? cur[t] - WAVE : low[t];
+					pw[t] = A.post[(uint64_t)(pb[t] + wb + min(lane, cur[t] - wb - 1))];
+				}
+			});
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				bool first = true;
+				while (cur[t] > low[t]) {
+					const uint32_t wb = cur[t] > low[t] + WAVE ? cur[t] - WAVE : low[t];
+					const uint32_t cw = cur[t] - wb;
+					posting_t p = pw[t];
+					if (!first) {
+						p = A.post[(uint64_t)(pb[t] + wb + min(lane, cw - 1))];
+					}
+					first = false;
+					const uint32_t rel = p.doc & (ST_DOCS - 1);
+					const bool valid = lane < cw && rel >= rlo;
+					const uint32_t shv = (rel & 3) * 8;
+					/* floor + 2 >= the exact ceiling whatever the f32 product rounds to */
+					const uint32_t qq = (uint32_t)(p.imp * qs) + 2;
+					const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], valid ? (qq << shv) : 0u,
+					    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
+					const uint64_t vm = ballot64(valid);
+					const uint64_t cm = ballot64(valid && (int32_t)sum > thr_q);
+					SSTAT_ADD(3, 1);
+					if (cm) {
+						push(cm, p.doc, sum);
+					}
+					const uint32_t nv = (uint32_t)__popcll(vm);
+					cur[t] = rfl32(cur[t] - nv);
+					if (nv < cw) {
+						break;		/* the rest of the window lies below the sub-range */
 					}
 				}
-				uint32_t oldv[ST_CH], qq[ST_CH], shv[ST_CH];
-				bool valid[ST_CH];
-#pragma unroll
-				for (int k = 0; k < ST_CH; k++) {
-					valid[k] = false;
-					if (i0 + k * WAVE < n) {
-						const uint32_t rel = p[k].doc & (ST_DOCS - 1);
-						valid[k] = i0 + k * WAVE + lane < n && rel - rlo < rhi - rlo;
-						shv[k] = (rel & 3) * 8;
-						/* floor + 2 >= the exact ceiling whatever the f32 product rounds to */
-						qq[k] = (uint32_t)(p[k].imp * qs) + 2;
-						oldv[k] = __hip_atomic_fetch_add(&s_map[rel >> 2], valid[k] ? (qq[k] << shv[k]) : 0u,
-						    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					}
-				}
-#pragma unroll
-				for (int k = 0; k < ST_CH; k++) {
-					if (i0 + k * WAVE < n) {
-						const uint32_t sum = ((oldv[k] >> shv[k]) & 0xffu) + qq[k];
-						const uint64_t cm = ballot64(valid[k] && (int32_t)sum > thr_q);
-						if (cm) {
-							push(cm, p[k].doc);
-						}
-					}
-				}
-			}
-			if (ST_REDO && n_pend > ST_PEND && tw > (uint32_t)ST_W0) {
+			});
+			if (n_pend > ST_PEND && tw > (uint32_t)ST_W0) {
 				/* a burst (the threshold is still weak for a sub-range this wide): the sub-range once
 				 * more, a quarter as wide -- what it pushed is dropped, its bytes are wiped (the
 				 * sub-ranges above it are done: their bytes are not needed any more) */
 				n_pend = n_before;
 				tw = max(tw / 4, (uint32_t)ST_W0);
+				static_for<NT>([&](auto tc) {
+					constexpr int t = decltype(tc)::value;
+					cur[t] = cur0[t];
+				});
 				wipe();
 				SSTAT_ADD(13, 1 << 16);
 				continue;
 			}
+			const uint32_t n_tile = n_pend - n_before, width = rhi - rlo;
 			rhi = rlo;
-			const uint32_t n_tile = n_pend - n_before;
-			if (n_tile <= 8) {
+			/*
+			 * Whole stripes as soon as they look affordable: a threshold exists and, at this
+			 * sub-range's rate, a stripe would push at most ST_GO docs.  (k_scanm's rule alone --
+			 * double while a sub-range pushes <= 8 -- keeps a dense query whose sub-ranges push a
+			 * dozen each in narrow sub-ranges for its whole range: one window per memory latency,
+			 * a millisecond for 40 000 postings -- the kernel's tail.)
+			 */
+			if (thr_q >= (DROP ? (int32_t)q1max : 0) && n_tile * ((uint32_t)ST_DOCS / max(width, 1u)) <= (uint32_t)ST_GO) {
+				tw = ST_DOCS;
+			} else if (n_tile <= 8) {
 				tw = min(tw * 2, (uint32_t)ST_DOCS);
 			} else if (n_tile > 48) {
 				tw = max(tw / 2, (uint32_t)ST_W0);
 			}
 			if (n_pend > ST_PEND) {
 				ovf = 1;
-			} else if (n_pend >= 24 || (n_pend && thr_q < 0)) {
+			} else if (n_pend >= 24 || (n_pend && thr_q < (DROP ? (int32_t)q1max : 0))) {
 				WAVE_SYNC();
 				flush(n_pend);
 			}
@@ -548,8 +714,9 @@ k_scans(const scan_args_t A)
 	 */
 	{
 		uint32_t cnt[R], last[R];
+		const int32_t w_ld0 = (int32_t)rfl32((uint32_t)w_ld);	/* every stripe down to this one is done */
 		/* the next window of the stream: its address, how many of its lanes count (0: nothing left),
-		 * whether it ends its stripe */
+		 * whether it ends its stripe (then: the stripe's number + 1) */
 		auto advance = [&](const posting_t *&pa, uint32_t &pc, uint32_t &pl) __attribute__((always_inline)) {
 			i0_ld = rfl32(i0_ld);
 			n_ld = rfl32(n_ld);
@@ -567,7 +734,7 @@ k_scans(const scan_args_t A)
 			 */
 			const uint32_t i0 = i0_ld, iend = min(i0 + WAVE, n_ld);
 #if ST_ADV_SCALAR
-			uint32_t base = dsel[0];	/* (sums of differences, not selects over dsel[]: see load_window) */
+			uint32_t base = dsel[0];	/* (sums of differences: a chain of selects over dsel[] is turned into an indexed load from a stack array -- scratch) */
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
 				if (t > 0) {
@@ -589,13 +756,13 @@ k_scans(const scan_args_t A)
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
 				if (t > 0) {
-					dv += ic >= c[t] ? ddel[t] : 0u;
+					dv += ic >= c[t] ? ddv[t] : 0u;
 				}
 			});
 #endif
 			pa = A.post + dv;
 			pc = iend - i0;
-			pl = iend >= n_ld ? 1u : 0u;
+			pl = iend >= n_ld ? (uint32_t)w_ld + 1 : 0u;	/* (the window ends stripe w_ld) */
 			i0_ld = i0 + WAVE;
 			SSTAT_ADD(3, 1);
 		};
@@ -610,6 +777,7 @@ k_scans(const scan_args_t A)
 			bpair_request<s>(pa);
 		});
 		uint32_t mark = n_pend;		/* pending docs of finished stripes */
+		int32_t w_mark = w_ld0;		/* ... the last of which was this one */
 		uint32_t rounds = 0;
 		for (;;) {
 			n_pend = rfl32(n_pend);
@@ -639,36 +807,37 @@ k_scans(const scan_args_t A)
 					const uint32_t rel = pdoc & (ST_DOCS - 1);
 					const uint32_t shv = (rel & 3) * 8;
 					const uint32_t qq = (uint32_t)(pimp * qs) + 2;
-					uint64_t cm;
-					if (ST_PROC_FAST && cnt[s] == WAVE) {		/* a full window: no lane masks */
-						const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], qq << shv,
-						    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-						const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
-						cm = ballot64((int32_t)sum > thr_q);
-					} else {
-						const bool valid = lane < cnt[s];	/* (not a mask built by 1 << cnt: cnt may be 64) */
-						const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], valid ? (qq << shv) : 0u,
-						    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-						const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
-						cm = ballot64(valid && (int32_t)sum > thr_q);
-					}
+					const bool valid = lane < cnt[s];	/* (not a mask built by 1 << cnt: cnt may be 64) */
+					const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], valid ? (qq << shv) : 0u,
+					    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
+					const uint64_t cm = ballot64(valid && (int32_t)sum > thr_q);
 					if (cm) {
-						push(cm, pdoc);
+						push(cm, pdoc, sum);
 					}
 					if (last[s]) {
 						wipe();
-						mark = min(n_pend, (uint32_t)ST_PEND);
+						/* (a stripe whose pushes did not all fit is not finished: the flood check
+						 * below sends the loader back to it -- its docs are not on the list) */
+						if (n_pend <= (uint32_t)ST_PEND) {
+							mark = n_pend;
+							w_mark = (int32_t)last[s] - 1;
+						}
 					}
 				}
 				cnt[s] = ncnt;
 				last[s] = nlast;
 			});
 			if (n_pend > ST_PEND) {
-				ovf = 1;
+				flood = 1;
 			} else if (mark >= ST_FLUSH) {
 				WAVE_SYNC();
 				flush(mark);
 				mark = 0;
+			}
+			flood = rfl32(flood);
+			if (flood) {
+				break;
 			}
 			if ((++rounds & 7) == 0) {
 				/* a higher range may have published since */
@@ -679,6 +848,44 @@ k_scans(const scan_args_t A)
 				}
 			}
 		}
+#ifdef NXS_DBG_NORESTART
+		if (flood) {
+			ovf = 1;
+			flood = 0;
+		}
+#endif
+		if (!flood) {
+			break;
+		}
+		/*
+		 * More docs pushed than the pending list takes (a weak hint, a threshold that is still
+		 * immature): the stripes in progress -- everything below stripe w_mark, the last one whose docs
+		 * are all on the list or scored -- start again in doc sub-ranges.  What they pushed is dropped,
+		 * the loader goes back to the stripe below w_mark (its upper ends from the directory), the
+		 * windows still in flight are simply requested over.
+		 */
+		SSTAT_ADD(13, 1);
+		flood = 0;
+		n_pend = min(n_pend, mark);
+		{
+			uint32_t v = 0;
+			if (ft < (uint32_t)NT && fj == 0 && w_mark <= w_top) {
+				v = A.bmrank[(uint64_t)f_row + (uint64_t)w_mark * ST_WORDS];
+			}
+			static_for<NT>([&](auto tc) {
+				constexpr int t = decltype(tc)::value;
+				const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)v, t * G);
+				e[t] = w_mark > w_top ? hi[t] : min(max(raw, lo[t]), hi[t]);
+			});
+		}
+		w_ld = w_mark;
+		j_ld = -1;
+		rkv = fetch_dir(w_mark - 1);
+		rk_next = fetch_dir(w_mark - 1 - G);
+		n_ld = i0_ld = 0;
+		tw = ST_DOCS / 4;
+		wipe();
+	}
 	}
 	if (n_pend && !ovf) {
 		WAVE_SYNC();
@@ -704,6 +911,20 @@ k_scans(const scan_args_t A)
 				A.overflow[q] = 1;
 			}
 		}
+	}
+}
+
+/* the sparse + dense OR class on stripes: its cold phase (k_cold, nxs_gpu_scan_mask.hip) has run on this stream */
+void
+nxs_launch_scans_drop(uint32_t nt_bucket, unsigned grid_, hipStream_t st, const scan_args_t &a)
+{
+	const dim3 grid(grid_), block(WAVE);
+
+	switch (nt_bucket) {
+	case 2:
+	case 3: hipLaunchKernelGGL((k_scans<3, false, true>), grid, block, 0, st, a); break;
+	case 5: hipLaunchKernelGGL((k_scans<5, false, true>), grid, block, 0, st, a); break;
+	default: hipLaunchKernelGGL((k_scans<8, false, true>), grid, block, 0, st, a); break;
 	}
 }
 

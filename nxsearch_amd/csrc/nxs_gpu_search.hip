@@ -171,6 +171,17 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 						total += work[i];
 					}
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
+					/* ... on doc stripes (k_cold + k_scans<.., DROP>) if the sparse terms all have a rank
+					 * directory and no dropped term brings an outlier list (those have none) */
+					if (cf.use_scans && cf.use_scans_drop && ix->n_post < (1ull << 32) && ix->d_bmrank && !hq[i].outl_mask) {
+						bool all = true;
+						for (uint32_t t = 0; t < hq[i].nt; t++) {
+							all = all && (((hq[i].drop_mask >> t) & 1) || hq[i].bm_col[t] != 0xffffffffu);
+						}
+						if (all) {
+							cls[i] = 9u * 64 + 16u + nt_bucket(hq[i].nt);
+						}
+					}
 				}
 			}
 			/* required terms: intersect first (k_scanr).  Its work is set by
@@ -271,7 +282,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	 * runs beside the NEXT class's scan, and the last class (required-term
 	 * queries: few candidates, short replay) is the one left exposed */
 	/* (the sparse + dense class leads: it runs on a stream of its own, beside the rest) */
-	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 5 ? (c & 63) : (c >> 6) == 8 ? 64 + (c & 63) : (c >> 6) == 4 ? 128 + (c & 63) : (c >> 6) == 6 ? 192 + (c & 63) : c + 256; };
+	auto cls_key = [&](uint32_t c) -> uint32_t { return (c >> 6) == 9 ? (c & 63) : (c >> 6) == 5 ? 32 + (c & 63) : (c >> 6) == 8 ? 64 + (c & 63) : (c >> 6) == 4 ? 128 + (c & 63) : (c >> 6) == 6 ? 192 + (c & 63) : c + 256; };
 	std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
 		if (cls[x] != cls[y]) return cls_key(cls[x]) < cls_key(cls[y]);
 		return work[x] != work[y] ? work[x] > work[y] : x < y;
@@ -384,7 +395,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 				 * pushes on a weak threshold (8 x the pending docs of the plain class).  The first
 				 * level(s) go ahead in a launch of their own here too.
 				 */
-				if (lev + 1 == cf.drop_split && l.kind == 5 && max_g > cf.drop_split && !big_k && !solo) {
+				if (lev + 1 == cf.drop_split && (l.kind == 5 || l.kind == 9) && max_g > cf.drop_split && !big_k && !solo) {
 					launch_t l0 = l;
 					l0.count = (uint32_t)n_items - l0.first;
 					l0.q_first = o0;
@@ -496,7 +507,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 	const bool early_ok = early_big || (early_stream && early_done && MODE == MODE_TOPK && ra && n_late >= 1 &&
 	    a0.k >= 1 && a0.k <= WAVE);
 	for (const launch_t &l : wl.launches) {
-		if (l.count && !(side3 && l.kind == 5) && !(early_ok && (l.kind == 3 || l.kind == 7))) {
+		if (l.count && !(side3 && (l.kind == 5 || l.kind == 9)) && !(early_ok && (l.kind == 3 || l.kind == 7))) {
 			last_launch = &l;
 		}
 	}
@@ -534,7 +545,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		a.item_base = l.first;
 		/* profiling: events around this class's scan kernels, on the stream they go to */
 		const bool early = early_ok && (l.kind == 3 || l.kind == 7);
-		const hipStream_t cls_stream = (side3 && l.kind == 5) ? ix->stream3 : early ? early_stream : ix->stream;
+		const hipStream_t cls_stream = (side3 && (l.kind == 5 || l.kind == 9)) ? ix->stream3 : early ? early_stream : ix->stream;
 		int pc = -1;
 		if (psl && psl->ev_cls_ok && psl->n_cls < NXSGPU_PROF_CLS && MODE_FILTERS(MODE)) {
 			pc = (int)psl->n_cls++;
@@ -556,7 +567,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 		a.flags |= (l.kind == 5 && ix->cfg.drop_b && l.nt_bucket <= 5 && !(a.flags & 4)) ? 8u : 0u;
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
-		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6 || l.kind == 8);
+		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6 || l.kind == 8 || l.kind == 9);
 		a.retry_count = retry ? a0.retry_count + li : NULL;
 		a.retry_items = retry ? a0.retry_items + li * RETRY_CAP : NULL;
 		a.retry_cap = retry ? RETRY_CAP : 0;
@@ -567,10 +578,13 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			if (retry) {
 				scan_args_t a2 = a;
 				a2.flags |= 2;
-				nxs_launch_scan8(MODE_TOPK, l.nt_bucket, (l.kind == 5 || l.nomask == 1) ? 1u : 0u, RETRY_CAP, st, a2);
+				nxs_launch_scan8(MODE_TOPK, l.nt_bucket, (l.kind == 5 || l.kind == 9 || l.nomask == 1) ? 1u : 0u, RETRY_CAP, st, a2);
 			}
 		};
-		if (side3 && l.kind == 5) {
+		if (l.kind == 9) {
+			a.flags |= 16u;		/* the class's second kernel is k_scans<.., DROP> */
+		}
+		if (side3 && (l.kind == 5 || l.kind == 9)) {
 			replay_args_t r = *ra;
 			r.qlist = d_qorder + l.q_first;
 			if (!forked3) {
@@ -639,7 +653,7 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				nxs_launch_scan8(MODE, l.nt_bucket, l.nomask == 1 ? 1u : 0u, grid, ix->stream, a);
 			}
-		} else if (l.kind == 5) {
+		} else if (l.kind == 5 || l.kind == 9) {
 			/* sparse + dense pure OR: top-k pass with the dense lists dropped */
 			if (topk64 && !ix->cfg.drop_tiles) {
 				nxs_launch_drop_class(l.nt_bucket, grid, ix->stream, a);
@@ -1861,7 +1875,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			n_l += l.count != 0;
 		}
 		for (launch_t &l : wl.launches) {
-			if (l.kind == 5 && l.q_count == 0 && l.count && n_l > 2 &&
+			if ((l.kind == 5 || l.kind == 9) && l.q_count == 0 && l.count && n_l > 2 &&
 			    !(((ix->cfg.use_grid >> 1) & 1) && ix->n_post < (1ull << 32))) {
 				scan_args_t a = sa;
 				a.item_base = l.first;

@@ -528,6 +528,10 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANS": "1"}, {"NXS_GPU_NOSCANS": "1", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1"},
                                  {"NXS_GPU_BM_SHARE": "1073741824", "NXS_GPU_NOSCANB": "1"},
+                                 # ... and as the sparse + dense class's second kernel (k_scans<.., DROP>, opt-in)
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.02"},
                                  # single-token classes: every query's top range in a launch of its own
                                  {"NXS_GPU_SCAN1_SPLIT": "1", "NXS_GPU_WAVES": "4096", "NXS_GPU_MINPOST": "64"},
                                  # conjunctions through the block-presence bitmaps (k_scanq): whenever the required
@@ -571,6 +575,8 @@ def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env)
                                  {"NXS_GPU_NOSCANS": "1", "NXS_GPU_NOSCANB": "1"},
                                  {"NXS_GPU_NOSCANB": "1", "NXS_GPU_BM_SHARE": "1073741824"},
                                  {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_SCANM_DENS": "0.005"},
                                  {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_BM_GAIN": "0", "NXS_GPU_BM_SHARE": "1073741824"}])
 def test_sparse_terms_on_a_larger_corpus(nxs, tmp_path, monkeypatch, env):
     """400k docs: queries whose terms are all sparse (few postings per tile, most
@@ -1289,7 +1295,12 @@ def test_doc_sharded_rank_form_through_rccl(nxs, tmp_path):
                                  # the class's second kernel on presence bits (k_scanb<.., DROP>), outlier lists included
                                  {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1"},
                                  {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},
-                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "2", "NXS_GPU_WAVES": "64"}])
+                                 {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_OUTL_SHARE": "2", "NXS_GPU_WAVES": "64"},
+                                 # ... on doc stripes (k_scans<.., DROP>: BM25; queries with outlier lists stay on k_scanm) / the plain
+                                 # mask class on register windows only
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1"},
+                                 {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "32"},
+                                 {"NXS_GPU_NOSCANS": "1", "NXS_GPU_DROP_MINPOST": "1"}])
 def test_dense_terms_leave_sparse_or_scans(nxs, tmp_path, monkeypatch, env):
     """k_scanm<.., DROP>: pure-OR queries that mix dense terms (8 % of the docs and
     more) with sparse ones.  The dense lists are scanned only until the threshold

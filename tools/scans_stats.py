@@ -29,6 +29,8 @@ sets = {
   "K": [" OR ".join(T(r) for r in rng.sample(range(100, 1001), 5)) for _ in range(batch)],
   "M": [" OR ".join(T(r) for r in rng.sample(range(30, 101), 5)) for _ in range(batch)],
   "X": [" OR ".join(T(r) for r in rng.sample(range(28, 1001), 5)) for _ in range(batch)],
+  "R": [" OR ".join(T(r) for r in [rng.randint(1, 27)] + rng.sample(range(100, 1001), 4)) for _ in range(batch)],
+
 }
 if os.environ.get("STATS_SETS"):
     sets = {k: v for k, v in sets.items() if k in os.environ["STATS_SETS"].split(",")}

@@ -44,7 +44,12 @@ for env in ({}, {"NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_DROP_MINPOST": "1", "NX
             # through the block bitmaps always / never, no classes sent ahead
             {"NXS_GPU_SCANB_DENS": "1.0"}, {"NXS_GPU_SCANB_DENS": "1.0", "NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_WAVES": "256"},
             {"NXS_GPU_DROPB": "1", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_BM_GAIN": "0"}, {"NXS_GPU_NOBLKMAP": "1"},
-            {"NXS_GPU_DROP_SPLIT": "0", "NXS_GPU_AND_NOEARLY": "1"}):
+            {"NXS_GPU_DROP_SPLIT": "0", "NXS_GPU_AND_NOEARLY": "1"},
+            # round 5: the byte map on doc stripes (k_scans) for every density / with short ranges / off / with a rank
+            # directory for every term / also as the sparse + dense class's second kernel
+            {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1"}, {"NXS_GPU_SCANM_DENS": "1.0", "NXS_GPU_NOSCANB": "1", "NXS_GPU_WAVES": "256"},
+            {"NXS_GPU_NOSCANS": "1"}, {"NXS_GPU_BM_SHARE": "1073741824", "NXS_GPU_NOSCANB": "1"},
+            {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1"}, {"NXS_GPU_SCANS_DROP": "1", "NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_WAVES": "256"}):
     if os.environ.get("STRESS_ONLY") and os.environ["STRESS_ONLY"] not in env:
         continue
     for kk, v in env.items():

@@ -36,6 +36,7 @@ Rank 0 prints ONE JSON line.  Extra objects in that line:
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -81,6 +82,9 @@ def parse_args():
                     help="batches in flight in the timed loop (default: 3; 4 for limits above 64, whose "
                          "batches end in milliseconds of heap replay)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the timed loop of --steps steps until this much time has been measured; the line "
+                         "reports the median loop (0: one loop)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--np", type=int, default=0,
@@ -237,6 +241,10 @@ def main():
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
             ok = int(t_ok.item())
         sharded = ok == 1
+        if sharded:
+            # like the reference's worker processes (compose/nginx.conf:2) a rank materialises and walks the
+            # responses of ITS slice only: O(n / world) host work per rank and step
+            idx.shard_local(True)
         if not sharded:
             # Safety net: the communicator could not be built (on some rank).  The ranks still
             # split the batch by query -- each runs ITS slice on its replica -- but nothing is
@@ -270,28 +278,68 @@ def main():
     idx.set_profiling(True)
     idx.profile(reset=True)
     idx.host_profile()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = run(args.steps)
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    own_loops = []
+
+    def timed_loop():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; the MAX over the ranks."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = run(args.steps)
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        own_loops.append(dt)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return r, dt
+
+    # A loop of K steps may last a few dozen milliseconds (the driver's `--steps 20` at C3: 20 ms) -- one host
+    # hiccup moves such a figure by 10 %.  So the loop of EXACTLY K steps is REPEATED until at least
+    # --min-seconds have been timed (every rank takes the same count from the all-reduced first loop), and the
+    # line reports the MEDIAN loop: ms_per_step x steps is what that one loop took, `repeat_ms_per_step`
+    # lists them all.
+    res, first = timed_loop()
+    loops = [first]
+    n_loops = 1 if first <= 0 else max(1, min(400, int(math.ceil(args.min_seconds / first))))
+    n_loops = max(n_loops, 1 + int(os.environ.get("NXS_BENCH_REPEATS", "0")))
+    for _ in range(n_loops - 1):
+        r2, dt = timed_loop()
+        loops.append(dt)
+        res.results += r2.results
+        res.failed += r2.failed
     prof = idx.profile(reset=True)
     host_prof = idx.host_profile()
     idx.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    repeats = []
-    for _ in range(int(os.environ.get("NXS_BENCH_REPEATS", "0"))):     # diagnostics: run-to-run spread
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize()
-        repeats.append(round(1e3 * (time.perf_counter() - t0) / args.steps, 4))
+    elapsed = sorted(loops)[(len(loops) - 1) // 2]          # the median loop (the lower one of an even count)
+    # N > 1: evidence that RCCL saw N ranks -- its own count of the communicator, every rank's own loop
+    # time (the line's figure is their MAX), what the all-gathers carried
+    shard_ev = None
+    if sharded:
+        si = idx.shard_info()
+        mine = 1e3 * sorted(own_loops)[(len(own_loops) - 1) // 2] / args.steps
+        rank_ms = [round(mine, 4)]
+        if dist is not None:
+            tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([mine], dtype=torch.float64, device=dev))
+            rank_ms = [round(float(x.item()), 4) for x in tl]
+        gathers = max(si["allgathers"], 1)
+        hp = [host_prof.get("begin_ms", 0.0) + host_prof.get("end_ms", 0.0)]
+        if dist is not None:
+            tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor(hp, dtype=torch.float64, device=dev))
+            hp = [float(x.item()) for x in tl]
+        shard_ev = {"rccl_ranks": si["rccl_ranks"], "library_world": si["world"], "rank_ms_per_step": rank_ms,
+                    "rank_host_ms_per_step": [round(x, 4) for x in hp], "responses": "own slice per rank (nxs_index_shard_local)",
+                    "allgathers": si["allgathers"],
+                    "allgather_bytes_per_rank": si["bytes_contributed"] // gathers,
+                    "allgather_bytes_received_per_step": si["bytes_contributed"] // gathers * si["world"]}
+    repeats = [round(1e3 * dt / args.steps, 4) for dt in loops]
+    res_results_per_loop = res.results / len(loops)
+    res_failed = res.failed
 
     total_q = n_total * args.steps
     qps = total_q / elapsed
@@ -299,8 +347,8 @@ def main():
 
     # ---- roofline of the dominant kernels (the scan launches) on this rank ----
     launches = max(prof["launches"], 1)
-    my_share = 1.0 / world if (world > 1 and sharded) else 1.0     # records of all ranks are read back
-    matched = res.results / max(args.steps, 1) * my_share
+    my_share = 1.0      # (sharded: a rank walks the responses of its own slice only -- nxs_index_shard_local)
+    matched = res_results_per_loop / max(args.steps, 1) * my_share
     alg_bytes = prof["postings"] * POSTING_BYTES / launches + matched * RESULT_BYTES
     # first scan launch -> every class scanned and replayed (classes overlap: the
     # sparse + dense OR class runs on a stream of its own beside the others)
@@ -374,7 +422,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic", "depth": depth,
         "config": {"workload": "%s: %d docs / %d terms Zipf, %s, batch %d %s" % (
                        args.workload, args.docs, args.terms, what, args.batch,
                        "in all (sharded by query)" if strong else "per GPU"),
@@ -386,12 +434,13 @@ def main():
                                    "record blocks per step" % world) if (world > 1 and sharded) else
                                   ("query-sharded x%d, index replicated, NO collective (the RCCL communicator "
                                    "could not be built: %s)" % (world, shard_err)) if world > 1 else
-                                  "one GPU, no collective"},
+                                  "one GPU, no collective",
+                   **({"sharding": shard_ev} if shard_ev else {})},
         "roofline": roofline,
         "host_ms_per_step": host_prof,
-        **({"repeat_ms_per_step": repeats} if repeats else {}),
-        "results_per_step": int(res.results // max(args.steps, 1)),
-        "failed_queries": int(res.failed),
+        "timed_loops": len(loops), "repeat_ms_per_step": repeats,
+        "results_per_step": int(res_results_per_loop // max(args.steps, 1)),
+        "failed_queries": int(res_failed),
         "setup_s": {"corpus": round(t_gen, 1), "index_load": round(t_load, 1)},
     }
 
@@ -526,12 +575,27 @@ def docshard_bench(args, info, terms, corpus, work, t_gen):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def source_hash():
+    """sha256 over the HIP sources + headers the library is built from (tools/pmc_summary.py stamps its
+    summaries with it)."""
+    import hashlib
+    root = os.path.join(ROOT, "nxsearch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args, world):
     """HBM bytes per step (all scan launches) from the newest committed rocprofv3
     --pmc summary whose workload matches this run (collected by
-    tools/profile_round.sh on the same command), and the file it came from;
-    (None, None) otherwise -- the counters are not collected inside this run."""
+    tools/profile_round.sh on the same command) AND whose kernels are this tree's (the summary's
+    `source_hash`), and the file it came from; (None, reason, {}) otherwise -- the counters are not
+    collected inside this run, and figures of other kernels are not printed as this run's."""
     best = (None, None, {})
+    head = source_hash()
     pdir = os.path.join(ROOT, "profiles")
     try:
         names = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_summary.json"))
@@ -551,6 +615,10 @@ def pmc_traffic(args, world):
                     if "FETCH_SIZE" in ctr:
                         per_k[kname] = int(ctr["FETCH_SIZE"]["sum_per_step"] * 1024 * fac +
                                            ctr.get("WRITE_SIZE", {}).get("sum_per_step", 0.0) * 1024)
+                if p.get("source_hash") != head:
+                    best = (None, "profiles/%s is stale (kernel sources %s, this tree %s): traffic not reported" % (
+                        name, p.get("source_hash", "unstamped"), head), {})
+                    continue
                 best = (int(p["hbm_bytes_per_launch"]), "profiles/" + name, per_k)
         except (OSError, KeyError, ValueError):
             pass

@@ -133,6 +133,15 @@ int		nxs_index_search_batch_end(nxs_index_t *, nxs_resp_t **resps,
 #define	NXS_SHARD_UID_BYTES	128
 int		nxs_shard_unique_id(nxs_t *, uint8_t *uid);
 int		nxs_index_shard(nxs_index_t *, int rank, int world, const uint8_t *uid);
+/*
+ * nxs_index_shard_local(idx, true): like the reference's worker processes, which answer only their own
+ * requests (compose/nginx.conf:2), a rank then materialises the responses of ITS slice only: after _end
+ * resps[i] is NULL and errs[i] untouched for the queries other ranks own, and the return value counts the
+ * own slice's failures -- O(n / world) host work per rank and batch.  nxs_index_shard_slice() tells which
+ * part [*lo, *hi) of an n-query batch that is (the whole batch when the mode is off or nothing is attached).
+ */
+int		nxs_index_shard_local(nxs_index_t *, bool on);
+void		nxs_index_shard_slice(const nxs_index_t *, size_t n, size_t *lo, size_t *hi);
 
 /*
  * Front half of a batch only: parse + resolve (fuzzy misses on the device) +

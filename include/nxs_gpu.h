@@ -314,6 +314,10 @@ nxsgpu_comm_t *	nxsgpu_comm_create(int device, int rank, int world,
 void		nxsgpu_comm_destroy(nxsgpu_comm_t *);
 int		nxsgpu_comm_rank(const nxsgpu_comm_t *);
 int		nxsgpu_comm_world(const nxsgpu_comm_t *);
+/* what RCCL itself reports for the communicator (ncclCommCount; -1: unknown), and how much has gone through
+ * it: out[0] all-gathers queued, out[1] bytes this rank contributed -- evidence for scaling records */
+int		nxsgpu_comm_rccl_count(const nxsgpu_comm_t *);
+void		nxsgpu_comm_stats(const nxsgpu_comm_t *, uint64_t out[2]);
 /* blocking all-gather of host buffers (staged through the device): the rare
  * fix-up round of a sharded batch, barriers */
 int		nxsgpu_comm_allgather(nxsgpu_comm_t *, const void *send, void *recv,

@@ -85,11 +85,12 @@ NXS_H_SYMBOLS = [
     "nxs_index_search_batch", "nxs_index_open_files",
     "nxs_index_plan_batch", "nxs_index_search_batch_begin",
     "nxs_index_search_batch_end", "nxs_shard_unique_id", "nxs_index_shard",
+    "nxs_index_shard_local", "nxs_index_shard_slice",
     "nxs_index_open_shard", "nxs_docshard_search_batch",
     "nxs_docshard_attach", "nxs_docshard_search_batch_rank",
 ]
 # csrc/nxs_hooks.h: test hooks + bench accessors, only in builds with -DNXS_TEST_HOOKS (the default)
-NXS_HOOK_SYMBOLS = ["nxs_index_device", "nxs_index_host_profile", "nxs_test_pool", "nxs_test_assemble",
+NXS_HOOK_SYMBOLS = ["nxs_index_device", "nxs_index_host_profile", "nxs_index_shard_info", "nxs_test_pool", "nxs_test_assemble",
                     "nxs_test_fixup_scan", "nxs_test_inject_failure"]
 NXS_GPU_H_SYMBOLS = [
     "nxsgpu_device_count", "nxsgpu_last_error", "nxsgpu_index_create",
@@ -100,7 +101,7 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_set_profiling", "nxsgpu_get_profile", "nxsgpu_synchronize",
     "nxsgpu_search_wide", "nxsgpu_shard_slice", "nxsgpu_shard_capacity",
     "nxsgpu_comm_unique_id", "nxsgpu_comm_create", "nxsgpu_comm_destroy",
-    "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_allgather",
+    "nxsgpu_comm_rank", "nxsgpu_comm_world", "nxsgpu_comm_rccl_count", "nxsgpu_comm_stats", "nxsgpu_comm_allgather",
     "nxsgpu_index_set_comm", "nxsgpu_batch_begin", "nxsgpu_batch_end",
     "nxsgpu_batches_in_flight", "nxsgpu_index_reconfigure", "nxsgpu_index_set_parallel", "nxsgpu_hbm_read_gbs",
     "nxsgpu_hbm_calibrate",
@@ -538,6 +539,31 @@ class Index:
         """nxs_index_shard(): collective; `uid` from shard_unique_id() of rank 0."""
         if lib().nxs_index_shard(self._h, rank, world, uid) != 0:
             self.nxs._raise()
+
+    def shard_local(self, on=True):
+        """nxs_index_shard_local(): responses of the own slice only (others None)."""
+        L = lib()
+        L.nxs_index_shard_local.argtypes = [C.c_void_p, C.c_bool]
+        if L.nxs_index_shard_local(self._h, on) != 0:
+            self.nxs._raise()
+
+    def shard_slice(self, n):
+        """nxs_index_shard_slice(): the part of an n-query batch whose responses this index delivers."""
+        lo, hi = C.c_size_t(), C.c_size_t()
+        L = lib()
+        L.nxs_index_shard_slice.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.nxs_index_shard_slice(self._h, n, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def shard_info(self):
+        """What the attached communicator is and has carried (bench evidence): RCCL's own rank count
+        (ncclCommCount), the library's world, all-gathers queued, bytes this rank contributed."""
+        out = (C.c_uint64 * 4)()
+        L = lib()
+        L.nxs_index_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.nxs_index_shard_info(self._h, out)
+        return {"rccl_ranks": int(C.c_int64(out[0]).value), "world": int(out[1]), "allgathers": int(out[2]),
+                "bytes_contributed": int(out[3])}
 
     def host_profile(self):
         """nxs_index_host_profile(): per-batch host phase times in ms."""

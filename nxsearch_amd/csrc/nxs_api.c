@@ -1801,6 +1801,18 @@ nxs_index_host_profile(nxs_index_t *idx, double out[8])
 	idx->hp_batches = 0;
 }
 
+void
+nxs_index_shard_info(nxs_index_t *idx, uint64_t out[4])
+{
+	uint64_t st[2] = { 0, 0 };
+
+	out[0] = (uint64_t)(int64_t)(idx->comm ? nxsgpu_comm_rccl_count(idx->comm) : -1);
+	out[1] = idx->comm ? (uint64_t)nxsgpu_comm_world(idx->comm) : 1;
+	nxsgpu_comm_stats(idx->comm, st);
+	out[2] = st[0];
+	out[3] = st[1];
+}
+
 #endif /* NXS_TEST_HOOKS */
 
 /* status word of a record slot: 0, an nxs_err_t, or ... */
@@ -2199,15 +2211,20 @@ exact_pick(const nxsgpu_results_t *res, const nxsgpu_results_t *wres, uint32_t p
 static int
 resps_from_blocks(nxs_t *nxs, const nxs_pend_t *pd, size_t n, uint32_t world, uint32_t n_slots,
     uint32_t k, const uint8_t *blocks, nxs_resp_t **resps, nxs_err_t *errs, slab_builder_t *sb,
-    int *failed)
+    int *failed, int only_rank)
 {
 	const size_t rec_bytes = NXSGPU_REC_BYTES(k), block_bytes = NXSGPU_BLOCK_BYTES(n_slots, k);
 	size_t total = 0;
 
+	/* only_rank >= 0 (nxs_index_shard_local): that rank's slice alone -- the other slices' responses stay
+	 * NULL and their errs[] untouched: O(n / world) host work per rank and batch instead of O(n) */
 	for (uint32_t r = 0; r < world; r++) {
 		const uint8_t *blk = blocks + (size_t)r * block_bytes;
 		uint64_t rlo, rhi;
 
+		if (only_rank >= 0 && (int)r != only_rank) {
+			continue;
+		}
 		nxsgpu_shard_slice(n, (int)r, (int)world, &rlo, &rhi);
 		for (uint64_t i = 0; i < rhi - rlo; i++) {
 			const uint32_t c = ((const uint32_t *)(blk + i * rec_bytes))[0];
@@ -2227,6 +2244,9 @@ resps_from_blocks(nxs_t *nxs, const nxs_pend_t *pd, size_t n, uint32_t world, ui
 		const uint32_t *st = (const uint32_t *)(blk + (size_t)n_slots * rec_bytes);
 		uint64_t rlo, rhi;
 
+		if (only_rank >= 0 && (int)r != only_rank) {
+			continue;
+		}
 		nxsgpu_shard_slice(n, (int)r, (int)world, &rlo, &rhi);
 		for (uint64_t i = 0; i < rhi - rlo; i++) {
 			const uint8_t *rec = blk + i * rec_bytes;
@@ -2530,7 +2550,8 @@ batch_end_core(nxs_index_t *idx, nxs_pend_t *pd, nxs_resp_t **resps, nxs_err_t *
 			ret = 0;
 			goto out;
 		}
-		if (resps_from_blocks(nxs, pd, n, W, v.n_slots, v.k, blocks, resps, errs, &sb, &failed) == -1) {
+		if (resps_from_blocks(nxs, pd, n, W, v.n_slots, v.k, blocks, resps, errs, &sb, &failed,
+		    (idx->shard_local && W > 1) ? pd->rank : -1) == -1) {
 			goto out;
 		}
 		idx->hp_resps += now_s() - t0;
@@ -3160,6 +3181,42 @@ nxs_index_shard(nxs_index_t *idx, int rank, int world, const uint8_t *uid)
 	return 0;
 }
 
+/*
+ * The reference scales out by independent worker processes, each answering only ITS OWN requests
+ * (compose/nginx.conf:2).  nxs_index_shard_local(idx, true): a rank of a sharded index materialises the
+ * responses of its own slice only -- resps[i] stays NULL and errs[i] is left alone for the queries the other
+ * ranks own; the return value counts the failures of the own slice.  The collective is unchanged (every rank
+ * still sees every block: aborts, the fix-up round and re-sync agreement read all status words), but the
+ * per-rank host work per batch is O(n / world) instead of O(n).
+ */
+int
+nxs_index_shard_local(nxs_index_t *idx, bool on)
+{
+	nxs_clear_error(idx->nxs);
+	if (pend_oldest(idx)) {
+		nxs_decl_err(idx->nxs, NXS_ERR_INVALID, "batches are in flight");
+		return -1;
+	}
+	idx->shard_local = on;
+	return 0;
+}
+
+/* the part [*lo, *hi) of an n-query batch whose responses this index delivers (everything unless
+ * nxs_index_shard_local is on and a communicator of more than one rank -- or its emulation -- is attached) */
+void
+nxs_index_shard_slice(const nxs_index_t *idx, size_t n, size_t *lo, size_t *hi)
+{
+	const int world = idx->comm ? nxsgpu_comm_world(idx->comm) : idx->emu_world;
+	const int rank = idx->comm ? nxsgpu_comm_rank(idx->comm) : idx->emu_rank;
+	uint64_t a = 0, b = n;
+
+	if (idx->shard_local && world > 1) {
+		nxsgpu_shard_slice(n, rank, world, &a, &b);
+	}
+	*lo = (size_t)a;
+	*hi = (size_t)b;
+}
+
 /* ---- test hooks (host-only pieces, exercised without a GPU) ------------------------ */
 #ifdef NXS_TEST_HOOKS
 
@@ -3362,7 +3419,7 @@ nxs_test_inject_failure(nxs_index_t *idx, int which, unsigned nth)
  * every rank sees that and fails the batch, none is left in a collective */
 int
 nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k,
-    size_t n, nxs_resp_t **resps, nxs_err_t *errs)
+    size_t n, nxs_resp_t **resps, nxs_err_t *errs, int only_rank)
 {
 	nxs_t fake;
 	slab_builder_t sb = { 0 };
@@ -3380,7 +3437,7 @@ nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint3
 		}
 		return -2 - ar;
 	}
-	if (resps_from_blocks(&fake, NULL, n, world, n_slots, k, blocks, resps, errs, &sb, &failed) == -1) {
+	if (resps_from_blocks(&fake, NULL, n, world, n_slots, k, blocks, resps, errs, &sb, &failed, only_rank) == -1) {
 		free(fake.errmsg);
 		return -1;
 	}

@@ -29,10 +29,26 @@ now_s(void)
 	return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* (a rank of a sharded index in nxs_index_shard_local mode delivers -- and a worker walks -- its own slice only) */
+static size_t own_lo, own_hi;
+
+static void
+consume_range(nxs_resp_t **resps, size_t lo, size_t hi, nxs_bench_out_t *o);
+
 static void
 consume(nxs_resp_t **resps, size_t n, nxs_bench_out_t *o)
 {
-	for (size_t i = 0; i < n; i++) {
+	if (own_hi > own_lo && own_hi <= n) {
+		consume_range(resps, own_lo, own_hi, o);
+	} else {
+		consume_range(resps, 0, n, o);
+	}
+}
+
+static void
+consume_range(nxs_resp_t **resps, size_t lo, size_t hi, nxs_bench_out_t *o)
+{
+	for (size_t i = lo; i < hi; i++) {
 		nxs_doc_id_t id;
 		float sc;
 
@@ -72,6 +88,7 @@ nxs_bench_batches_rot(nxs_index_t *idx, nxs_params_t *params, const char *const 
 	if (!resps || !errs || n_sets == 0) {
 		goto out;
 	}
+	nxs_index_shard_slice(idx, n, &own_lo, &own_hi);
 	t0 = now_s();
 	if (depth <= 1) {
 		for (unsigned s = 0; s < steps; s++) {

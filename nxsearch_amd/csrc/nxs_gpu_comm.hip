@@ -17,6 +17,7 @@ struct rccl_api_t {
 	ncclResult_t	(*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
 	ncclResult_t	(*CommDestroy)(ncclComm_t);
 	ncclResult_t	(*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+	ncclResult_t	(*CommCount)(const ncclComm_t, int *);		/* (optional: evidence only) */
 	const char *	(*GetErrorString)(ncclResult_t);
 };
 
@@ -49,6 +50,7 @@ rccl_api(void)
 	api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
 	api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
 	api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+	api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
 	if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
 		set_error("librccl lacks an expected symbol");
 		return NULL;
@@ -63,6 +65,7 @@ struct nxsgpu_comm {
 	hipStream_t	stream;		/* blocking helper's own stream */
 	void *		d_buf;
 	size_t		d_len;
+	uint64_t	n_gathers, gather_bytes;	/* all-gathers queued so far, bytes this rank contributed */
 };
 
 static const char *
@@ -152,6 +155,27 @@ nxsgpu_comm_destroy(nxsgpu_comm_t *c)
 extern "C" int nxsgpu_comm_rank(const nxsgpu_comm_t *c) { return c ? c->rank : 0; }
 extern "C" int nxsgpu_comm_world(const nxsgpu_comm_t *c) { return c ? c->world : 1; }
 
+/* what RCCL itself says the communicator spans (ncclCommCount): -1 if it cannot be asked */
+extern "C" int
+nxsgpu_comm_rccl_count(const nxsgpu_comm_t *c)
+{
+	rccl_api_t *R = rccl_api();
+	int n = -1;
+
+	if (!R || !c || !R->CommCount || R->CommCount(c->comm, &n) != ncclSuccess) {
+		return -1;
+	}
+	return n;
+}
+
+/* out[0] = all-gathers queued on this communicator so far, out[1] = bytes this rank contributed to them */
+extern "C" void
+nxsgpu_comm_stats(const nxsgpu_comm_t *c, uint64_t out[2])
+{
+	out[0] = c ? c->n_gathers : 0;
+	out[1] = c ? c->gather_bytes : 0;
+}
+
 /* device buffers, asynchronous on `stream`; recv holds world x bytes */
 int
 comm_allgather_dev(nxsgpu_comm_t *c, const void *send, void *recv, size_t bytes, hipStream_t stream)
@@ -167,6 +191,8 @@ comm_allgather_dev(nxsgpu_comm_t *c, const void *send, void *recv, size_t bytes,
 		set_error("ncclAllGather: %s", rccl_err(R, r));
 		return -1;
 	}
+	c->n_gathers++;
+	c->gather_bytes += bytes;
 	return 0;
 }
 

@@ -67,7 +67,6 @@ cfg_from_env(gpu_cfg_t &c)
 	c.wave_target = u64("NXS_GPU_WAVES", 65536, 1, 1u << 22);
 	c.min_post = u64("NXS_GPU_MINPOST", 4096, 1, ~0ull);
 	c.min_post_solo = u64("NXS_GPU_MINPOST_SOLO", 512, 1, ~0ull);
-	c.dense_thr = dbl("NXS_GPU_DENSE", 0.0);
 	c.scanm_dens = dbl("NXS_GPU_SCANM_DENS", 0.08);
 	c.scanm_minnt = (uint32_t)u64("NXS_GPU_SCANM_MINNT", 2, 2, 8);
 	c.scanm_maxnt = (uint32_t)u64("NXS_GPU_SCANM_MAXNT", 8, 2, 8);
@@ -78,7 +77,6 @@ cfg_from_env(gpu_cfg_t &c)
 	c.big_minpost = u64("NXS_GPU_BIG_MINPOST", 16, 0, 1u << 20);
 	c.fuzzy_items = u64("NXS_GPU_FUZZY_ITEMS", 256ull << 20, 1, 1ull << 32);
 	c.use_scanr = !on("NXS_GPU_NOSCANR");
-	c.no_step = on("NXS_GPU_NOSTEP");
 	c.mask_off = !on("NXS_GPU_NOMASKOFF");
 	c.by_level = !on("NXS_GPU_NOLEVELS");
 	c.use_scanm = !on("NXS_GPU_NOSCANM");
@@ -90,11 +88,6 @@ cfg_from_env(gpu_cfg_t &c)
 	c.use_scans_drop = on("NXS_GPU_SCANS_DROP");
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
-#ifdef NXS_EXPERIMENTAL
-	c.use_grid = (uint32_t)u64("NXS_GPU_GRID", 0, 0, 3);
-#else
-	c.use_grid = 0;		/* k_scang is an opt-in build */
-#endif
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");
 	c.tfidf_drop = !on("NXS_GPU_TFIDF_NODROP");
 	c.outl_share = (uint32_t)u64("NXS_GPU_OUTL_SHARE", 8, 2, 1u << 20);

@@ -18,8 +18,6 @@
  *                         every term has a directory)
  *  nxs_gpu_scan_bit.hip   k_scanb: the same class on one presence BIT per doc pair (64k-doc tiles),
  *                         candidates scored one per lane by lower-bound searches (the default)
- *  nxs_gpu_scan_grid.hip  k_scang: the mask path over a doc grid (all terms' postings of a
- *                         part in one run of slots): opt-in alternative to k_scanm
  *  nxs_gpu_scan_req.hip   k_cursors, k_scan1 (one token), k_scanr (required
  *                         terms: intersect first), k_scanq (the same through
  *                         block-presence bitmaps: postings of surviving blocks only)
@@ -122,7 +120,6 @@ struct gpu_cfg_t {
 	uint64_t	wave_target;	/* NXS_GPU_WAVES */
 	uint64_t	min_post;	/* NXS_GPU_MINPOST */
 	uint64_t	min_post_solo;	/* NXS_GPU_MINPOST_SOLO: the same for a small batch with nothing else in flight */
-	double		dense_thr;	/* NXS_GPU_DENSE (0 = posting-step path off) */
 	double		scanm_dens;	/* NXS_GPU_SCANM_DENS */
 	uint32_t	scanm_minnt, scanm_maxnt;
 	uint32_t	rmin;		/* fewest tokens for k_scanr (NXS_GPU_NOSCANR2 => 3) */
@@ -132,7 +129,7 @@ struct gpu_cfg_t {
 	uint32_t	seg_cap_big;	/* NXS_GPU_SEGCAP_BIG: the same for limits > 64 (0: 6 x limit) */
 	uint64_t	big_minpost;	/* NXS_GPU_BIG_MINPOST: postings per range and unit of limit, limits > 64 */
 	uint64_t	fuzzy_items;	/* NXS_GPU_FUZZY_ITEMS */
-	bool		use_scanr, no_step, mask_off, by_level, use_scanm, scanm_general;
+	bool		use_scanr, mask_off, by_level, use_scanm, scanm_general;
 	bool		old_scan, no_scan1, no_req, one_replay, fuzzy_safe, fuzzy_noprune;
 	bool		fuzzy_bfs;	/* NXS_GPU_FUZZY_BFS: level-by-level frontier search only */
 	uint64_t	fuzzy_cand;	/* NXS_GPU_FUZZY_CAND: survivor queue of the match-first search (items) */
@@ -167,8 +164,6 @@ struct gpu_cfg_t {
 					 * wavefronts all start cold at once (a C3 batch: NOTES.md) */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
-	uint32_t	use_grid;	/* NXS_GPU_GRID (bit 0: the plain class, bit 1: the sparse + dense class): the mask path on the doc grid (k_scang) instead of register windows
-					 * (k_scanm) -- measured slower on C3, kept as a tested alternative */
 };
 
 void cfg_from_env(gpu_cfg_t &c);
@@ -375,7 +370,6 @@ struct scan_args_t {
 						 * best score, j = 0..5 (bigk_publish / bigk_hint) */
 	uint32_t		flags;		/* bit 0: raise the wavefronts' issue priority (side-stream class);
 						 * bit 1 (k_scan8): the work items are the retry list's;
-						 * bit 2: the mask path walks the doc grid (k_scang);
 						 * bit 4: the sparse + dense class's second kernel is k_scans<.., DROP> */
 	/*
 	 * Ranges whose pending list overflowed on the mask path (k_scanm: a burst of docs
@@ -446,7 +440,8 @@ struct replay_args_t {
 #define	HEAP_LDS	2
 #define	REPLAY_LDS_K	8000
 
-struct launch_t { uint32_t first, count, nt_bucket, kind, nomask, q_first, q_count; uint64_t postings; };	/* kind: 0 wide, 1 tile, 2 step */
+struct launch_t { uint32_t first, count, nt_bucket, kind, nomask, q_first, q_count; uint64_t postings; };	/* kind: 0 generic (9..32 tokens), 1 accumulator tiles / k_scan1, 3 k_scanr, 4 k_scanm, 5 k_cold + k_scanm<DROP>,
+ * 6 k_scanb, 7 k_scanq, 8 k_scans, 9 k_cold + k_scans<DROP> */
 
 struct worklist_t {
 	std::vector<qmeta_t>	qmeta;
@@ -516,13 +511,10 @@ void	nxs_launch_scans(uint32_t nt_bucket, bool gen, unsigned grid, hipStream_t s
 void	nxs_launch_scans_drop(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* the mask path on presence bits, candidates scored one per lane (k_scanb) */
 void	nxs_launch_scanb(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
-/* the same two on the doc grid (k_scang; scan_args_t::flags bit 2 routes the launchers above here) */
-void	nxs_launch_scang(uint32_t nt_bucket, bool gen, bool drop, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scan1(int mode, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStream_t st, const scan_args_t &a);
 /* conjunctions whose required terms all have a block bitmap: intersect the bitmaps, look only at surviving blocks */
 void	nxs_launch_scanq(uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
-void	nxs_launch_scanh(int mode, uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a);
 void	nxs_launch_replay(int heap, unsigned grid, size_t dyn_lds, hipStream_t st, const replay_args_t &r);
 
 #endif /* NXS_GPU_INT_H */

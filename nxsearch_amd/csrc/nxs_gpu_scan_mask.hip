@@ -984,12 +984,6 @@ nxs_launch_scanm(uint32_t nt_bucket, bool gen, unsigned grid_, hipStream_t st, c
 {
 	const dim3 grid(grid_), block(WAVE);
 
-#ifdef NXS_EXPERIMENTAL
-	if (a.flags & 4) {
-		nxs_launch_scang(nt_bucket, gen, false, grid_, st, a);
-		return;
-	}
-#endif
 	if (!gen) {
 		switch (nt_bucket) {
 		case 2:		/* two tokens: the third slot stays empty */
@@ -1019,28 +1013,20 @@ nxs_launch_drop_class(uint32_t nt_bucket, unsigned grid_, hipStream_t st, const 
 	case 3:
 		hipLaunchKernelGGL((k_cold<3, false>), grid, block, 0, st, a);
 		if (a.flags & 16) { nxs_launch_scans_drop(nt_bucket, grid_, st, a); break; }
-		if (a.flags & 4) break;
 		if (a.flags & 8) { nxs_launch_scanb(nt_bucket, false, true, grid_, st, a); break; }
 		hipLaunchKernelGGL((k_scanm<3, false, true>), grid, block, 0, st, a);
 		break;
 	case 5:
 		hipLaunchKernelGGL((k_cold<5, false>), grid, block, 0, st, a);
 		if (a.flags & 16) { nxs_launch_scans_drop(nt_bucket, grid_, st, a); break; }
-		if (a.flags & 4) break;
 		if (a.flags & 8) { nxs_launch_scanb(nt_bucket, false, true, grid_, st, a); break; }
 		hipLaunchKernelGGL((k_scanm<5, false, true>), grid, block, 0, st, a);
 		break;
 	default:
 		hipLaunchKernelGGL((k_cold<8, false>), grid, block, 0, st, a);
 		if (a.flags & 16) { nxs_launch_scans_drop(nt_bucket, grid_, st, a); break; }
-		if (a.flags & 4) break;
 		hipLaunchKernelGGL((k_scanm<8, false, true>), grid, block, 0, st, a);
 		break;
 	}
-#ifdef NXS_EXPERIMENTAL
-	if (a.flags & 4) {
-		nxs_launch_scang(nt_bucket, false, true, grid_, st, a);
-	}
-#endif
 }
 

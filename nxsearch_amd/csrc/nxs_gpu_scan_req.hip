@@ -1,5 +1,5 @@
 /*
- * nxs_gpu_scan_req.hip -- k_cursors, k_scan1 (single token), k_scanr (required terms: intersect first), k_scanh (opt-in)
+ * nxs_gpu_scan_req.hip -- k_cursors, k_scan1 (single token), k_scanr (required terms: intersect first), k_scanq (the same through block bitmaps)
  * (MI355X / gfx950 query path of nxsearch; see nxs_gpu_int.h for the map of the files)
  */
 #include "nxs_gpu_int.h"
@@ -926,351 +926,6 @@ k_scanq(const scan_args_t A)
 	}
 }
 
-#ifdef NXS_EXPERIMENTAL	/* opt-in build: measured not faster than the tiles (DESIGN.md "dead ends") */
-/*
- * k_scanh: the posting-step path for queries without a very dense term.
- *
- * Every term streams its list through register sets as in k_scan8.  A STEP
- * picks base = the largest, over the terms, of the lowest doc still held in
- * the term's set A.  All unconsumed postings with doc >= base are then in
- * registers, for every term: the term that defines base drains its whole set
- * (so a query needs at most sum_t ceil(df_t / 64K) steps, however sparse it
- * is), the others contribute the part of their set above base.  The docs of a
- * step can span far more than an LDS tile, so scores accumulate in a small
- * LDS hash table keyed by doc (slot = low doc bits, linear probing, claims are
- * written then verified -- no atomics).  Terms are applied in token order, so
- * a doc's f32 sum order is the reference's (results.c:134-136).  Claimed slots
- * go to a list: the table is scanned and wiped through it.  Steps run in
- * descending doc ranges and a step's candidates are rank-sorted by doc, so the
- * segment is in descending doc order like k_scan8's.
- */
-template <int MODE, int NT>
-__global__ void __launch_bounds__(WAVE)
-k_scanh(const scan_args_t A)
-{
-	constexpr int KSH = NT <= 2 ? 2 : NT <= 3 ? 1 : 0;
-	constexpr int K = 1 << KSH;
-	constexpr int SW = WAVE * K;
-	constexpr int MAXE = WAVE * K * NT;		/* table entries per step */
-	constexpr int TAB = MAXE <= 256 ? 512 : 1024;	/* load factor <= 1/2 */
-	constexpr uint32_t EMPTY = 0xffffffffu;
-
-	__shared__ uint32_t s_key[TAB];
-	__shared__ float s_val[TAB];
-	__shared__ uint8_t s_msk[TAB];
-	__shared__ uint16_t s_list[MAXE];
-	__shared__ uint32_t s_cd[MAXE];
-	__shared__ float s_cs[MAXE];
-	__shared__ uint32_t s_truth[8];
-	__shared__ uint32_t s_hist[4];	/* (MODE_BIG never comes here) */
-	__shared__ int64_t s_init[16];
-
-	const unsigned lane = threadIdx.x;
-	const item_t item = A.items[A.item_base + blockIdx.x];
-	const uint32_t q = item.q, g = item.g;
-	const qmeta_t qm = A.qmeta[q];
-	const dev_query_t *Q = &A.queries[q];
-	const uint32_t nt = Q->nt;
-	const uint64_t seg = (uint64_t)qm.seg_first + g;
-	const uint64_t dlo = (uint64_t)g * qm.group_docs;
-	const uint64_t dhi = min(A.n_docs, dlo + (uint64_t)qm.group_docs);
-
-	for (uint32_t i = lane; i < TAB; i += WAVE) {
-		s_key[i] = EMPTY;
-		s_val[i] = 0.0f;
-		s_msk[i] = 0;
-	}
-	if (lane < 8) {
-		s_truth[lane] = Q->truth[lane];
-	}
-	if (lane < 16) {
-		const uint32_t t = lane & 7;
-		int64_t v = 0;
-		if (t < nt) {
-			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
-			(void)dlo; (void)dhi;
-			v = (int64_t)A.cursors[cb + (lane < 8 ? NXSGPU_MAX_TOKENS : 0)];
-		}
-		s_init[lane] = v;
-	}
-	WAVE_SYNC();
-
-	/* wave-uniform per-term state */
-	const posting_t *pt[NT];
-	int32_t hi[NT], lo[NT], pdoc[NT], lowdoc[NT];
-	uint32_t Ad[NT][K], Bd[NT][K];
-	float Ai[NT][K], Bi[NT][K];
-
-#pragma unroll
-	for (int t = 0; t < NT; t++) {
-		pt[t] = A.post;
-		hi[t] = lo[t] = 0;
-		pdoc[t] = lowdoc[t] = -1;
-#pragma unroll
-		for (int k = 0; k < K; k++) {
-			Ad[t][k] = Bd[t][k] = 0;
-			Ai[t][k] = Bi[t][k] = 0.0f;
-		}
-		if (t < (int)nt) {
-			pt[t] = A.post + Q->pbeg[t];
-			hi[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[t]);
-			lo[t] = __builtin_amdgcn_readfirstlane((int32_t)s_init[8 + t]);
-			if (hi[t] > lo[t]) {
-				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
-#pragma unroll
-				for (int k = 0; k < K; k++) {
-					const int32_t ia = ab + k * WAVE + (int32_t)lane, ib = ia - SW;
-					if (ia >= lo[t] && ia < hi[t]) {
-						const posting_t p = pt[t][ia];
-						Ad[t][k] = p.doc; Ai[t][k] = p.imp;
-					}
-					if (ib >= lo[t]) {
-						const posting_t p = pt[t][ib];
-						Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-					}
-				}
-				const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
-#pragma unroll
-				for (int k = 0; k < K; k++) {
-					if (k == kt) {
-						pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-					}
-				}
-				/* lowest doc held in set A, or -1 if the set reaches the
-				 * start of this range's postings */
-				if (ab > lo[t]) {
-					lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
-				}
-			}
-		}
-	}
-
-	float top = -INFINITY;
-	float hint = (MODE == MODE_TOPK && A.k <= WAVE) ? range_hint(A, qm, g) :
-	    MODE == MODE_BIG ? bigk_hint(A, qm, g) : -INFINITY;
-	float thr = hint;
-	const uint32_t kidx = (A.k >= 1 && A.k <= WAVE) ? A.k - 1 : WAVE - 1;
-	const bool track = (MODE == MODE_TOPK) && A.k <= WAVE;
-	/* MODE_BIG: candidates counted since the threshold was last read off the histogram */
-	uint32_t big_since = 0;
-	const uint32_t big_upd = bigk_update_every(A.k);
-	uint32_t n_out = 0;
-	bool ovf = false;
-	const uint64_t out_base = (MODE == MODE_ALL) ? A.seg_off[seg] : seg * A.seg_cap;
-
-	for (;;) {
-		int32_t md = -1, bs = -1;
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
-			md = max(md, pdoc[t]);
-			bs = max(bs, lowdoc[t]);
-		}
-		if (md < 0) {
-			break;		/* every list is consumed */
-		}
-		const uint32_t base = bs < 0 ? 0u : (uint32_t)bs;
-		uint32_t n_list = 0;
-		float tmax = -INFINITY;
-
-#pragma unroll
-		for (int t = 0; t < NT; t++) {
-			if (t < (int)nt && pdoc[t] >= (int32_t)base) {
-				const int32_t ab = ((hi[t] - 1) >> (6 + KSH)) << (6 + KSH);
-				uint32_t ctot = 0;
-				bool more = true;
-#pragma unroll
-				for (int k = K - 1; k >= 0; k--) {
-					if (more && hi[t] > ab + k * WAVE) {
-						const int32_t idx = ab + k * WAVE + (int32_t)lane;
-						const uint32_t doc = Ad[t][k];
-						const bool in = idx >= lo[t] && idx < hi[t] && doc >= base;
-						const uint32_t c = __popcll(ballot64(in));
-						const int32_t top_ = min(hi[t], ab + (k + 1) * WAVE);
-						const int32_t bot_ = max(lo[t], ab + k * WAVE);
-						ctot += c;
-						if ((int32_t)c < top_ - bot_) {
-							more = false;
-						}
-						if (c) {
-							/* find or claim the doc's slot */
-							/* volatile: the claim must really be re-read, not
-							 * forwarded from this lane's own store */
-							volatile uint32_t *vkey = s_key;
-							uint32_t slot = doc & (TAB - 1);
-							bool pending = in, isnew = false;
-							while (ballot64(pending)) {
-								uint32_t kk = 0;
-								if (pending) {
-									kk = vkey[slot];
-									if (kk == EMPTY) {
-										vkey[slot] = doc;
-									}
-								}
-								if (pending) {
-									if (kk == doc) {
-										pending = false;
-									} else if (kk == EMPTY) {
-										/* several lanes may have written
-										 * this slot: one value landed */
-										if (vkey[slot] == doc) {
-											pending = false;
-											isnew = true;
-										}
-									} else {
-										slot = (slot + 1) & (TAB - 1);
-									}
-								}
-							}
-							if (in) {
-								const float v = s_val[slot] + Ai[t][k];
-								s_val[slot] = v;
-								s_msk[slot] = (uint8_t)(s_msk[slot] | (1u << t));
-								tmax = fmaxf(tmax, v);
-							}
-							const uint64_t fb = ballot64(isnew);
-							if (isnew) {
-								s_list[n_list + lanes_below(fb)] = (uint16_t)slot;
-							}
-							n_list += __popcll(fb);
-						}
-					}
-				}
-				hi[t] = __builtin_amdgcn_readfirstlane(hi[t] - (int32_t)ctot);
-				pdoc[t] = -1;
-				if (hi[t] <= lo[t]) {
-					lowdoc[t] = -1;
-				} else if (hi[t] == ab) {
-					/* set A drained: take over set B, K new loads in flight */
-#pragma unroll
-					for (int k = 0; k < K; k++) {
-						Ad[t][k] = Bd[t][k];
-						Ai[t][k] = Bi[t][k];
-					}
-#pragma unroll
-					for (int k = 0; k < K; k++) {
-						const int32_t ib = ab - 2 * SW + k * WAVE + (int32_t)lane;
-						Bd[t][k] = 0; Bi[t][k] = 0.0f;
-						if (ib >= lo[t]) {
-							const posting_t p = pt[t][ib];
-							Bd[t][k] = p.doc; Bi[t][k] = p.imp;
-						}
-					}
-					lowdoc[t] = -1;
-					if (ab - SW > lo[t]) {
-						lowdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][0], 0);
-					}
-					pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][K - 1], WAVE - 1);
-				} else {
-					const int32_t kt = ((hi[t] - 1) >> 6) & (K - 1);
-#pragma unroll
-					for (int k = 0; k < K; k++) {
-						if (k == kt) {
-							pdoc[t] = __builtin_amdgcn_readlane((int)Ad[t][k], (hi[t] - 1) & 63);
-						}
-					}
-				}
-			}
-		}
-		WAVE_SYNC();
-
-		/* candidates of this step (skipped when nothing beat the threshold:
-		 * scores only grow within a step, see k_scan8) */
-		if (MODE == MODE_COUNT || ballot64(tmax > thr) != 0) {
-			uint32_t ncand = 0;
-			for (uint32_t off = 0; off < n_list; off += WAVE) {
-				const uint32_t i = off + lane;
-				const bool valid = i < n_list;
-				uint32_t d = 0, m = 0;
-				float sc = 0.0f;
-				if (valid) {
-					const uint32_t slot = s_list[i];
-					d = s_key[slot];
-					m = s_msk[slot];
-					sc = s_val[slot];
-				}
-				if (MODE == MODE_COUNT) {
-					const bool match = valid && ((s_truth[m >> 5] >> (m & 31)) & 1);
-					n_out += __popcll(ballot64(match));
-					continue;
-				}
-				const bool pre = valid && (sc > thr);
-				if (ballot64(pre) == 0) {
-					continue;
-				}
-				const bool cand = pre && ((s_truth[m >> 5] >> (m & 31)) & 1);
-				const uint64_t bal = ballot64(cand);
-				if (cand) {
-					const uint32_t j = ncand + lanes_below(bal);
-					s_cd[j] = d;
-					s_cs[j] = sc;
-				}
-				ncand += __popcll(bal);
-			}
-			if (MODE != MODE_COUNT && ncand) {
-				WAVE_SYNC();
-				if (MODE_FILTERS(MODE) && n_out + ncand > A.seg_cap) {
-					ovf = true;
-				} else {
-					/* rank by doc, descending: docs are distinct */
-					for (uint32_t i0 = 0; i0 < ncand; i0 += WAVE) {
-						const uint32_t i = i0 + lane;
-						const uint32_t cd = i < ncand ? s_cd[i] : 0;
-						uint32_t rank = 0;
-						for (uint32_t j = 0; j < ncand; j++) {
-							rank += s_cd[j] > cd;
-						}
-						if (i < ncand) {
-							const uint64_t o = out_base + n_out + rank;
-							A.cand_doc[o] = cd;
-							A.cand_sc[o] = s_cs[i];
-						}
-					}
-				}
-				n_out += ncand;
-				if (track) {
-					for (uint32_t j = 0; j < ncand; j++) {
-						const float v = s_cs[j];
-						if (v > thr) {
-							const uint32_t pos = __popcll(ballot64(top >= v));
-							const float up = __shfl_up(top, 1);
-							top = (lane < pos) ? top : (lane == pos ? v : up);
-							thr = fmaxf(__shfl(top, kidx), hint);
-						}
-					}
-				}
-			}
-		}
-		/* wipe the table through the list */
-		for (uint32_t off = 0; off < n_list; off += WAVE) {
-			const uint32_t i = off + lane;
-			if (i < n_list) {
-				const uint32_t slot = s_list[i];
-				s_key[slot] = EMPTY;
-				s_val[slot] = 0.0f;
-				s_msk[slot] = 0;
-			}
-		}
-		WAVE_SYNC();
-	}
-
-	if (MODE == MODE_TOPK && track && !ovf) {
-		range_publish(A, seg, __shfl(top, kidx));	/* k-th best of this range */
-	}
-	if constexpr (MODE == MODE_BIG) {
-		if (!ovf) {
-			bigk_publish(A, seg, s_hist, A.k);	/* lower bounds of this range's k-th, k/2-th ... best */
-		}
-	}
-	if (lane == 0) {
-		if (MODE != MODE_ALL) {
-			A.seg_count[seg] = ovf ? 0 : n_out;
-		}
-		if (MODE_FILTERS(MODE) && ovf) {
-			A.overflow[q] = 1;
-		}
-	}
-}
-#endif /* NXS_EXPERIMENTAL */
 
 /* ---- launchers ------------------------------------------------------ */
 
@@ -1350,33 +1005,4 @@ nxs_launch_scanr(int mode, uint32_t nt_bucket, bool hash, unsigned grid, hipStre
 	}
 }
 
-#ifdef NXS_EXPERIMENTAL
-template <int MODE>
-static void
-launch_scanh_mode(uint32_t nt_bucket, const dim3 grid, hipStream_t st, const scan_args_t &a)
-{
-	const dim3 block(WAVE);
-
-	switch (nt_bucket) {
-	case 2: hipLaunchKernelGGL((k_scanh<MODE, 2>), grid, block, 0, st, a); break;
-	case 3: hipLaunchKernelGGL((k_scanh<MODE, 3>), grid, block, 0, st, a); break;
-	case 5: hipLaunchKernelGGL((k_scanh<MODE, 5>), grid, block, 0, st, a); break;
-	default: hipLaunchKernelGGL((k_scanh<MODE, 8>), grid, block, 0, st, a); break;
-	}
-}
-#endif
-
-void
-nxs_launch_scanh(int mode, uint32_t nt_bucket, unsigned grid, hipStream_t st, const scan_args_t &a)
-{
-#ifdef NXS_EXPERIMENTAL
-	switch (mode) {
-	case MODE_TOPK: launch_scanh_mode<MODE_TOPK>(nt_bucket, dim3(grid), st, a); break;
-	case MODE_COUNT: launch_scanh_mode<MODE_COUNT>(nt_bucket, dim3(grid), st, a); break;
-	default: launch_scanh_mode<MODE_ALL>(nt_bucket, dim3(grid), st, a); break;
-	}
-#else
-	(void)mode; (void)nt_bucket; (void)grid; (void)st; (void)a;	/* opt-in build */
-#endif
-}
 

@@ -977,9 +977,6 @@ launch_scan8_mode(uint32_t nt_bucket, uint32_t mm, const dim3 grid, hipStream_t 
 		break;
 	case 2:
 		if (mm == 1) { hipLaunchKernelGGL((k_scan8<MODE, 2, 1>), grid, block, 0, st, a); }
-#ifdef NXS_EXPERIMENTAL
-		else if (mm == 2) { hipLaunchKernelGGL((k_scan8<MODE, 2, 2>), grid, block, 0, st, a); }
-#endif
 		else { hipLaunchKernelGGL((k_scan8<MODE, 2, 0>), grid, block, 0, st, a); }
 		break;
 	case 3:
@@ -997,7 +994,7 @@ launch_scan8_mode(uint32_t nt_bucket, uint32_t mm, const dim3 grid, hipStream_t 
 	}
 }
 
-/* k_scan8: mm = 0 mask byte + truth table, 1 pure OR, 2 two-token AND (opt-in build) */
+/* k_scan8: mm = 0 mask byte + truth table, 1 pure OR */
 void
 nxs_launch_scan8(int mode, uint32_t nt_bucket, uint32_t mm, unsigned grid, hipStream_t st, const scan_args_t &a)
 {

@@ -36,15 +36,8 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	const gpu_cfg_t &cf = ix->cfg;
 	/* (a batch that has the GPU to itself is latency-bound: shorter ranges, more of them) */
 	const uint64_t target = cf.wave_target, min_post = solo ? std::min(cf.min_post, cf.min_post_solo) : cf.min_post;
-	/* densest term has >= this many postings per tile => tile path (step path
-	 * off by default: the tile path is at least as fast) */
-#ifdef NXS_EXPERIMENTAL
-	const double dense_thr = cf.dense_thr;
-#else
-	const double dense_thr = 0.0;	/* k_scanh is an opt-in build */
-#endif
 	const bool use_scanr = cf.use_scanr && ix->n_docs < (1ull << 31);
-	const bool no_step = cf.no_step, mask_off = cf.mask_off;
+	const bool mask_off = cf.mask_off;
 	const uint32_t rmin = cf.rmin;	/* 3: "a AND b" takes k_scan8's sign-bit path */
 	const bool by_level = cf.by_level;
 	/* (limits > 64 -- big_k -- filter on a histogram threshold: the accumulator tiles,
@@ -73,27 +66,13 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 		if (hq[i].nt > 8) {
 			cls[i] = 0;
 		} else {
-			const double per_tile = (double)wmax * TILE_W / (double)std::max<uint64_t>(ix->n_docs, 1);
-			const bool tile = dense_thr <= 0.0 || per_tile >= dense_thr || hq[i].nt <= 1 ||
-			    ix->n_docs >= (1ull << 31) || no_step;
 			/* pure OR: every non-empty presence mask matches => no mask array */
 			bool or_only = hq[i].nt >= 2 && mask_off;
 			for (uint32_t m = 1; or_only && m < (1u << hq[i].nt); m++) {
 				or_only = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
 			}
-			/* pure AND of exactly two tokens: only the full mask matches.
-			 * (The sign-parity scheme of MM = 2 cannot tell "stuck at token
-			 * t-2" from "updated by token t" for three tokens or more.) */
-			bool and_only = hq[i].nt == 2 && mask_off;
-			for (uint32_t m = 1; and_only && m < (1u << hq[i].nt); m++) {
-				const bool hit = (hq[i].truth[m >> 5] >> (m & 31)) & 1;
-				and_only = hit == (m == (1u << hq[i].nt) - 1);
-			}
-#ifndef NXS_EXPERIMENTAL
-			and_only = false;	/* the sign-bit AND path (MM = 2) is an opt-in build */
-#endif
-			const uint32_t mm = !tile ? 0u : or_only ? 1u : and_only ? 2u : 0u;
-			cls[i] = (tile ? 1u : 2u) * 64 + mm * 16 + nt_bucket(hq[i].nt);
+			const uint32_t mm = or_only ? 1u : 0u;
+			cls[i] = 1u * 64 + mm * 16 + nt_bucket(hq[i].nt);
 			/* pure OR of 2..8 tokens whose lists are sparse: mask path (k_scanm).
 			 * Dense lists stream faster through the accumulator tiles. */
 			/* ... or any expression without a required token: the bound in the
@@ -110,7 +89,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 			}
 			const bool no_req = hq[i].req == 0 && hq[i].nt >= 2 && hq[i].nt <= 8 && mm != 2 &&
 			    2 * singles >= hq[i].nt;
-			if (tile && (or_only || (no_req && scanm_general)) && use_scanm &&
+			if ((or_only || (no_req && scanm_general)) && use_scanm &&
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt &&
 			    (double)wmax <= scanm_dens * (double)ix->n_docs) {
 				cls[i] = 4u * 64 + (or_only ? 16u : 0u) + nt_bucket(hq[i].nt);
@@ -132,7 +111,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 						cls[i] += 4u * 64;
 					}
 				}
-			} else if (tile && or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
+			} else if (or_only && use_scanm && cf.use_drop && hq[i].drop_mask &&
 			    hq[i].nt >= scanm_minnt && hq[i].nt <= scanm_maxnt) {
 				/*
 				 * A pure OR of sparse terms AND dense ones: the mask path on the
@@ -186,7 +165,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 			}
 			/* required terms: intersect first (k_scanr).  Its work is set by
 			 * the shortest required list; longer lists are mostly skipped */
-			if (tile && hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
+			if (hq[i].n_req && hq[i].nt >= rmin && use_scanr) {
 				const uint64_t dfd = hq[i].pend[hq[i].slot_tok[0]] - hq[i].pbeg[hq[i].slot_tok[0]];
 				uint64_t wr = 0;
 				for (uint32_t t = 0; t < hq[i].nt; t++) {
@@ -352,6 +331,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 			o1++;
 		}
 		launch_t l;
+		l.postings = 0;
 		l.first = (uint32_t)n_items;
 		l.nt_bucket = cls[order[o0]] & 15;
 		l.nomask = (cls[order[o0]] >> 4) & 3;	/* 0 mask array, 1 pure OR, 2 two-token AND */
@@ -409,6 +389,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 					l0.count = (uint32_t)n_items - l0.first;
 					l0.q_first = o0;
 					l0.q_count = 0;			/* (no replay behind this one) */
+					l0.postings = 0;		/* (the class's postings are charged to the launch its queries end in) */
 					wl.launches.push_back(l0);
 					l.first = (uint32_t)n_items;
 				}
@@ -560,11 +541,8 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 				(void)hipEventRecord(psl->ev_cls[pc][1], cls_stream);
 			}
 		};
-		/* (k_scang: 32-bit posting indexes) */
-		a.flags |= ((ix->cfg.use_grid >> (l.kind == 5 ? 1 : 0)) & 1) && ix->n_post < (1ull << 32) &&
-		    !(l.kind == 5 && a0.dense_col == ix->d_dense_col[NXSGPU_TF_IDF]) ? 4u : 0u;	/* (nor outlier lists) */
-		/* (k_scanb<.., DROP>: up to five tokens, no doc grid) */
-		a.flags |= (l.kind == 5 && ix->cfg.drop_b && l.nt_bucket <= 5 && !(a.flags & 4)) ? 8u : 0u;
+		/* (k_scanb<.., DROP>: up to five tokens) */
+		a.flags |= (l.kind == 5 && ix->cfg.drop_b && l.nt_bucket <= 5) ? 8u : 0u;
 		/* this launch's retry list (mask path only) */
 		const size_t li = (size_t)(&l - wl.launches.data());
 		const bool retry = a0.retry_items && li < RETRY_LISTS && topk64 && (l.kind == 4 || l.kind == 5 || l.kind == 6 || l.kind == 8 || l.kind == 9);
@@ -667,8 +645,6 @@ launch_scan(int MODE, nxsgpu_index_t *ix, const scan_args_t &a0, const worklist_
 			} else {
 				nxs_launch_scanr(MODE, l.nt_bucket, l.nomask == 1, grid, ix->stream, a);
 			}
-		} else {
-			nxs_launch_scanh(MODE, l.nt_bucket, grid, ix->stream, a);
 		}
 		prof_stop();
 		if (ra && l.q_count) {
@@ -1875,8 +1851,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 			n_l += l.count != 0;
 		}
 		for (launch_t &l : wl.launches) {
-			if ((l.kind == 5 || l.kind == 9) && l.q_count == 0 && l.count && n_l > 2 &&
-			    !(((ix->cfg.use_grid >> 1) & 1) && ix->n_post < (1ull << 32))) {
+			if ((l.kind == 5 || l.kind == 9) && l.q_count == 0 && l.count && n_l > 2) {
 				scan_args_t a = sa;
 				a.item_base = l.first;
 				a.flags |= ix->cfg.drop_prio ? 1u : 0u;

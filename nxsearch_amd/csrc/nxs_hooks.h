@@ -19,6 +19,9 @@
  * whole _begin() / _end() calls.
  */
 void		nxs_index_host_profile(nxs_index_t *, double out[8]);
+/* out[0] ncclCommCount of the attached communicator (-1: none / unknown), out[1] world, out[2] all-gathers queued,
+ * out[3] bytes this rank contributed to them */
+void		nxs_index_shard_info(nxs_index_t *, uint64_t out[4]);
 /* the device-side handle behind an index (nxs_gpu.h): pre-resolved plans, results left in HBM */
 struct nxsgpu_index;
 struct nxsgpu_index *nxs_index_device(nxs_index_t *);
@@ -50,7 +53,7 @@ int		nxs_test_fixup_scan(const uint8_t *blocks, uint32_t world, uint32_t n_slots
 		    size_t n, int rank, uint32_t *which, size_t *nw);
 int		nxs_test_fixup_verify(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k, size_t n);
 int		nxs_test_assemble(const uint8_t *blocks, uint32_t world, uint32_t n_slots, uint32_t k,
-		    size_t n, nxs_resp_t **resps, nxs_err_t *errs);
+		    size_t n, nxs_resp_t **resps, nxs_err_t *errs, int only_rank);
 void		nxs_test_inject_failure(nxs_index_t *, int which, unsigned nth);
 /* doc shards: the two halves of the rank form */
 int		nxs_test_docshard_block(nxs_index_t *shard, nxs_params_t *, const char *const *queries, size_t n,

@@ -129,6 +129,7 @@ struct nxs_index {
 	unsigned	shard, n_shards;
 	int		want_device;	/* explicit device + 1, or 0: NXS_GPU_DEVICE / device 0 */
 	bool		global_df_set;
+	bool		shard_local;	/* nxs_index_shard_local: responses of the own slice only */
 	/* tests: play one rank of emu_world (nxs_test_shard_emulate) */
 	int		emu_rank, emu_world;
 	uint8_t *	emu_block;

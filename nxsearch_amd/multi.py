@@ -160,17 +160,19 @@ def inject_failure(index, which, nth=1):
     L.nxs_test_inject_failure(index._h, {"begin": 0, "fixup": 1, "fixup_recv": 2}[which], nth)
 
 
-def assemble(blocks, world, n_slots, k, n):
+def assemble(blocks, world, n_slots, k, n, only_rank=-1):
     """What every rank does with the gathered blocks (resps_from_blocks):
-    -> list of result lists; a failed query is an NxsError in its slot."""
+    -> list of result lists; a failed query is an NxsError in its slot.
+    only_rank >= 0 (nxs_index_shard_local): that rank's slice alone, None elsewhere."""
     from . import _drain
     L = lib()
     L.nxs_test_assemble.restype = C.c_int
     L.nxs_test_assemble.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t,
-                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
     resps = (C.c_void_p * max(n, 1))()
     errs = (C.c_int * max(n, 1))()
-    r = L.nxs_test_assemble(blocks, world, n_slots, k, n, resps, errs)
+    r = L.nxs_test_assemble(blocks, world, n_slots, k, n, resps, errs, only_rank)
+    own = shard_slice(n, only_rank, world) if only_rank >= 0 else (0, n)
     if r <= -2:
         raise ShardAborted(-2 - r, errs[0] if n else 1)
     if r < 0:
@@ -180,6 +182,8 @@ def assemble(blocks, world, n_slots, k, n):
         if resps[i]:
             out.append(_drain(resps[i]))
             L.nxs_resp_release(resps[i])
+        elif not own[0] <= i < own[1]:
+            out.append(None)                     # another rank's query: not materialised here
         else:
             out.append(NxsError(errs[i], "query %d failed" % i))
     return out

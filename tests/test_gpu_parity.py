@@ -101,6 +101,7 @@ def test_default_filters_raw_text_scoring(golden, tmp_path):
     from test_oracle_golden import stem_docs
     g = golden["scoring_raw"]
     base = tmp_path / "b"
+    base.mkdir()
     with N.Nxs(str(base)) as n2:
         for n, c in enumerate(g["cases"]):
             items = [(int(k), v.split()) for k, v in stem_docs(c["docs"]).items()]
@@ -506,8 +507,7 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
     gidx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"NXS_GPU_DENSE": "1e12"}, {"NXS_GPU_DENSE": "8"},
-                                 {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
+@pytest.mark.parametrize("env", [{}, {"NXS_GPU_OLDSCAN": "1"}, {"NXS_GPU_NOSCAN1": "1"},
                                  {"NXS_GPU_NOREQ": "1"}, {"NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
                                  {"NXS_GPU_NOSCANR": "1"}, {"NXS_GPU_NOSCANR2": "1"},
                                  {"NXS_GPU_NOSCANR2": "1", "NXS_GPU_WAVES": "64", "NXS_GPU_MINPOST": "1"},
@@ -545,7 +545,7 @@ def test_synthetic_corpus_medium(nxs, tmp_path):
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_DROP_SPLIT": "0"},
                                  {"NXS_GPU_DROP_MINPOST": "1", "NXS_GPU_DROP_NOEARLY": "1", "NXS_GPU_DROP_SPLIT": "2"}])
 def test_every_scan_path_agrees_with_the_oracle(nxs, tmp_path, monkeypatch, env):
-    """The tile path (k_scan8), the posting-step path (k_scanh), the generic
+    """The tile path (k_scan8), the mask paths (k_scans, k_scanm, k_scanb), the generic
     kernel (k_scan), the single-token kernel and the skip logic are selected by
     query shape; force each of them over the same mixed workload."""
     for kk, v in env.items():
@@ -919,6 +919,16 @@ def test_sharded_emulated_ranks_reassemble(nxs, tmp_path, monkeypatch, world):
             assert isinstance(g, N.NxsError) and g.code == e.code, q
             continue
         assert_same(g, want, (world, q[:50]))
+    # nxs_index_shard_local: every rank materialises its own slice only -- together they give the batch
+    for r in range(world):
+        lo, hi = multi.shard_slice(n, r, world)
+        part = multi.assemble(blocks, world, cap, k, n, only_rank=r)
+        for i, g in enumerate(part):
+            if lo <= i < hi:
+                assert (isinstance(g, N.NxsError) and isinstance(got[i], N.NxsError) and g.code == got[i].code) or g == got[i]
+            else:
+                assert g is None
+    assert gidx.shard_slice(n) == (0, n)                # nothing attached: the whole batch is this index's
     gidx.close()
 
 

@@ -489,6 +489,8 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
     ringr = int(re.search(r"#define\s+SCANR_RING\s+(\d+)", src).group(1))
     srcb = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu_scan_bit.hip")).read()
     ringb = int(re.search(r"#define\s+SB_RING\s+(\d+)", srcb).group(1))
+    srcs = open(os.path.join(ROOT, "nxsearch_amd", "csrc", "nxs_gpu_scan_stripe.hip")).read()
+    rings = int(re.search(r"#define\s+ST_RING\s+(\d+)", srcs).group(1))     # k_scans: one ring for all terms
     so = shutil.copy(N.LIB_PATH, str(tmp_path / "lib.so"))
     subprocess.run([llvm + "/llvm-objdump", "--offloading", so], check=True, capture_output=True)
     co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
@@ -502,7 +504,10 @@ def test_scan_kernels_own_exactly_their_prefetch_agprs(tmp_path):
         kr = re.match(r"_Z7k_scanrILi\d+ELi(\d+)ELb[01]EE", name)
         km = re.match(r"_Z7k_scanmILi(\d+)ELb[01]ELb[01]EE", name)
         kb = re.match(r"_Z7k_scanbILi(\d+)ELb[01]ELb[01]EE", name)
-        if k8:
+        ks = re.match(r"_Z7k_scansILi(\d+)ELb[01]ELb[01]EE", name)
+        if ks:
+            want = 2 * rings
+        elif k8:
             mode, nt, mm = int(k8.group(1)), int(k8.group(2)), int(k8.group(3))
             want = 2 * (ring8b if mode == 3 else ring8) * nt if (nt >= 3 and mm != 2) else 0
         elif kr:

@@ -10,6 +10,7 @@ The `-m gpu` tier runs the same reassembly on blocks the GPU produced
 import os
 import socket
 import struct
+import time
 
 import pytest
 import torch
@@ -190,6 +191,7 @@ def _worker8(rank, world, port, tdir, n, k, ret):
         return ok
 
     out = []
+    own_times = []
     for batch, failing in ((0, None), (1, 5), (2, None)):
         mine = [answer(q) for q in queries[lo:hi]]
         # first pass: the overflowed queries carry a truncated answer and the "inexact" mark
@@ -212,9 +214,26 @@ def _worker8(rank, world, port, tdir, n, k, ret):
         bad = multi.fixup_verify(blocks2, world, cap, k, n)
         if failing is None:
             assert bad == -1
-            out.append(check(multi.assemble(blocks2, world, cap, k, n)))
+            t0 = time.perf_counter()
+            every = multi.assemble(blocks2, world, cap, k, n)
+            t_all = time.perf_counter() - t0
+            ok = check(every)
+            # nxs_index_shard_local: the own slice only -- the same answers there, nothing materialised
+            # for the queries the other ranks own (a rank's host work per batch is then O(n / world))
+            t0 = time.perf_counter()
+            own_only = multi.assemble(blocks2, world, cap, k, n, only_rank=rank)
+            t_own = time.perf_counter() - t0
+            for i, g in enumerate(own_only):
+                if lo <= i < hi:
+                    ok &= (isinstance(g, Exception) and isinstance(every[i], Exception) and g.code == every[i].code) or g == every[i]
+                else:
+                    ok &= g is None
+            own_times.append((t_own, t_all))
+            out.append(ok)
         else:
             out.append(bad == failing)
+    # (the own slice is an eighth of the batch: well under half the time of all of it, whatever the host's noise)
+    out.append(min(a for a, _ in own_times) < 0.5 * min(b for _, b in own_times))
     ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
@@ -229,7 +248,7 @@ def test_eight_ranks_fixup_round_and_an_abort_inside_it(tmp_path):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker8, args=(world, _free_port(), tdir, n, k, ret), nprocs=world, join=True)
-    assert dict(ret) == {r: [True, True, True] for r in range(world)}
+    assert dict(ret) == {r: [True, True, True, True] for r in range(world)}
 
 
 def _worker_resync(rank, world, port, tdir, n, k, ret):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the C3 bench inside one session: "name:ENV=val,ENV=val" or "name:lib=<variant suffix>" per argument
-# usage: tools/r5_ab.sh [--rounds N] spec...
+# usage: tools/ab_bench.sh [--rounds N] spec...
 mkdir -p gpurun_out/r5/ab
 ROUNDS=2
 if [ "$1" = "--rounds" ]; then ROUNDS=$2; shift 2; fi

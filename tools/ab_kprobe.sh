@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the mask-path kernels on the kprobe query sets, one session: default build, variants (NXS_GPU_LIB), k_scanm
-# usage: tools/r5_kp.sh "<sets>" <variant suffixes...>
+# usage: tools/ab_kprobe.sh "<sets>" <variant suffixes...>
 mkdir -p gpurun_out/r5
 SETS=${1:-X,K,E,M}; shift
 C=$PWD/nxsearch_amd/csrc

@@ -1,6 +1,6 @@
 #!/bin/bash
 # instruction / wait counters of the mask-path kernel on a kprobe query set (GPU box)
-# usage: tools/r5_pmc_kp.sh <set> [ENV=val ...]
+# usage: tools/pmc_kprobe.sh <set> [ENV=val ...]
 set -u
 SET=${1:-X}; shift
 out=$PWD/gpurun_out/pmckp

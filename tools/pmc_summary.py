@@ -25,6 +25,19 @@ import shutil
 import sqlite3
 
 
+def source_hash():
+    """sha256 over the HIP sources + headers the profiled library is built from (bench.py recomputes it
+    and refuses a summary whose kernels are not the tree's)."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nxsearch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     m = re.match(r"(?:void )?([A-Za-z_0-9]+(?:<[^>]*>)?)", name)
     return m.group(1) if m else name
@@ -126,6 +139,7 @@ def main():
     out = {
         "command": a.command,
         "workload": {"name": a.name, "docs": a.docs, "terms": a.terms, "batch": a.batch, "limit": a.limit},
+        "source_hash": source_hash(),
         "fetch_size_calibration": calib,
         "fetch_size_factor": factor,
         "fetch_size_factor_source": factor_src,

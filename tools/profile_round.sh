@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 note() { echo "[profile_round $(date +%T)] $*"; }
 
 # (2) C3: kernel stats + counters.  8 steps = every one of the 4 rotated batches twice
-B="python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras"
+B="python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras --min-seconds 0"
 prof() { # prefix, workload args..., then the counters come from the caller
   name=$1; shift
   note "$name: kernel trace"
-  rocprofv3 --kernel-trace --stats -d "$out/${tag}_${name}_stats" -o run -- python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras "$@" \
+  rocprofv3 --kernel-trace --stats -d "$out/${tag}_${name}_stats" -o run -- python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras --min-seconds 0 "$@" \
       > "$sum/${tag}_${name}_bench_under_rocprof.json" 2> "$out/${tag}_${name}_stats.log"
 }
 pmc() { # name, dir suffix, counters..., -- workload args
@@ -25,7 +25,7 @@ pmc() { # name, dir suffix, counters..., -- workload args
   while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
   shift
   note "$name: pmc ${ctrs[*]}"
-  rocprofv3 --pmc "${ctrs[@]}" -d "$out/${tag}_${name}_pmc_${sfx}" -o run -- python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras "$@" \
+  rocprofv3 --pmc "${ctrs[@]}" -d "$out/${tag}_${name}_pmc_${sfx}" -o run -- python3 bench.py --steps 7 --warmup 1 --cpu-seconds 0 --no-extras --min-seconds 0 "$@" \
       > /dev/null 2> "$out/${tag}_${name}_pmc_${sfx}.log"
 }
 # PARTS=a: C3 + C2 + C4 + default limit + sparse ids + doc shards; PARTS=b: C5 (two gpurun calls of <= 20 min each)

@@ -35,7 +35,6 @@ if os.environ.get("STATS_SETS"):
     sets = {k: v for k, v in sets.items() if k in os.environ["STATS_SETS"].split(",")}
 L = N.lib()
 L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-L.nxsgpu_debug_stats_grid.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "redone", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
 names = ["waves", "tiles", "visits", "flushes", "pending", "emitted", "flush_cyc", "wave_cyc", "tile_w_sum", "lanes_in_visits", "overflows", "reg_chunks", "deep_chunks"]
 ALGO = N.TF_IDF if os.environ.get("STATS_TFIDF") else N.BM25
@@ -44,13 +43,8 @@ for name, qs in sets.items():
     idx.search_dev(plans, batch, k, ALGO, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     out = (C.c_ulonglong * 16)()
     L.nxsgpu_debug_stats(out, 1)
-    L.nxsgpu_debug_stats_grid(out, 1)
     idx.search_dev(plans, batch, k, ALGO, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr())
     L.nxsgpu_debug_stats(out, 1)
     v = dict(zip(names, list(out)))
     w = max(v["waves"], 1)
     print(name, {n: round(v[n] / w, 1) for n in names[1:]}, "waves", v["waves"], flush=True)
-    L.nxsgpu_debug_stats_grid(out, 1)
-    v = dict(zip(gnames, list(out)))
-    w = max(v["waves"], 1)
-    print(name, "grid", {n: round(v[n] / w, 1) for n in gnames[1:] if n != "-"}, "waves", v["waves"], flush=True)

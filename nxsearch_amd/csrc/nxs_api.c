@@ -1468,7 +1468,9 @@ plan_cache_destroy(struct plan_cache *pc)
 static struct plan_cache *
 plan_cache_get(nxs_index_t *idx)
 {
-	const uint64_t gen = idx->n_incremental + idx->n_rebuilds;
+	/* (the dictionary can move without either refresh counter moving -- a refresh whose device half fails
+	 * after sync_terms has consumed new terms --: what a lookup yields depends on the terms consumed) */
+	const uint64_t gen = idx->n_incremental + idx->n_rebuilds + ((uint64_t)idx->last_id << 20);
 	struct plan_cache *pc = idx->pcache;
 
 	if (!pc) {
@@ -1488,7 +1490,9 @@ plan_cache_get(nxs_index_t *idx)
 	if (pc->off) {
 		return NULL;
 	}
-	if (pc->gen != gen || pc->n > pc->cap / 2) {
+	if (pc->gen != gen || pc->n >= pc->cap / 2) {
+		/* (half full: start over -- plan_cache_put refuses inserts from there on, so without this the table
+		 * would stay frozen at its first 16 384 strings) */
 		plan_cache_clear(pc);
 		pc->gen = gen;
 	}
@@ -1890,6 +1894,8 @@ static int batch_end_core(nxs_index_t *, nxs_pend_t *, nxs_resp_t **, nxs_err_t 
 static int
 stash_inflight(nxs_index_t *idx)
 {
+	int failed = 0;
+
 	for (;;) {
 		nxs_pend_t *pd = NULL;
 
@@ -1900,17 +1906,34 @@ stash_inflight(nxs_index_t *idx)
 			}
 		}
 		if (!pd) {
-			return 0;
+			if (failed) {
+				nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
+			}
+			return failed;
 		}
 		pd->st_resps = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_resps));
 		pd->st_errs = calloc(pd->n ? pd->n : 1, sizeof(*pd->st_errs));
 		if (!pd->st_resps || !pd->st_errs) {
+			/*
+			 * No memory to keep the batch's outcome: the batch is given up (its _end reports the
+			 * error) but its device slot is still handed back HERE, in order -- a caller that goes on
+			 * to end a younger slot (abort_collective) must not find this one the oldest.
+			 */
 			free(pd->st_resps);
 			free(pd->st_errs);
 			pd->st_resps = NULL;
 			pd->st_errs = NULL;
-			nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "out of memory");
-			return -1;
+			if (pd->on_device) {
+				nxsgpu_batch_view_t v;
+				(void)nxsgpu_batch_end(idx->dev, &v);
+				pd->on_device = false;
+			}
+			pd->st_ret = -1;
+			pd->st_errcode = NXS_ERR_SYSTEM;
+			pd->st_errmsg = strdup("out of memory");
+			pd->stashed = true;
+			failed = -1;
+			continue;
 		}
 		pd->st_ret = batch_end_core(idx, pd, pd->st_resps, pd->st_errs);
 		pd->st_errcode = idx->nxs->errcode;
@@ -2291,10 +2314,12 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 		/* finished early by a later _begin (resync_before_batch): hand over */
 		nxs_clear_error(idx->nxs);
 		for (size_t i = 0; i < pd->n; i++) {
-			resps[i] = pd->st_resps[i];
-			pd->st_resps[i] = NULL;
+			resps[i] = pd->st_resps ? pd->st_resps[i] : NULL;
+			if (pd->st_resps) {
+				pd->st_resps[i] = NULL;
+			}
 			if (errs) {
-				errs[i] = pd->st_errs[i];
+				errs[i] = pd->st_errs ? pd->st_errs[i] : pd->st_errcode;
 			}
 		}
 		if (pd->st_errcode) {

@@ -1229,11 +1229,21 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	/* (queue D: a sharded batch's all-gather waits there for the batch's last replay -- on
 	 * queue B it would hold up the NEXT batch's dense-term class, queued behind it) */
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_down, hipStreamNonBlocking));
-	/* (at the highest stream priority the fuzzy passes finish sooner -- the host
-	 * waits 8-10 instead of 27-32 ms per C5 step for them -- but that wait is
-	 * hidden behind the device's 38 ms anyway, and the changed timing made one
-	 * query per step overflow its candidate lists: plain priority) */
-	HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
+	/*
+	 * The fuzzy passes of batch i + 1 run beside batch i's scans, and the HOST waits for them in _begin
+	 * (the plans need the resolved terms): at the highest stream priority their workgroups are dispatched
+	 * ahead of the scans' as CUs free up.  (Round 2 measured 8-10 instead of 27-32 ms of waiting per C5
+	 * step and left it off -- the wait was hidden behind 38 ms of device work then; since round 4 a C5 step
+	 * is 30 ms of which the host waits 24 for its fuzzy tokens.  NXS_GPU_FZ_NOPRIO: plain priority.)
+	 */
+	{
+		int lo_p = 0, hi_p = 0;
+		if (getenv("NXS_GPU_FZ_NOPRIO") || hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess ||
+		    hipStreamCreateWithPriority(&ix->stream_fz, hipStreamNonBlocking, hi_p) != hipSuccess) {
+			(void)hipGetLastError();
+			HIP_TRY(hipStreamCreateWithFlags(&ix->stream_fz, hipStreamNonBlocking));
+		}
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->xstream[2], hipStreamNonBlocking));
 	ix->stream_rp[0] = ix->stream3;		/* (the dense-term class does not exist for limits > 64) */
 	/* (queue C: MODE_BIG batches send their plans up on the scan stream, so nothing of theirs waits

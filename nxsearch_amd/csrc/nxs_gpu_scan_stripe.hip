@@ -516,7 +516,7 @@ k_scans(const scan_args_t A)
 	uint32_t ddv[NT];	/* ddel[] once more, in vector registers: the per-window select chain takes them as they are
 				 * (from scalar registers every select needs a copy first: four per window) */
 	int32_t w_ld = w_top + 1, j_ld = -1;
-	uint32_t rkv = fetch_dir(w_top), rk_next = fetch_dir(w_top - G);
+	uint32_t rkv = fetch_dir(w_top);
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
 		c[t] = dsel[t] = ddel[t] = 0;
@@ -533,8 +533,13 @@ k_scans(const scan_args_t A)
 			w_ld--;
 			j_ld++;
 			if (j_ld == G) {
-				rkv = rk_next;
-				rk_next = fetch_dir(w_ld - G);
+				/*
+				 * Loaded and used at once: one exposed load per G stripes.  (A copy requested G stripes
+				 * ahead cost more: the compiler shuffled it between registers at EVERY stripe, behind an
+				 * s_waitcnt vmcnt(0) that drained the window ring.  The asm keeps this a branch.)
+				 */
+				asm volatile("" ::: "memory");
+				rkv = fetch_dir(w_ld);
 				j_ld = 0;
 			}
 			uint32_t n = 0;
@@ -881,7 +886,6 @@ k_scans(const scan_args_t A)
 		w_ld = w_mark;
 		j_ld = -1;
 		rkv = fetch_dir(w_mark - 1);
-		rk_next = fetch_dir(w_mark - 1 - G);
 		n_ld = i0_ld = 0;
 		tw = ST_DOCS / 4;
 		wipe();

@@ -31,10 +31,6 @@ pmc() { # name, dir suffix, counters..., -- workload args
 # PARTS=a: C3 + C2 + C4 + default limit + sparse ids + doc shards; PARTS=b: C5 (two gpurun calls of <= 20 min each)
 PARTS=${PARTS:-ab}
 if [ "${PARTS#*a}" != "$PARTS" ]; then
-# (1) the driver's command, as the driver runs it
-note "default bench"
-python3 bench.py > "$sum/${tag}_bench.json" 2> "$out/${tag}_bench.err"
-
 prof c3
 pmc c3 fetch FETCH_SIZE --
 pmc c3 write WRITE_SIZE --
@@ -45,6 +41,11 @@ note "FETCH_SIZE calibration"
 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_calib" -o run -- python3 tools/pmc_calib.py > "$sum/${tag}_pmc_calib.json" 2> "$out/${tag}_pmc_calib.log"
 python3 tools/pmc_summary.py --stats "$out/${tag}_c3_stats" --pmc "$out/${tag}_c3_pmc_fetch" "$out/${tag}_c3_pmc_write" "$out/${tag}_c3_pmc_sq1" "$out/${tag}_c3_pmc_sq2" \
     --steps 8 --out-prefix "$sum/${tag}" --command "$B" --calib "$out/${tag}_pmc_calib" --calib-json "$sum/${tag}_pmc_calib.json"
+# (1) the driver's command, as the driver runs it -- AFTER the counters: its roofline.traffic comes from the summary just
+# made (stamped with the hash of the kernel sources: bench.py refuses a summary of other kernels)
+cp "$sum/${tag}_pmc_summary.json" profiles/ 2>/dev/null
+note "default bench"
+python3 bench.py > "$sum/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 
 # (3) the other configurations
 for w in C2 C4; do
@@ -56,6 +57,7 @@ for w in C2 C4; do
       --steps 8 --out-prefix "$sum/${tag}_${lw}" --command "$B --workload $w" --name $w \
       --docs $([ $w = C2 ] && echo 1000000 || echo 10000000) --terms $([ $w = C2 ] && echo 100000 || echo 1000000) \
       --calib "$out/${tag}_pmc_calib" --calib-json "$sum/${tag}_pmc_calib.json"
+  cp "$sum/${tag}_${lw}_pmc_summary.json" profiles/ 2>/dev/null
   python3 bench.py --workload $w --cpu-seconds 10 > "$sum/${tag}_${lw}_bench.json" 2>> "$out/${tag}_bench.err"
 done
 # C2 with the plan cache on (the loop's query strings repeat: planning becomes a hash lookup)
@@ -76,13 +78,14 @@ note "C5"
 if [ ! -d "$out/${tag}_pmc_calib" ]; then
   rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_pmc_calib" -o run -- python3 tools/pmc_calib.py > "$sum/${tag}_pmc_calib.json" 2> "$out/${tag}_pmc_calib.log"
 fi
-python3 bench.py --workload C5 --steps 8 --warmup 2 --cpu-seconds 10 --no-extras > "$sum/${tag}_c5_1gpu_bench.json" 2>> "$out/${tag}_bench.err"
 prof c5 --workload C5
 pmc c5 fetch FETCH_SIZE -- --workload C5
 pmc c5 write WRITE_SIZE -- --workload C5
 python3 tools/pmc_summary.py --stats "$out/${tag}_c5_stats" --pmc "$out/${tag}_c5_pmc_fetch" "$out/${tag}_c5_pmc_write" \
     --steps 8 --out-prefix "$sum/${tag}_c5" --command "$B --workload C5" --name C5 --docs 50000000 --terms 2000000 --batch 8192 \
     --calib "$out/${tag}_pmc_calib" --calib-json "$sum/${tag}_pmc_calib.json"
+cp "$sum/${tag}_c5_pmc_summary.json" profiles/ 2>/dev/null
+python3 bench.py --workload C5 --steps 8 --warmup 2 --cpu-seconds 10 --no-extras > "$sum/${tag}_c5_1gpu_bench.json" 2>> "$out/${tag}_bench.err"
 python3 bench.py --workload C5 --docshard 4 --steps 5 --warmup 1 --cpu-seconds 0 > "$sum/${tag}_docshard4_c5_bench.json" 2>> "$out/${tag}_bench.err"
 fi
 # the raw rocpd databases are ~10 MB each: gpurun merges at most 64 MiB back

@@ -266,6 +266,19 @@ int		nxsgpu_search_dev_end(nxsgpu_index_t *);
 int		nxsgpu_fuzzy(nxsgpu_index_t *, const uint8_t *tok_bytes,
 		    const uint32_t *tok_off, uint32_t n_tokens,
 		    uint32_t *term_ids, uint64_t *visited);
+/*
+ * The same search split in two (no visit counts): _begin queues the device pass on the fuzzy stream and
+ * returns a slot (>= 0; -1 error; -2 all NXSGPU_FZ_SLOTS slots taken), _end -- with the slot and the same
+ * tokens -- waits and delivers.  The host's planning of the NEXT batch and the scans of the batches in
+ * flight run meanwhile (nxs_api.c: a batch with misses is finished by the next
+ * nxs_index_search_batch_begin).  Passes run, and are to be ended, in the order they were begun;
+ * nxsgpu_fuzzy() refuses to run while one is in flight.
+ */
+#define	NXSGPU_FZ_SLOTS	2
+int		nxsgpu_fuzzy_begin(nxsgpu_index_t *, const uint8_t *tok_bytes,
+		    const uint32_t *tok_off, uint32_t n_tokens);
+int		nxsgpu_fuzzy_end(nxsgpu_index_t *, int slot, const uint8_t *tok_bytes,
+		    const uint32_t *tok_off, uint32_t n_tokens, uint32_t *term_ids);
 
 /*
  * ---- host batches as fixed-size records; query sharding over several GPUs ----

@@ -97,7 +97,7 @@ NXS_GPU_H_SYMBOLS = [
     "nxsgpu_index_destroy", "nxsgpu_index_df", "nxsgpu_index_postings",
     "nxsgpu_index_docs", "nxsgpu_index_first_bad_doc", "nxsgpu_search",
     "nxsgpu_results_free", "nxsgpu_search_dev", "nxsgpu_search_dev_begin",
-    "nxsgpu_search_dev_end", "nxsgpu_fuzzy",
+    "nxsgpu_search_dev_end", "nxsgpu_fuzzy", "nxsgpu_fuzzy_begin", "nxsgpu_fuzzy_end",
     "nxsgpu_set_profiling", "nxsgpu_get_profile", "nxsgpu_synchronize",
     "nxsgpu_search_wide", "nxsgpu_shard_slice", "nxsgpu_shard_capacity",
     "nxsgpu_comm_unique_id", "nxsgpu_comm_create", "nxsgpu_comm_destroy",
@@ -567,7 +567,7 @@ class Index:
 
     def host_profile(self):
         """nxs_index_host_profile(): per-batch host phase times in ms."""
-        out = (C.c_double * 8)()
+        out = (C.c_double * 12)()
         L = lib()
         L.nxs_index_host_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.nxs_index_host_profile(self._h, out)
@@ -575,6 +575,8 @@ class Index:
         return {"plan_ms": round(1e3 * out[0] / n, 4), "queue_ms": round(1e3 * out[1] / n, 4),
                 "wait_ms": round(1e3 * out[2] / n, 4), "resps_ms": round(1e3 * out[3] / n, 4),
                 "begin_ms": round(1e3 * out[6] / n, 4), "end_ms": round(1e3 * out[7] / n, 4),
+                "fuzzy_wait_ms": round(1e3 * out[8] / n, 4), "front_ms": round(1e3 * out[9] / n, 4),
+                "fuzzy_launch_ms": round(1e3 * out[10] / n, 4), "back_ms": round(1e3 * out[11] / n, 4),
                 "batches": int(out[4]), "exact_requeries": int(out[5])}
 
     def reconfigure(self):

@@ -1627,22 +1627,37 @@ plan_compile_chunk(void *arg, size_t lo, size_t hi)
 	}
 }
 
+/* the tokens of a batch that missed the dictionary, as one byte string (tokenizer.c:177-180) */
+typedef struct {
+	uint32_t *	q, *t, *off, *ids;	/* [n]: query, token index, byte offset, winner */
+	uint8_t *	bytes;
+	size_t		n;
+} fz_set_t;
+
+static void
+fz_set_free(fz_set_t *fz)
+{
+	free(fz->q);
+	free(fz->t);
+	free(fz->off);
+	free(fz->ids);
+	free(fz->bytes);
+	memset(fz, 0, sizeof(*fz));
+}
+
+/* parse + lookups (+ compile for the queries without misses) on the worker threads; the misses into *fz */
 static int
-plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
-    size_t n, qprep_t *prep)
+plan_front(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
+    size_t n, qprep_t *prep, fz_set_t *fz)
 {
 	nxs_t *nxs = idx->nxs;
 	struct nxs_pool *pool = n >= 64 ? nxs_pool_get(nxs) : NULL;
-	struct plan_cache *pc = plan_cache_get(idx);
-	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep, .pc = pc };
-	uint32_t *fz_q = NULL, *fz_t = NULL, *fz_off = NULL, *fz_ids = NULL;
-	uint8_t *fz_bytes = NULL;
-	size_t n_fz = 0, fz_len = 0;
-	int ret = -1;
+	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep, .pc = plan_cache_get(idx) };
+	size_t n_fz = 0, fz_len = 0, k = 0, o = 0;
 
+	memset(fz, 0, sizeof(*fz));
 	pool_run(pool, plan_parse_chunk, &job, n, 16);
 
-	/* one device BK-tree pass for every token that missed (tokenizer.c:177-180) */
 	for (size_t i = 0; sp->fuzzymatch && i < n; i++) {
 		const qprep_t *q = &prep[i];
 
@@ -1653,71 +1668,160 @@ plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queri
 			}
 		}
 	}
-	if (n_fz) {
-		size_t k = 0, o = 0;
-
-		fz_q = malloc(n_fz * sizeof(uint32_t));
-		fz_t = malloc(n_fz * sizeof(uint32_t));
-		fz_off = malloc((n_fz + 1) * sizeof(uint32_t));
-		fz_ids = calloc(n_fz, sizeof(uint32_t));
-		fz_bytes = malloc(fz_len + 1);
-		if (!fz_q || !fz_t || !fz_off || !fz_ids || !fz_bytes) {
-			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
-			goto out;
+	if (!n_fz) {
+		return 0;
+	}
+	fz->q = malloc(n_fz * sizeof(uint32_t));
+	fz->t = malloc(n_fz * sizeof(uint32_t));
+	fz->off = malloc((n_fz + 1) * sizeof(uint32_t));
+	fz->ids = calloc(n_fz, sizeof(uint32_t));
+	fz->bytes = malloc(fz_len + 16);
+	if (!fz->q || !fz->t || !fz->off || !fz->ids || !fz->bytes) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		fz_set_free(fz);
+		return -1;
+	}
+	for (size_t i = 0; i < n; i++) {
+		qprep_t *q = &prep[i];
+		if (q->errcode || q->compiled || q->cached) {
+			continue;
 		}
-		for (size_t i = 0; i < n; i++) {
-			qprep_t *q = &prep[i];
-			if (q->errcode || q->compiled || q->cached) {
+		for (size_t j = 0; j < q->n_tokens; j++) {
+			const qtok_t *t = &q->tokens[j];
+			if (t->term_id) {
 				continue;
 			}
-			for (size_t j = 0; j < q->n_tokens; j++) {
-				const qtok_t *t = &q->tokens[j];
-				if (t->term_id) {
-					continue;
-				}
-				fz_q[k] = (uint32_t)i;
-				fz_t[k] = (uint32_t)j;
-				fz_off[k] = (uint32_t)o;
-				memcpy(fz_bytes + o, t->value, t->len);
-				o += t->len;
-				k++;
-			}
-		}
-		fz_off[k] = (uint32_t)o;
-		if (nxs_index_bk_sync(idx) == -1) {
-			goto out;
-		}
-		if (nxsgpu_fuzzy(idx->dev, fz_bytes, fz_off, (uint32_t)n_fz, fz_ids, NULL) != 0) {
-			nxs_decl_err(nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s",
-			    nxsgpu_last_error());
-			goto out;
-		}
-		for (k = 0; k < n_fz; k++) {
-			prep[fz_q[k]].tokens[fz_t[k]].term_id = fz_ids[k];
+			fz->q[k] = (uint32_t)i;
+			fz->t[k] = (uint32_t)j;
+			fz->off[k] = (uint32_t)o;
+			memcpy(fz->bytes + o, t->value, t->len);
+			o += t->len;
+			k++;
 		}
 	}
-	bool second = n_fz != 0;
+	fz->off[k] = (uint32_t)o;
+	fz->n = n_fz;
+	return 0;
+}
+
+/* the winners into the token lists, the remaining queries compiled, the batch's new plans into the cache */
+static void
+plan_back(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
+    size_t n, qprep_t *prep, const fz_set_t *fz)
+{
+	struct nxs_pool *pool = n >= 64 ? nxs_pool_get(idx->nxs) : NULL;
+	struct plan_cache *pc = plan_cache_get(idx);
+	plan_job_t job = { .idx = idx, .sp = sp, .queries = queries, .prep = prep, .pc = pc };
+	bool second = fz->n != 0;
+
+	for (size_t k = 0; k < fz->n; k++) {
+		prep[fz->q[k]].tokens[fz->t[k]].term_id = fz->ids[k];
+	}
 	for (size_t i = 0; !second && i < n; i++) {
 		second = !prep[i].cached && !prep[i].compiled;
 	}
 	if (second) {
 		pool_run(pool, plan_compile_chunk, &job, n, 32);
 	}
-	/* the batch's new plans into the cache (this thread only) */
+	/* (this thread only; a query whose string is not at hand -- the late half keeps only the strings it
+	 * still has to compile -- was put there by the first half's caller or is not cached) */
 	for (size_t i = 0; pc && i < n; i++) {
 		const qprep_t *q = &prep[i];
-		if (!q->cached && !q->errcode && !q->wide) {
+		if (queries[i] && !q->cached && !q->errcode && !q->wide) {
 			plan_cache_put(pc, queries[i], strlen(queries[i]), sp->fuzzymatch, q);
 		}
 	}
+}
+
+static int late_finish(nxs_index_t *);
+
+static int
+plan_batch(nxs_index_t *idx, const search_params_t *sp, const char *const *queries,
+    size_t n, qprep_t *prep)
+{
+	fz_set_t fz;
+	int ret = -1;
+
+	if (plan_front(idx, sp, queries, n, prep, &fz) == -1) {
+		return -1;
+	}
+	if (fz.n) {
+		/* one device BK-tree pass for every token that missed */
+		(void)late_finish(idx);		/* (a batch whose own pass is still on the device: one pass at a time) */
+		if (nxs_index_bk_sync(idx) == -1) {
+			goto out;
+		}
+		if (nxsgpu_fuzzy(idx->dev, fz.bytes, fz.off, (uint32_t)fz.n, fz.ids, NULL) != 0) {
+			nxs_decl_err(idx->nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s",
+			    nxsgpu_last_error());
+			goto out;
+		}
+	}
+	plan_back(idx, sp, queries, n, prep, &fz);
 	ret = 0;
 out:
-	free(fz_q);
-	free(fz_t);
-	free(fz_off);
-	free(fz_ids);
-	free(fz_bytes);
+	fz_set_free(&fz);
 	return ret;
+}
+
+/*
+ * tokenizer.c:177-180 resolves a miss where it meets it; here a batch's misses are one device pass, and
+ * _begin does not wait for it: it returns once the pass is queued, and the batch's second half runs
+ * when the host comes by again (late_finish) -- the pass has had the caller's work on the previous
+ * responses and the next batch's parse to finish in.  What the second half needs is kept here.
+ */
+struct late_half {
+	search_params_t	sp;
+	fz_set_t	fz;
+	int		slot;		/* nxsgpu_fuzzy_begin's */
+	bool		collected;	/* the pass is over, fz.ids hold the winners */
+	char *		qbuf;		/* the strings still to compile (the caller's may be gone by then) */
+	const char **	queries;	/* [hi - lo]: into qbuf; NULL = nothing left to do for that query */
+};
+
+static void
+late_free(struct late_half *lh)
+{
+	if (lh) {
+		fz_set_free(&lh->fz);
+		free(lh->qbuf);
+		free(lh->queries);
+		free(lh);
+	}
+}
+
+static struct late_half *
+late_make(const search_params_t *sp, fz_set_t *fz, const char *const *queries, size_t n, const qprep_t *prep)
+{
+	struct late_half *lh = calloc(1, sizeof(*lh));
+	size_t total = 0, o = 0;
+
+	if (!lh) {
+		return NULL;
+	}
+	lh->sp = *sp;
+	for (size_t i = 0; i < n; i++) {
+		if (!prep[i].cached && !prep[i].compiled && !prep[i].errcode) {
+			total += strlen(queries[i]) + 1;
+		}
+	}
+	lh->queries = calloc(n ? n : 1, sizeof(*lh->queries));
+	lh->qbuf = malloc(total ? total : 1);
+	if (!lh->queries || !lh->qbuf) {
+		late_free(lh);
+		return NULL;
+	}
+	for (size_t i = 0; i < n; i++) {
+		if (!prep[i].cached && !prep[i].compiled && !prep[i].errcode) {
+			const size_t l = strlen(queries[i]) + 1;
+			memcpy(lh->qbuf + o, queries[i], l);
+			lh->queries[i] = lh->qbuf + o;
+			o += l;
+		}
+	}
+	lh->fz = *fz;			/* (moved) */
+	memset(fz, 0, sizeof(*fz));
+	return lh;
 }
 
 int
@@ -1786,11 +1890,17 @@ now_s(void)
  * Where the host's time goes, summed over the batches so far: out[0] parse +
  * resolve + compile (worker pool), out[1] queueing the batch on the device
  * (work list, staging, launches), out[2] waiting for the device, out[3]
- * building the responses; out[4] = batches.  Reset on read.
+ * building the responses; out[4] = batches; out[8] = the part of out[0] spent waiting for the device's
+ * fuzzy pass.  Reset on read.
  */
 void
-nxs_index_host_profile(nxs_index_t *idx, double out[8])
+nxs_index_host_profile(nxs_index_t *idx, double out[12])
 {
+	out[8] = idx->hp_fzwait;	/* of out[0]: waiting for the device's fuzzy pass, */
+	out[9] = idx->hp_front;		/* parse + lookups (+ compile of the queries without misses), */
+	out[10] = idx->hp_fzlaunch;	/* queueing the fuzzy pass, */
+	out[11] = idx->hp_back;		/* winners into the plans + compile of the rest */
+	idx->hp_fzwait = idx->hp_front = idx->hp_fzlaunch = idx->hp_back = 0;
 	out[6] = idx->hp_begin;		/* whole _begin() / _end() calls */
 	out[7] = idx->hp_end;
 	idx->hp_begin = idx->hp_end = 0;
@@ -1866,6 +1976,7 @@ pend_release(nxs_pend_t *p)
 		nxs_query_release(&p->prep[i]);
 	}
 	free(p->prep);
+	late_free(p->late);
 	for (size_t i = 0; p->st_resps && i < p->n; i++) {
 		if (p->st_resps[i]) {		/* stashed and never collected */
 			nxs_resp_release(p->st_resps[i]);
@@ -1895,6 +2006,8 @@ static int
 stash_inflight(nxs_index_t *idx)
 {
 	int failed = 0;
+
+	(void)late_finish(idx);		/* (a failure is that batch's: kept in its slot) */
 
 	for (;;) {
 		nxs_pend_t *pd = NULL;
@@ -1987,6 +2100,9 @@ index_drain(nxs_index_t *idx)
 {
 	nxs_pend_t *pd;
 
+	if (idx->dev) {
+		(void)late_finish(idx);
+	}
 	while ((pd = pend_oldest(idx)) != NULL) {
 		nxsgpu_batch_view_t v;
 
@@ -1997,6 +2113,152 @@ index_drain(nxs_index_t *idx)
 	}
 }
 
+/* the planned batch (record path: limit <= NXSGPU_BIG_K) onto the device; 0, or -1 with the error declared */
+static int
+queue_on_device(nxs_index_t *idx, nxs_pend_t *pd, const search_params_t *sp, bool collective)
+{
+	nxs_t *nxs = idx->nxs;
+	const size_t nl = pd->hi - pd->lo;
+	nxsgpu_query_t *plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
+	uint32_t *slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
+	uint32_t *status = calloc(NXSGPU_STATUS_WORDS(pd->cap), sizeof(uint32_t));
+	size_t n_plans = 0;
+	int ret = -1;
+
+	if (!plans || !slot_of || !status) {
+		nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+		goto out;
+	}
+	for (size_t i = 0; i < nl; i++) {
+		const qprep_t *q = &pd->prep[i];
+
+		if (q->errcode) {
+			status[i] = q->errcode;
+		} else if (q->wide) {
+			status[i] = STATUS_HOSTPATH;
+		} else if (!q->empty) {
+			slot_of[n_plans] = (uint32_t)i;
+			plans[n_plans++] = q->plan;
+		}
+	}
+	if (collective && nxs_index_changed(idx)) {
+		/* a batch is in flight (else resync_before_batch refreshed just now): tell
+		 * the peers, all ranks drain and re-sync together */
+		status[pd->cap] = NXSGPU_BLOCK_CHANGED;
+	}
+	/* the worker threads are lent for THIS call only (the pool takes one run at a time: the doc-shard
+	 * entry runs a host thread per shard through the same device layer and must never find it set) */
+	nxsgpu_index_set_parallel(idx->dev, api_parallel, nxs);
+	const int brc = nxsgpu_batch_begin(idx->dev, sp->algo, (uint32_t)sp->limit, plans,
+	    (uint32_t)n_plans, slot_of, status, pd->cap,
+	    idx->comm != NULL && pd->world >= 1 && !idx->emu_world);
+	nxsgpu_index_set_parallel(idx->dev, NULL, NULL);
+	if (brc != 0) {
+		nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s", nxsgpu_last_error());
+		goto out;
+	}
+	pd->on_device = true;
+	ret = 0;
+out:
+	free(plans);
+	free(slot_of);
+	free(status);
+	return ret;
+}
+
+/*
+ * The second half of a batch whose fuzzy pass was left running (struct late_half), in two steps: COLLECT
+ * waits for the pass and takes its winners (the fuzzy workspaces are free again: the next batch's pass can
+ * be queued), COMPLETE finishes the plans and queues the batch.  The batch's _begin has long returned
+ * success, so a failure here is kept in the batch's slot for its _end (like a batch finished early by a
+ * re-sync).
+ */
+static nxs_pend_t *
+late_oldest(nxs_index_t *idx)
+{
+	nxs_pend_t *pd = NULL;
+
+	for (int i = 0; i < NXSGPU_INFLIGHT; i++) {
+		nxs_pend_t *c = &idx->pend[i];
+		if (c->active && c->late && (!pd || c->seq < pd->seq)) {
+			pd = c;
+		}
+	}
+	return pd;
+}
+
+static void
+late_failed(nxs_index_t *idx, nxs_pend_t *pd)
+{
+	nxs_t *nxs = idx->nxs;
+
+	pd->st_ret = -1;
+	pd->st_errcode = nxs->errcode ? nxs->errcode : NXS_ERR_FATAL;
+	pd->st_errmsg = nxs->errmsg ? strdup(nxs->errmsg) : NULL;
+	pd->stashed = true;
+	nxs_clear_error(nxs);
+	late_free(pd->late);
+	pd->late = NULL;
+}
+
+static int
+late_collect(nxs_index_t *idx, nxs_pend_t *pd)
+{
+	struct late_half *lh = pd->late;
+	const double t0 = now_s();
+
+	if (lh->collected) {
+		return 0;
+	}
+	if (nxsgpu_fuzzy_end(idx->dev, lh->slot, lh->fz.bytes, lh->fz.off, (uint32_t)lh->fz.n, lh->fz.ids) != 0) {
+		nxs_decl_err(idx->nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s", nxsgpu_last_error());
+		late_failed(idx, pd);
+		return -1;
+	}
+	lh->collected = true;
+	idx->hp_fzwait += now_s() - t0;
+	idx->hp_plan += now_s() - t0;
+	return 0;
+}
+
+static int
+late_complete(nxs_index_t *idx, nxs_pend_t *pd)
+{
+	struct late_half *lh = pd->late;
+	const double t0 = now_s();
+	double t1;
+
+	plan_back(idx, &lh->sp, lh->queries, pd->hi - pd->lo, pd->prep, &lh->fz);
+	t1 = now_s();
+	idx->hp_back += t1 - t0;
+	idx->hp_plan += t1 - t0;
+	if ((idx->test_fail_late && idx->test_fail_late-- == 1 &&
+	    (nxs_decl_err(idx->nxs, NXS_ERR_SYSTEM, "injected failure in the late half (test)"), true)) ||
+	    queue_on_device(idx, pd, &lh->sp, false) != 0) {
+		late_failed(idx, pd);
+		return -1;
+	}
+	idx->hp_queue += now_s() - t1;
+	late_free(lh);
+	pd->late = NULL;
+	return 0;
+}
+
+/* every late batch, oldest first (0: nothing to do, or all went well) */
+static int
+late_finish(nxs_index_t *idx)
+{
+	nxs_pend_t *pd;
+	int ret = 0;
+
+	while ((pd = late_oldest(idx)) != NULL) {
+		if (late_collect(idx, pd) != 0 || late_complete(idx, pd) != 0) {
+			ret = -1;
+		}
+	}
+	return ret;
+}
+
 int
 nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
     const char *const *queries, size_t n)
@@ -2004,12 +2266,13 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	nxs_t *nxs = idx->nxs;
 	nxs_pend_t *pd = NULL;
 	search_params_t sp;
-	nxsgpu_query_t *plans = NULL;
-	uint32_t *slot_of = NULL, *status = NULL;
+	uint32_t *status = NULL;
 	uint64_t lo = 0, hi = n;
-	size_t n_plans = 0, nl;
+	size_t nl;
 	double t0, t1 = 0;
 	const double t_in = now_s();
+	fz_set_t fz = { 0 };
+	nxs_pend_t *old;
 	int ret = -1;
 
 	nxs_clear_error(nxs);
@@ -2067,60 +2330,116 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 		goto out;
 	}
 	t0 = now_s();
-	if (plan_batch(idx, &sp, queries + lo, nl, pd->prep) == -1 ||
+	if (plan_front(idx, &sp, queries + lo, nl, pd->prep, &fz) == -1 ||
 	    (idx->test_fail_begin && idx->test_fail_begin-- == 1 &&
 	    (nxs_decl_err(nxs, NXS_ERR_SYSTEM, "injected failure (test)"), true))) {
+		(void)late_finish(idx);
 		if (collective) {
 			goto abort_collective;
 		}
 		goto out;
 	}
 	t1 = now_s();
+	idx->hp_front += t1 - t0;
 	idx->hp_plan += t1 - t0;
-	if (sp.limit <= NXSGPU_BIG_K) {
-		plans = malloc((nl ? nl : 1) * sizeof(nxsgpu_query_t));
-		slot_of = malloc((nl ? nl : 1) * sizeof(uint32_t));
-		status = calloc(NXSGPU_STATUS_WORDS(pd->cap), sizeof(uint32_t));
-		if (!plans || !slot_of || !status) {
-			nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+	/*
+	 * The batch before this one may still lack its second half: its fuzzy pass has had the time since its
+	 * _begin returned (the caller's work, this batch's parse).  THIS batch's pass is queued first (the
+	 * device layer has two sets of fuzzy workspaces; the passes run in order), then the older batch's
+	 * winners are collected, its plans compiled and the batch sent to the device -- it still goes there
+	 * before this one.  A failure of the older batch is its own (reported by its _end).
+	 */
+	old = late_oldest(idx);
+	t0 = now_s();
+	if (fz.n) {
+		if (!idx->late_mode) {
+			const char *e = getenv("NXS_LATE_FUZZY");	/* (once per index: the query path reads no environment) */
+			idx->late_mode = e && atoi(e) == 0 ? 2 : 1;
+		}
+		/* (sharded batches, doc shards and limits beyond the record path wait for the pass here: their
+		 * failure paths are collectives of their own) */
+		const bool late = idx->late_mode == 1 && !collective && !idx->comm && !idx->emu_world &&
+		    !idx->n_shards && sp.limit <= NXSGPU_BIG_K;
+		struct late_half *lh = NULL;
+		bool failed;
+
+		if (old && (!late || idx->bk_upto != idx->last_id || idx->bk_flags_stale)) {
+			/* (the BK-tree image is about to be replaced, or this batch's pass runs at once:
+			 * nothing of the older batch's may be on the device then) */
+			(void)late_finish(idx);
+			old = NULL;
+			t0 = now_s();
+		}
+		failed = nxs_index_bk_sync(idx) == -1;
+		if (!failed && late) {
+			if ((lh = late_make(&sp, &fz, queries + lo, nl, pd->prep)) == NULL) {
+				nxs_decl_err(nxs, NXS_ERR_SYSTEM, "out of memory");
+				failed = true;
+			} else if ((lh->slot = nxsgpu_fuzzy_begin(idx->dev, lh->fz.bytes, lh->fz.off, (uint32_t)lh->fz.n)) < 0) {
+				nxs_decl_err(nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s", nxsgpu_last_error());
+				late_free(lh);
+				lh = NULL;
+				failed = true;
+			}
+		}
+		idx->hp_fzlaunch += now_s() - t0;
+		idx->hp_plan += now_s() - t0;
+		if (old) {
+			/* (its failure would wipe this batch's error slot: kept aside) */
+			const nxs_err_t code = nxs->errcode;
+			char *msg = failed && nxs->errmsg ? strdup(nxs->errmsg) : NULL;
+
+			if (late_collect(idx, old) == 0) {
+				(void)late_complete(idx, old);
+			}
+			old = NULL;
+			if (failed) {
+				nxs_decl_err(nxs, code ? code : NXS_ERR_FATAL, "%s", msg ? msg : "");
+			}
+			free(msg);
+		}
+		if (failed) {
 			if (collective) {
 				goto abort_collective;
 			}
 			goto out;
 		}
-		for (size_t i = 0; i < nl; i++) {
-			const qprep_t *q = &pd->prep[i];
-
-			if (q->errcode) {
-				status[i] = q->errcode;
-			} else if (q->wide) {
-				status[i] = STATUS_HOSTPATH;
-			} else if (!q->empty) {
-				slot_of[n_plans] = (uint32_t)i;
-				plans[n_plans++] = q->plan;
+		if (lh) {
+			pd->late = lh;
+			idx->hp_batches++;
+			idx->hp_begin += now_s() - t_in;
+			pd->seq = ++idx->pend_seq;
+			pd->active = true;
+			ret = 0;
+			goto out;
+		}
+		t0 = now_s();
+		if (nxsgpu_fuzzy(idx->dev, fz.bytes, fz.off, (uint32_t)fz.n, fz.ids, NULL) != 0) {
+			nxs_decl_err(nxs, NXS_ERR_FATAL, "device fuzzy search failed: %s", nxsgpu_last_error());
+			if (collective) {
+				goto abort_collective;
 			}
+			goto out;
 		}
-		if (collective && nxs_index_changed(idx)) {
-			/* a batch is in flight (else resync_before_batch refreshed just now): tell
-			 * the peers, all ranks drain and re-sync together */
-			status[pd->cap] = NXSGPU_BLOCK_CHANGED;
-		}
-		/* the worker threads are lent for THIS call only (the pool takes one run at a time: the doc-shard
-		 * entry runs a host thread per shard through the same device layer and must never find it set) */
-		nxsgpu_index_set_parallel(idx->dev, api_parallel, nxs);
-		const int brc = nxsgpu_batch_begin(idx->dev, sp.algo, (uint32_t)sp.limit, plans,
-		    (uint32_t)n_plans, slot_of, status, pd->cap,
-		    idx->comm != NULL && pd->world >= 1 && !idx->emu_world);
-		nxsgpu_index_set_parallel(idx->dev, NULL, NULL);
-		if (brc != 0) {
-			nxs_decl_err(nxs, NXS_ERR_FATAL, "device search failed: %s",
-			    nxsgpu_last_error());
+		idx->hp_fzwait += now_s() - t0;
+	}
+	if (old && late_collect(idx, old) == 0) {
+		(void)late_complete(idx, old);
+	}
+	t1 = now_s();
+	plan_back(idx, &sp, queries + lo, nl, pd->prep, &fz);
+	idx->hp_back += now_s() - t1;
+	t1 = now_s();
+	idx->hp_plan += t1 - t0;
+	if (sp.limit <= NXSGPU_BIG_K) {
+		const int qrc = queue_on_device(idx, pd, &sp, collective);
+
+		if (qrc != 0) {
 			if (collective) {
 				goto abort_collective;	/* (an empty block may still go up) */
 			}
 			goto out;
 		}
-		pd->on_device = true;
 	}
 	idx->hp_queue += now_s() - t1;
 	idx->hp_batches++;
@@ -2129,8 +2448,7 @@ nxs_index_search_batch_begin(nxs_index_t *idx, nxs_params_t *params,
 	pd->active = true;
 	ret = 0;
 out:
-	free(plans);
-	free(slot_of);
+	fz_set_free(&fz);
 	free(status);
 	if (ret != 0) {
 		pend_release(pd);
@@ -2309,6 +2627,9 @@ nxs_index_search_batch_end(nxs_index_t *idx, nxs_resp_t **resps, nxs_err_t *errs
 		nxs_clear_error(idx->nxs);
 		nxs_decl_err(idx->nxs, NXS_ERR_INVALID, "no batch in flight");
 		return -1;
+	}
+	if (pd->late) {
+		(void)late_finish(idx);		/* (no later _begin came by: the second half runs here) */
 	}
 	if (pd->stashed) {
 		/* finished early by a later _begin (resync_before_batch): hand over */
@@ -3427,7 +3748,7 @@ nxs_test_pack_abort(uint8_t *block, uint32_t n_slots, uint32_t k, uint32_t code)
 }
 
 /* the n-th next _begin (which = 0) / exact fix-up round (1) of the index fails; 2: the n-th next
- * fix-up round finds no memory for its receive buffer */
+ * fix-up round finds no memory for its receive buffer; 3: the n-th next late second half (late_complete) fails */
 void
 nxs_test_inject_failure(nxs_index_t *idx, int which, unsigned nth)
 {
@@ -3435,6 +3756,8 @@ nxs_test_inject_failure(nxs_index_t *idx, int which, unsigned nth)
 		idx->test_fail_begin = nth;
 	} else if (which == 1) {
 		idx->test_fail_fixup = nth;
+	} else if (which == 3) {
+		idx->test_fail_late = nth;
 	} else {
 		idx->test_fail_fixup_recv = nth;
 	}

@@ -653,14 +653,15 @@ bk_aux_build(nxsgpu_index_t *ix, const nxsgpu_bknode_t *nodes, uint32_t n)
 /* ---- fuzzy ----------------------------------------------------------- */
 
 /*
- * Match-first search of all tokens at once (tokens of <= 64 bytes only).
- * 0 = term_ids filled, 1 = a queue overflowed (the caller takes the
- * level-by-level search), -1 = error.
+ * Match-first search of all tokens at once (tokens of <= 64 bytes only), in two halves: mf_launch
+ * queues the upload, the kernels and the copy back on stream_fz and returns (0 / -1); mf_finish waits
+ * for them: 0 = term_ids filled, 1 = a queue overflowed (the caller takes the level-by-level
+ * search), -1 = error.  Between the two the pass owns the fuzzy workspaces (fz, fz_pin).
  */
 static int
-fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok,
-    uint32_t *term_ids)
+mf_launch(nxsgpu_index_t *ix, int slot, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok)
 {
+	nxsgpu_index::fz_slot_t &sl = ix->fzs[slot];
 	const uint32_t n_c = ix->n_fz;
 	const uint32_t blen = tok_off[n_tok] - tok_off[0];
 	/* FZ_NQ sub-queues of qcap survivors each */
@@ -674,7 +675,6 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	const uint64_t mcap = std::max<uint64_t>(1024, ccap / 4);
 	const size_t need = 16384 + FZ_NQ * FZ_CSTRIDE * 4 + (ccap + mcap) * sizeof(fz_item_t) + (size_t)n_tok * (256 * 8 + 8 + 4 + 4 + 4) + 64 + blen + 16 +
 	    ((size_t)n_tok + 1) * 4 + (NXS_MYERS_MAXPAT + 4) * 4 + 16 * 256 + 256;
-	std::vector<uint32_t> h_qcnt(FZ_NQ * FZ_CSTRIDE);
 	/* ONE upload from pinned memory -- token offsets, rank of every token in the length-sorted order, first
 	 * rank of every length, then the tokens' bytes -- and ONE copy back (term ids, counters, evaluation counts):
 	 * a copy to or from pageable memory is staged by the runtime and costs the host 20-40 us apiece, and the
@@ -682,36 +682,37 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	const size_t up_words = (size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2;
 	const size_t up_bytes = (up_words * 4 + 15) & ~(size_t)15;
 	const size_t dn_bytes = ((size_t)n_tok * 4 + 15 & ~(size_t)15) + 16 + 16;
-	const size_t pin_need = up_bytes + blen + 16 + dn_bytes + 64;
-	if (ix->fz_pin_len < pin_need) {
-		if (ix->fz_pin) {
-			(void)hipHostFree(ix->fz_pin);
-			ix->fz_pin = NULL;
-			ix->fz_pin_len = 0;
+	const size_t qcnt_bytes = (size_t)FZ_NQ * FZ_CSTRIDE * 4;	/* (copied back with the rest when profiling) */
+	const size_t pin_need = up_bytes + blen + 16 + dn_bytes + qcnt_bytes + 64;
+	if (sl.pin_len < pin_need) {
+		if (sl.pin) {
+			(void)hipHostFree(sl.pin);
+			sl.pin = NULL;
+			sl.pin_len = 0;
 		}
-		if (hipHostMalloc((void **)&ix->fz_pin, pin_need + pin_need / 2, hipHostMallocDefault) != hipSuccess) {
+		if (hipHostMalloc((void **)&sl.pin, pin_need + pin_need / 2, hipHostMallocDefault) != hipSuccess) {
 			set_error("hipHostMalloc(%zu) for the fuzzy staging failed", pin_need);
 			return -1;
 		}
-		ix->fz_pin_len = pin_need + pin_need / 2;
+		sl.pin_len = pin_need + pin_need / 2;
 	}
-	uint32_t *const up = (uint32_t *)ix->fz_pin;
-	uint8_t *const h_dn = ix->fz_pin + up_bytes + ((blen + 16 + 15) & ~(size_t)15);
+	uint32_t *const up = (uint32_t *)sl.pin;
+	uint8_t *const h_dn = sl.pin + up_bytes + ((blen + 16 + 15) & ~(size_t)15);
 	uint32_t *roff = up, *rank = roff + n_tok + 1, *len_off = rank + n_tok;
 
-	if (ix->fz_len < need) {
-		if (ix->fz) {
-			(void)hipFree(ix->fz);
-			ix->fz = NULL;
-			ix->fz_len = 0;
+	if (sl.ws_len < need) {
+		if (sl.ws) {
+			(void)hipFree(sl.ws);
+			sl.ws = NULL;
+			sl.ws_len = 0;
 		}
-		if (hipMalloc(&ix->fz, need) != hipSuccess) {
+		if (hipMalloc(&sl.ws, need) != hipSuccess) {
 			set_error("hipMalloc(%zu) for the fuzzy workspace failed", need);
 			return -1;
 		}
-		ix->fz_len = need;
+		sl.ws_len = need;
 	}
-	uint8_t *p = (uint8_t *)ix->fz;
+	uint8_t *p = (uint8_t *)sl.ws;
 	fz_item_t *d_cand = carve<fz_item_t>(p, ccap);
 	fz_item_t *d_match = carve<fz_item_t>(p, mcap);
 	/* (what comes back, in one piece: term ids | counters | evaluation counts; the sub-queue counters behind
@@ -732,6 +733,14 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	hipStream_t st = ix->stream_fz;
 	fz_args_t fa;
 
+#ifdef NXS_DBG_FZT
+	static double acc[8]; static int ncall;
+	auto nowd = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+	double tt = nowd();
+#define FZT(i) do { double n_ = nowd(); acc[i] += n_ - tt; tt = n_; } while (0)
+#else
+#define FZT(i) do { } while (0)
+#endif
 	for (uint32_t i = 0; i <= n_tok; i++) {
 		roff[i] = tok_off[i] - tok_off[0];
 	}
@@ -751,14 +760,20 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 			rank[i] = next[roff[i + 1] - roff[i]]++;
 		}
 	}
-	memcpy(ix->fz_pin + up_bytes, tok_bytes + tok_off[0], blen);
-	if (hipMemcpyAsync(d_upb, ix->fz_pin, up_bytes + blen, hipMemcpyHostToDevice, st) != hipSuccess ||
-	    hipMemsetAsync(d_cnt, 0, 16 + 16 + FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
+	memcpy(sl.pin + up_bytes, tok_bytes + tok_off[0], blen);
+	FZT(0);
+	if (hipMemcpyAsync(d_upb, sl.pin, up_bytes + blen, hipMemcpyHostToDevice, st) != hipSuccess) {
+		set_error("fuzzy upload failed");
+		return -1;
+	}
+	FZT(1);
+	if (hipMemsetAsync(d_cnt, 0, 16 + 16 + FZ_NQ * FZ_CSTRIDE * 4, st) != hipSuccess ||
 	    hipMemsetAsync(d_tokf + n_tok, 0xff, 4 * sizeof(uint2), st) != hipSuccess) {
 		set_error("fuzzy upload failed");
 		return -1;
 	}
-	if (ix->profiling) (void)hipEventRecord(ix->ev[0], st);
+	FZT(2);
+	if (ix->profiling) (void)hipEventRecord(sl.ev[0], st);
 	hipLaunchKernelGGL(k_bk_peq, dim3(n_tok), dim3(256), 0, st, d_bytes, d_off, n_tok, d_peq, d_tokf, d_rank);
 	hipLaunchKernelGGL(k_bk_seed, dim3((n_tok + 255) / 256), dim3(256), 0, st, d_cand, d_cnt + 3, n_tok, d_best,
 	    (unsigned long long *)NULL);
@@ -767,7 +782,7 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 		    ix->d_fz_sig, ix->d_fz_node, ix->d_fz_len, n_c, d_tokf, d_len_off, d_cand, d_qcnt,
 		    (uint32_t)qcap, d_cnt + 2);
 	}
-	if (ix->profiling) (void)hipEventRecord(ix->ev[2], st);
+	if (ix->profiling) (void)hipEventRecord(sl.ev[2], st);
 	memset(&fa, 0, sizeof(fa));
 	fa.bk = ix->d_bk;
 	fa.bk_bytes = ix->d_bk_bytes;
@@ -781,18 +796,47 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	fa.evals = ix->profiling ? d_evals : NULL;
 	hipLaunchKernelGGL(k_fz_dist, dim3(8, FZ_NQ), dim3(1024), 0, st, fa, d_cand, d_qcnt, (uint32_t)qcap, d_match, d_cnt + 1,
 	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
-	if (ix->profiling) (void)hipEventRecord(ix->ev[3], st);
+	if (ix->profiling) (void)hipEventRecord(sl.ev[3], st);
 	hipLaunchKernelGGL(k_fz_chain, dim3(1024), dim3(256), 0, st, fa, ix->d_bk_parent, ix->d_bk_slot, d_match, d_cnt + 1,
 	    (uint32_t)std::min<uint64_t>(mcap, 0xffffffffu));
 	hipLaunchKernelGGL(k_bk_finish, dim3((n_tok + 255) / 256), dim3(256), 0, st, ix->d_bk, d_best, n_tok, d_tids);
-	if (ix->profiling) (void)hipEventRecord(ix->ev[1], st);
+	if (ix->profiling) (void)hipEventRecord(sl.ev[1], st);
 	if (hipGetLastError() != hipSuccess) {
 		set_error("fuzzy kernel launch failed");
 		return -1;
 	}
-	if (hipMemcpyAsync(h_dn, d_dn, dn_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
-	    (ix->profiling && hipMemcpyAsync(h_qcnt.data(), d_qcnt, h_qcnt.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-	    hipStreamSynchronize(st) != hipSuccess) {
+	FZT(3);
+#ifdef NXS_DBG_FZT
+	if (++ncall % 200 == 0) fprintf(stderr, "fzt host %.1f up %.1f memset %.1f kernels %.1f us (prof %d)\n", 1e6*acc[0]/ncall, 1e6*acc[1]/ncall, 1e6*acc[2]/ncall, 1e6*acc[3]/ncall, (int)ix->profiling);
+#endif
+	/* (one copy into PINNED memory: a copy to pageable memory makes the call wait for the stream) */
+	if (hipMemcpyAsync(h_dn, d_dn, dn_bytes + (ix->profiling ? qcnt_bytes : 0), hipMemcpyDeviceToHost, st) != hipSuccess) {
+		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	/* (the pass's own end: another pass may be queued behind it on the stream before this one is waited for) */
+	if (hipEventRecord(sl.ev_done, st) != hipSuccess) {
+		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	return 0;
+}
+
+static int
+mf_finish(nxsgpu_index_t *ix, int slot, uint32_t n_tok, uint32_t *term_ids)
+{
+	nxsgpu_index::fz_slot_t &sl = ix->fzs[slot];
+	/* (the staging layout of mf_launch) */
+	const uint32_t n_c = ix->n_fz;
+	const size_t up_words = (size_t)n_tok + 1 + n_tok + NXS_MYERS_MAXPAT + 2;
+	const size_t up_bytes = (up_words * 4 + 15) & ~(size_t)15;
+	const uint32_t *const len_off = (const uint32_t *)sl.pin + n_tok + 1 + n_tok;
+	const uint32_t blen = ((const uint32_t *)sl.pin)[n_tok];
+	const uint8_t *const h_dn = sl.pin + up_bytes + ((blen + 16 + 15) & ~(size_t)15);
+	const size_t dn_bytes = ((size_t)n_tok * 4 + 15 & ~(size_t)15) + 16 + 16;
+	const uint32_t *const h_qcnt = (const uint32_t *)(h_dn + dn_bytes);	/* (valid when profiling) */
+
+	if (hipEventSynchronize(sl.ev_done) != hipSuccess) {
 		set_error("fuzzy pass failed: %s", hipGetErrorString(hipGetLastError()));
 		return -1;
 	}
@@ -801,13 +845,13 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	memcpy(term_ids, h_dn, (size_t)n_tok * 4);
 	if (ix->profiling) {
 		float ms = 0;
-		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
+		(void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]);
 		ix->prof.fuzzy_ms += ms;
-		(void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[2]);
+		(void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[2]);
 		ix->prof.fuzzy_filter_ms += ms;
-		(void)hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]);
+		(void)hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]);
 		ix->prof.fuzzy_dist_ms += ms;
-		(void)hipEventElapsedTime(&ms, ix->ev[3], ix->ev[1]);
+		(void)hipEventElapsedTime(&ms, sl.ev[3], sl.ev[1]);
 		ix->prof.fuzzy_chain_ms += ms;
 	}
 	if (h_cnt[2]) {
@@ -845,9 +889,112 @@ fuzzy_match_first(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *
 	return 0;
 }
 
+/* can the batch take the match-first pass as ONE launch sequence (the usual case: no visit counts wanted,
+ * every token fits the bit-vector distance)? */
+static bool
+mf_whole_batch(const nxsgpu_index_t *ix, const uint32_t *tok_off, uint32_t n_tok)
+{
+	if (ix->cfg.fuzzy_bfs || ix->cfg.fuzzy_noprune || !ix->d_bk_parent || !ix->n_bk || !n_tok) {
+		return false;
+	}
+	for (uint32_t i = 0; i < n_tok; i++) {
+		if (tok_off[i + 1] - tok_off[i] > NXS_MYERS_MAXPAT) {
+			return false;
+		}
+	}
+	return true;
+}
+
+static int fuzzy_search(nxsgpu_index_t *, const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint64_t *, bool);
+
+static int
+mf_free_slot(const nxsgpu_index_t *ix)
+{
+	for (int i = 0; i < NXSGPU_FZ_SLOTS; i++) {
+		if (!ix->fzs[i].state) {
+			return i;
+		}
+	}
+	return -1;
+}
+
 extern "C" int
 nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off,
     uint32_t n_tok, uint32_t *term_ids, uint64_t *visited)
+{
+	for (int i = 0; i < NXSGPU_FZ_SLOTS; i++) {
+		if (ix->fzs[i].state) {
+			set_error("a fuzzy pass is in flight (nxsgpu_fuzzy_begin without _end)");
+			return -1;
+		}
+	}
+	return fuzzy_search(ix, tok_bytes, tok_off, n_tok, term_ids, visited, false);
+}
+
+/*
+ * The same search in two calls: _begin queues the match-first pass of the whole batch on the fuzzy stream
+ * and returns a slot (>= 0; -1: error, -2: both slots are taken); _end (slot, same tokens) waits for it
+ * and delivers the term ids -- or runs the level-by-level search when a queue of the pass overflowed, and
+ * the whole search when the batch did not qualify for a single pass.  NXSGPU_FZ_SLOTS passes can be in
+ * flight, each with workspaces of its own; they run in the order they were begun and are to be ended in
+ * that order.  nxsgpu_fuzzy() refuses to run meanwhile.
+ */
+extern "C" int
+nxsgpu_fuzzy_begin(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok)
+{
+	const int slot = mf_free_slot(ix);
+
+	if (slot < 0) {
+		set_error("%d fuzzy passes are in flight already", NXSGPU_FZ_SLOTS);
+		return -2;
+	}
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	ix->fzs[slot].n = n_tok;
+	if (!mf_whole_batch(ix, tok_off, n_tok)) {
+		ix->fzs[slot].state = 2;
+		return slot;
+	}
+	if (mf_launch(ix, slot, tok_bytes, tok_off, n_tok) != 0) {
+		(void)hipStreamSynchronize(ix->stream_fz);
+		return -1;
+	}
+	ix->fzs[slot].state = 1;
+	return slot;
+}
+
+extern "C" int
+nxsgpu_fuzzy_end(nxsgpu_index_t *ix, int slot, const uint8_t *tok_bytes, const uint32_t *tok_off, uint32_t n_tok,
+    uint32_t *term_ids)
+{
+	if (slot < 0 || slot >= NXSGPU_FZ_SLOTS || !ix->fzs[slot].state || n_tok != ix->fzs[slot].n) {
+		set_error("nxsgpu_fuzzy_end without a matching _begin");
+		return -1;
+	}
+	const int mode = ix->fzs[slot].state;
+	if (hipSetDevice(ix->device) != hipSuccess) {
+		ix->fzs[slot].state = 0;
+		set_error("hipSetDevice failed");
+		return -1;
+	}
+	if (mode == 1) {
+		const int r = mf_finish(ix, slot, n_tok, term_ids);
+		ix->fzs[slot].state = 0;
+		if (r <= 0) {
+			return r;
+		}
+		return fuzzy_search(ix, tok_bytes, tok_off, n_tok, term_ids, NULL, true);
+	}
+	ix->fzs[slot].state = 0;
+	return fuzzy_search(ix, tok_bytes, tok_off, n_tok, term_ids, NULL, false);
+}
+
+/* (no_mf: the match-first pass of these tokens has been tried and overflowed) */
+static int
+fuzzy_search(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_off,
+    uint32_t n_tok, uint32_t *term_ids, uint64_t *visited, bool no_mf)
 {
 	const uint64_t budget = ix->cfg.fuzzy_items;
 	const uint32_t n_bk = ix->n_bk;
@@ -884,9 +1031,16 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 	/* the usual case: no visit counts wanted, every token fits the bit-vector
 	 * distance -- match first, then reachability; the frontier search below is
 	 * what the reference does, step for step, and the fallback */
-	if (!visited && !ix->cfg.fuzzy_bfs && !ix->cfg.fuzzy_noprune && ix->d_bk_parent) {
+	if (!visited && !no_mf && !ix->cfg.fuzzy_bfs && !ix->cfg.fuzzy_noprune && ix->d_bk_parent) {
 		if (!any_long) {
-			const int r = fuzzy_match_first(ix, tok_bytes, tok_off, n_tok, term_ids);
+			/* (a free slot: nxsgpu_fuzzy() runs with none taken, nxsgpu_fuzzy_end() has given its own back) */
+			const int slot = mf_free_slot(ix);
+			int r = slot < 0 ? 1 : mf_launch(ix, slot, tok_bytes, tok_off, n_tok);
+			if (slot >= 0 && r == 0) {
+				r = mf_finish(ix, slot, n_tok, term_ids);
+			} else if (slot >= 0) {
+				(void)hipStreamSynchronize(ix->stream_fz);
+			}
 			if (r <= 0) {
 				return r;
 			}
@@ -911,7 +1065,7 @@ nxsgpu_fuzzy(nxsgpu_index_t *ix, const uint8_t *tok_bytes, const uint32_t *tok_o
 				if (!sel[w].empty()) {
 					ids[w].resize(sel[w].size());
 					bytes[w].resize(bytes[w].size() + 16);
-					rc = nxsgpu_fuzzy(ix, bytes[w].data(), off[w].data(), (uint32_t)sel[w].size(), ids[w].data(), NULL);
+					rc = fuzzy_search(ix, bytes[w].data(), off[w].data(), (uint32_t)sel[w].size(), ids[w].data(), NULL, false);
 					for (size_t j = 0; j < sel[w].size(); j++) {
 						term_ids[sel[w][j]] = ids[w][j];
 					}

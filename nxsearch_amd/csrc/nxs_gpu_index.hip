@@ -627,8 +627,21 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	if (ix->h_pin) {
 		(void)hipHostFree(ix->h_pin);
 	}
-	if (ix->fz_pin) {
-		(void)hipHostFree(ix->fz_pin);
+	for (int i = 0; i < NXSGPU_FZ_SLOTS; i++) {
+		if (ix->fzs[i].pin) {
+			(void)hipHostFree(ix->fzs[i].pin);
+		}
+		if (ix->fzs[i].ws) {
+			(void)hipFree(ix->fzs[i].ws);
+		}
+		for (int j = 0; j < 4; j++) {
+			if (ix->fzs[i].ev[j]) {
+				(void)hipEventDestroy(ix->fzs[i].ev[j]);
+			}
+		}
+		if (ix->fzs[i].ev_done) {
+			(void)hipEventDestroy(ix->fzs[i].ev_done);
+		}
 	}
 	for (int i = 0; i < 4; i++) {
 		if (ix->ev[i]) {
@@ -1266,6 +1279,12 @@ nxsgpu_index_create(int device, const nxsgpu_index_src_t *src)
 	HIP_TRY(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
 	for (int i = 0; i < 4; i++) {
 		HIP_TRY(hipEventCreate(&ix->ev[i]));
+		for (int j = 0; j < NXSGPU_FZ_SLOTS; j++) {
+			HIP_TRY(hipEventCreate(&ix->fzs[j].ev[i]));
+		}
+	}
+	for (int j = 0; j < NXSGPU_FZ_SLOTS; j++) {
+		HIP_TRY(hipEventCreateWithFlags(&ix->fzs[j].ev_done, hipEventDisableTiming));
 	}
 
 	/* room for appended docs (N1) without moving the tables */

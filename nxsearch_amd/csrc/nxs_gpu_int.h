@@ -313,8 +313,23 @@ struct nxsgpu_index {
 	/* fuzzy workspaces */
 	void *		fz;
 	size_t		fz_len;
-	uint8_t *	fz_pin;		/* pinned staging of the match-first pass: one copy up, one down */
-	size_t		fz_pin_len;
+	/*
+	 * Match-first passes (nxs_gpu_fuzzy.hip mf_launch / mf_finish): NXSGPU_FZ_SLOTS of them can be queued on
+	 * stream_fz, each with its own device workspace, pinned staging (one copy up, one down) and profiling
+	 * events.  state: 0 free, 1 a pass is queued (nxsgpu_fuzzy_begin; its results land in pin), 2 begun but
+	 * nothing queued (the batch does not qualify for a single pass: _end runs the whole search).  `fz`
+	 * above is the level-by-level search's workspace.
+	 */
+	struct fz_slot_t {
+		void *		ws;
+		size_t		ws_len;
+		uint8_t *	pin;
+		size_t		pin_len;
+		int		state;
+		uint32_t	n;
+		hipEvent_t	ev[4];
+		hipEvent_t	ev_done;	/* after the copy back */
+	} fzs[NXSGPU_FZ_SLOTS];
 
 	bool		profiling;
 	hipEvent_t	ev[4];

@@ -98,8 +98,13 @@ nxsgpu_debug_stats_stripe(unsigned long long *out, int reset)
  * everything else (k_scanm<.., DROP>: one dependent gather per tile, 19-23 per wavefront).  Queries whose
  * dropped terms have outlier lists (TF-IDF) stay on k_scanm<.., DROP>: those lists have no directory.
  */
+#ifdef ST_OCC
+#define	ST_OCC_ATTR	__attribute__((amdgpu_waves_per_eu(ST_OCC, ST_OCC)))
+#else
+#define	ST_OCC_ATTR
+#endif
 template <int NT, bool GEN, bool DROP = false>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE) ST_OCC_ATTR
 k_scans(const scan_args_t A)
 {
 	static_assert(!(GEN && DROP), "the sparse + dense class is pure OR");

@@ -18,7 +18,7 @@
  * queries that had to be re-run on the exact two-pass path, out[6] / out[7] the
  * whole _begin() / _end() calls.
  */
-void		nxs_index_host_profile(nxs_index_t *, double out[8]);
+void		nxs_index_host_profile(nxs_index_t *, double out[12]);
 /* out[0] ncclCommCount of the attached communicator (-1: none / unknown), out[1] world, out[2] all-gathers queued,
  * out[3] bytes this rank contributed to them */
 void		nxs_index_shard_info(nxs_index_t *, uint64_t out[4]);

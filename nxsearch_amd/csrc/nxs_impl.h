@@ -81,6 +81,13 @@ typedef struct nxs_pend {
 	struct qprep *	prep;		/* [hi - lo] */
 	uint64_t	seq;
 	/*
+	 * The batch's misses are being resolved on the device (nxsgpu_fuzzy_begin) and _begin has returned:
+	 * the rest of its front half -- winners into the token lists, compile, queueing on the device -- is
+	 * done by the next _begin (after ITS parse) or by this batch's _end, whichever comes first
+	 * (nxs_api.c: late_finish).  NULL otherwise.
+	 */
+	struct late_half *late;
+	/*
 	 * Collected early: the index files changed while this batch was in flight and
 	 * a later _begin had to finish it to re-sync (search.c:309-312).  Its
 	 * responses wait here for the caller's _end.
@@ -118,18 +125,20 @@ struct nxs_index {
 	nxsgpu_comm_t *	comm;
 	struct nxs_pend	pend[NXSGPU_INFLIGHT];
 	/* tests: the n-th next _begin / exact fix-up of this index fails (0: off) */
-	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv;
+	unsigned	test_fail_begin, test_fail_fixup, test_fail_fixup_recv, test_fail_late;
 	bool		resync_pending;	/* sharded: a rank's block flags said its files moved */
 	struct plan_cache *pcache;	/* query string -> compiled plan (nxs_api.c: plan_batch) */
 	uint64_t	pend_seq;
 	/* host-side phase times of the batches, seconds (nxs_index_host_profile) */
-	double		hp_plan, hp_queue, hp_wait, hp_resps, hp_begin, hp_end;
+	double		hp_plan, hp_queue, hp_wait, hp_resps, hp_begin, hp_end, hp_fzwait, hp_front, hp_fzlaunch, hp_back;
 	uint64_t	hp_batches, hp_inexact;
 	/* doc-sharded mode (N4): this index is shard `shard` of `n_shards` (0 = whole) */
 	unsigned	shard, n_shards;
 	int		want_device;	/* explicit device + 1, or 0: NXS_GPU_DEVICE / device 0 */
 	bool		global_df_set;
 	bool		shard_local;	/* nxs_index_shard_local: responses of the own slice only */
+	int8_t		late_mode;	/* 0 not read yet, 1 a batch's fuzzy pass is left running (late_finish), 2 NXS_LATE_FUZZY=0:
+					 * _begin waits for it itself */
 	/* tests: play one rank of emu_world (nxs_test_shard_emulate) */
 	int		emu_rank, emu_world;
 	uint8_t *	emu_block;

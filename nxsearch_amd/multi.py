@@ -154,10 +154,10 @@ class ShardAborted(NxsError):
 
 
 def inject_failure(index, which, nth=1):
-    """tests: the nth next _begin ("begin") / exact fix-up round ("fixup") fails."""
+    """tests: the nth next _begin ("begin") / exact fix-up round ("fixup") / late second half ("late") fails."""
     L = lib()
     L.nxs_test_inject_failure.argtypes = [C.c_void_p, C.c_int, C.c_uint]
-    L.nxs_test_inject_failure(index._h, {"begin": 0, "fixup": 1, "fixup_recv": 2}[which], nth)
+    L.nxs_test_inject_failure(index._h, {"begin": 0, "fixup": 1, "fixup_recv": 2, "late": 3}[which], nth)
 
 
 def assemble(blocks, world, n_slots, k, n, only_rank=-1):

@@ -1104,6 +1104,120 @@ def test_resync_in_a_pipelined_loop_that_never_drains(nxs, tmp_path):
     gidx.close()
 
 
+@pytest.mark.parametrize("late", [True, False])
+def test_late_fuzzy_half_of_pipelined_batches(nxs, tmp_path, monkeypatch, late):
+    """tokenizer.c:177-180 under pipelining: a batch's misses are ONE device pass that _begin leaves
+    running (its second half -- winners, compile, queueing -- is done by the next _begin, after that
+    batch's parse and the launch of ITS pass, or by the batch's own _end).  Mixed BM25 + misspelt
+    tokens + syntax errors, 1-4 batches in flight, two limits; the caller's strings are gone when the
+    second half runs (the binding frees them on return); NXS_LATE_FUZZY=0 = _begin waits itself."""
+    from nxsearch_amd import multi
+    if not late:
+        monkeypatch.setenv("NXS_LATE_FUZZY", "0")
+    c, terms, qs = _mixed_workload(tmp_path)
+    qs = qs[:20] + ["broken AND", "zzzzqqqqzzzzqq"] + qs[20:]
+    gidx, oidx = nxs.open_files(c["terms"], c["dtmap"]), O.Index(c["terms"], c["dtmap"])
+    batches = [qs[i::6] for i in range(6)]
+
+    def check(b, got, limit):
+        assert len(got) == len(b)
+        for q, g in zip(b, got):
+            try:
+                want = oracle_memo("latefz", oidx, q, limit=limit)
+            except O.SearchError as e:
+                assert isinstance(g, N.NxsError) and g.code == e.code, q
+                continue
+            assert_same(g, want, (q, limit))
+    gidx.host_profile()
+    for depth, limit in ((1, 10), (2, 10), (4, 10), (3, 100)):
+        inflight = []
+        for b in batches:
+            gidx.search_batch_begin(b, limit=limit)
+            inflight.append(b)
+            if len(inflight) == depth:
+                check(inflight[0], gidx.search_batch_end(), limit)
+                inflight.pop(0)
+        while inflight:
+            check(inflight[0], gidx.search_batch_end(), limit)
+            inflight.pop(0)
+    hp = gidx.host_profile()
+    assert (hp["fuzzy_launch_ms"] > 0.005) == late, hp       # (a pass queued per batch: tens of microseconds)
+    # the blocking entry points between pipelined runs
+    check(batches[0], gidx.search_batch(batches[0], limit=10), 10)
+    assert_same(gidx.search(batches[1][0], limit=10), oracle_memo("latefz", oidx, batches[1][0], limit=10))
+    # the plan cache took the late batches' plans too: the same strings again are not planned again
+    if late:
+        gidx.search_batch_begin(batches[2], limit=10)
+        gidx.search_batch_begin(batches[3], limit=10)
+        check(batches[2], gidx.search_batch_end(), 10)
+        check(batches[3], gidx.search_batch_end(), 10)
+        # a second half that fails: its _begin has returned success, so its _end reports it; the batches
+        # around it are untouched
+        fresh = [[q + " OR " + batches[(i + 1) % 6][j % len(batches[(i + 1) % 6])] for j, q in enumerate(batches[i])
+                  if "broken" not in q] for i in range(3)]
+        gidx.search_batch_begin(fresh[0], limit=10)
+        multi.inject_failure(gidx, "late")
+        gidx.search_batch_begin(fresh[1], limit=10)      # finishes fresh[0]'s second half: fails there
+        gidx.search_batch_begin(fresh[2], limit=10)
+        with pytest.raises(N.NxsError) as e:
+            gidx.search_batch_end()
+        assert e.value.code == 2 and "late half" in e.value.msg
+        gidx._pending = gidx._pending[1:]
+        check(fresh[1], gidx.search_batch_end(), 10)
+        check(fresh[2], gidx.search_batch_end(), 10)
+        # an index closed with a batch's pass still on the device
+        gidx.search_batch_begin(fresh[0], limit=10)
+    gidx.close()
+
+
+def test_late_fuzzy_half_sees_a_resync(nxs, tmp_path):
+    """A never-draining loop of batches WITH misses (each one's second half still open when the next
+    _begin comes by) while an indexer appends a term that changes the fuzzy winners: the open half is
+    finished against the OLD snapshot before the refresh, the new batch resolves against the new one
+    (BK-tree image re-flattened with no pass in flight)."""
+    import shutil
+    ev = [("add", i + 1, ["carpet", "donkey", "w%d" % (i % 7)]) for i in range(300)]
+    timg, dimg, _ = nxsfmt.build_images_log(ev)
+    t, d = str(tmp_path / "nxsterms"), str(tmp_path / "nxsdtmap")
+    open(t, "wb").write(timg + b"\0" * 262144)
+    open(d, "wb").write(dimg + b"\0" * 262144)
+    gidx = nxs.open_files(t, d)
+    qs = ["carpit", "monkey", "donkeys OR monkey", "w3 AND carpets", "monkei AND carpet", "zebra"]
+    oracles, seen_by = [], []
+
+    def snapshot():
+        k = len(oracles)
+        tt, dd = str(tmp_path / ("t%d" % k)), str(tmp_path / ("d%d" % k))
+        shutil.copy(t, tt)
+        shutil.copy(d, dd)
+        oracles.append(O.Index(tt, dd))
+    snapshot()
+    gidx.search_batch_begin(qs, limit=10)
+    seen_by.append(0)
+    for step in range(1, 8):
+        if step == 2:
+            ev.append(("add", 1000, ["carpet", "monkey"]))       # "monkey" now exists: "monkei" -> monkey, not donkey
+            timg, dimg, _ = nxsfmt.build_images_log(ev)
+            nxsfmt.publish_in_place(t, d, timg, dimg)
+            snapshot()
+        if step == 5:
+            ev.append(("rm", 1000))
+            ev.append(("add", 1001, ["zebra", "carpet"]))
+            timg, dimg, _ = nxsfmt.build_images_log(ev)
+            nxsfmt.publish_in_place(t, d, timg, dimg)
+            snapshot()
+        gidx.search_batch_begin(qs, limit=10)
+        seen_by.append(len(oracles) - 1)
+        got = gidx.search_batch_end()
+        for q, g in zip(qs, got):
+            assert_same(g, oracles[seen_by[step - 1]].search(q, limit=10), (step, q))
+    for q, g in zip(qs, gidx.search_batch_end()):
+        assert_same(g, oracles[seen_by[-1]].search(q, limit=10), ("last", q))
+    assert seen_by[2] == 1 and seen_by[5] == 2
+    assert [x for x, _ in gidx.search("monkei")] == [x for x, _ in oracles[-1].search("monkei")]
+    gidx.close()
+
+
 @pytest.mark.parametrize("bm", [False, True])
 def test_incremental_refresh_interleaved_appends_and_removes(nxs, tmp_path, monkeypatch, bm):
     """N1: 100 interleaved appends (new docs with growing ids, some with new

@@ -56,9 +56,6 @@
 #ifndef ST_UNR
 #define	ST_UNR		3		/* scoring rounds whose searches run side by side */
 #endif
-#ifndef ST_ADV_SCALAR
-#define	ST_ADV_SCALAR	0		/* the window's lists by scalar tests (else: a compare / select per term and lane) */
-#endif
 #ifndef ST_GO
 #define	ST_GO		96		/* cold start ends when a whole stripe is expected to push at most this many docs */
 #endif
@@ -149,28 +146,38 @@ k_scans(const scan_args_t A)
 	const uint32_t cs_nout = DROP ? rfl32(cs[1]) : 0u;
 	const float cs_thr = DROP ? __uint_as_float(rfl32(cs[2])) : 0.0f;
 	const uint32_t cs_ovf = DROP ? rfl32(cs[3]) : 0u;
-	/* per term (wave-uniform): list start as a posting index, the range's slice [lo, hi) of the list */
-	uint32_t pb[NT], lo[NT], hi[NT], e[NT];
+	/*
+	 * Per term, in LANES (lane t = term t; the other lanes hold zeros): list start as a posting index,
+	 * the range's slice [lo, hi) of the list, the upper end e of the stripe being described, the
+	 * directory row.  The stripe descriptor is computed across these lanes (next_stripe): as scalars --
+	 * five values per term -- it was ~135 instructions per stripe, most of them reloads of spilled SGPRs.
+	 */
+	uint32_t v_pb = 0, v_lo = 0, v_e = 0;
 	float tsum = 0.0f;
-	static_for<NT>([&](auto tc) {
-		constexpr int t = decltype(tc)::value;
-		pb[t] = lo[t] = hi[t] = 0;
-		if (t < (int)nt) {
-			const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + t;
-			pb[t] = rfl32((uint32_t)Q->pbeg[t]);
-			lo[t] = rfl32(A.cursors[cb]);
-			hi[t] = rfl32(A.cursors[cb + NXSGPU_MAX_TOKENS]);
-			tsum += Q->tmax[t];
-			if (DROP) {
-				if (((dmask >> t) & 1) || cs_left == 0) {
-					hi[t] = lo[t];		/* no postings as far as the stripes are concerned */
-				} else {
-					hi[t] = max(min(hi[t], rfl32(cs[4 + t])), lo[t]);
-				}
+	if (lane < nt && lane < (uint32_t)NT) {
+		const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + lane;
+		v_pb = (uint32_t)Q->pbeg[lane];
+		v_lo = A.cursors[cb];
+		v_e = A.cursors[cb + NXSGPU_MAX_TOKENS];
+		if (DROP) {
+			if (((dmask >> lane) & 1) || cs_left == 0) {
+				v_e = v_lo;		/* no postings as far as the stripes are concerned */
+			} else {
+				v_e = max(min(v_e, cs[4 + lane]), v_lo);
 			}
 		}
-		e[t] = hi[t];
+	}
+	/* (read here, so that the compiler waits for these loads HERE: it does not see the waits inside the
+	 * ring's asm blocks, and a wait at the values' first use -- the descriptor, inside the loop -- is an
+	 * s_waitcnt vmcnt(0) at every stripe: the ring of posting windows drained each time) */
+	asm volatile("" :: "v"(v_pb), "v"(v_lo), "v"(v_e));
+	static_for<NT>([&](auto tc) {
+		constexpr int t = decltype(tc)::value;
+		if (t < (int)nt) {
+			tsum += Q->tmax[t];
+		}
 	});
+	const uint32_t lg4 = (lane < (uint32_t)NT ? lane * G : 0u) << 2;	/* ds_bpermute address of (term lane, stripe 0) */
 	/* the lanes' roles: directory fetch -- term lane / G, stripe lane % G of the group;
 	 * flush -- term lane % NTP of candidate lane / NTP */
 	const uint32_t ft = lane / G, fj = lane % G;
@@ -192,10 +199,7 @@ k_scans(const scan_args_t A)
 	{	/* (diagnostic build: the hand-over from k_cold must describe a part of this range) */
 		const uint32_t r_top = (g + 1 == qm.n_groups) ? (uint32_t)A.n_docs : (uint32_t)min((uint64_t)(g + 1) * qm.group_docs, A.n_docs);
 		bool bad = d_top > r_top || (d_top && d_top < d_bot);
-		static_for<NT>([&](auto tc) {
-			constexpr int t = decltype(tc)::value;
-			bad = bad || hi[t] < lo[t];
-		});
+		bad = bad || ballot64(v_e < v_lo) != 0;
 		if (bad) {
 			if (lane == 0) {
 				printf("k_scans<%d,%d>: bad hand-over q %u g %u: d_bot %u d_top %u r_top %u cs %u %u %u %u\n", NT, (int)DROP, q, g,
@@ -207,13 +211,18 @@ k_scans(const scan_args_t A)
 #endif
 
 	/* the stripes' lower boundaries in every list: G stripes x NT terms per load */
-	auto fetch_dir = [&](int32_t wg) -> uint32_t {
+	/*
+	 * (Load and wait in ONE asm block: a load the compiler tracks gets its s_waitcnt vmcnt(0) where the value
+	 * is used -- the descriptor of EVERY stripe, whether a row was fetched for it or not -- and that drains the
+	 * ring of posting windows each time.  Lanes without a row load word 0 of the array and drop it.)
+	 */
+	auto fetch_dir = [&](int32_t wg) __attribute__((always_inline)) -> uint32_t {
 		const int32_t wj = wg - (int32_t)fj;
-		uint32_t v = 0;
-		if (ft < (uint32_t)NT && wj >= w_bot) {
-			v = A.bmrank[(uint64_t)f_row + (uint64_t)wj * ST_WORDS];
-		}
-		return v;
+		const bool on = ft < (uint32_t)NT && wj >= w_bot;
+		const uint32_t *ap = A.bmrank + (on ? (uint64_t)f_row + (uint64_t)wj * ST_WORDS : 0ull);
+		uint32_t v;
+		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ap) : "memory");
+		return on ? v : 0u;
 	};
 
 	float hint = range_hint(A, qm, g);		/* 0 = nothing published yet */
@@ -517,14 +526,15 @@ k_scans(const scan_args_t A)
 	 * the stripe above's s), as the flat run [0, n_ld): lane i of the run belongs to the last term t
 	 * with c[t] <= i and is posting i + dsel[t] of the posting array.
 	 */
-	uint32_t c[NT], dsel[NT], ddel[NT], n_ld = 0, i0_ld = 0;
-	uint32_t ddv[NT];	/* ddel[] once more, in vector registers: the per-window select chain takes them as they are
+	uint32_t c[NT], dsel0 = 0, n_ld = 0, i0_ld = 0;
+	uint32_t ddv[NT];	/* dsel[t] - dsel[t - 1], in vector registers: the per-window select chain takes them as they are
 				 * (from scalar registers every select needs a copy first: four per window) */
+	uint32_t cnt_v = 0;	/* the described stripe's slice of list t, in lane t: [v_e, v_e + cnt_v) */
 	int32_t w_ld = w_top + 1, j_ld = -1;
 	uint32_t rkv = fetch_dir(w_top);
 	static_for<NT>([&](auto tc) {
 		constexpr int t = decltype(tc)::value;
-		c[t] = dsel[t] = ddel[t] = 0;
+		c[t] = 0;
 		ddv[t] = 0;
 	});
 	auto next_stripe = [&]() __attribute__((always_inline)) -> bool {
@@ -547,20 +557,34 @@ k_scans(const scan_args_t A)
 				rkv = fetch_dir(w_ld);
 				j_ld = 0;
 			}
-			uint32_t n = 0;
+			/* lane t: the stripe's start in list t (directory, clamped to the range's slice), its count, the
+			 * exclusive prefix sum over the terms (row-shift DPP: the terms sit in lanes 0 .. NT - 1 of row 0) */
+			const uint32_t raw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lg4 + ((uint32_t)j_ld << 2)), (int)rkv);
+			const uint32_t sl_ = min(max(raw, v_lo), v_e);
+			const uint32_t cn_ = v_e - sl_;
+			uint32_t inc = cn_;
+			inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+			inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+			inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+			const uint32_t cl_ = inc - cn_;
+			const uint32_t dl_ = v_pb + sl_ - cl_;
+			/* (as an ADD of the negated neighbour: the compiler folds `x - dpp(x)` into v_subrev_u32_dpp, and what
+			 * that instruction delivered on gfx950 was dpp(x) - x -- measured against the scalar computation; the folded adds above
+			 * are commutative) */
+			const uint32_t ndl = 0u - dl_;
+			const uint32_t dd_ = dl_ + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ndl, 0x111, 0xf, 0xf, false);
+			v_e = sl_;
+			cnt_v = cn_;
+			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)inc, NT - 1);
+			dsel0 = (uint32_t)__builtin_amdgcn_readlane((int)dl_, 0);
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
-				const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)rkv, t * G + j_ld);
-				const uint32_t et = rfl32(e[t]);
-				const uint32_t s = min(max(raw, lo[t]), et);
-				c[t] = n;
-				dsel[t] = pb[t] + s - n;
-				ddel[t] = t ? dsel[t] - dsel[t ? t - 1 : 0] : 0u;
-				/* (the asm keeps the copy from being folded back into a scalar operand) */
-				ddv[t] = ddel[t];
-				asm volatile("" : "+v"(ddv[t]));
-				n += et - s;
-				e[t] = s;
+				if (t > 0) {
+					c[t] = (uint32_t)__builtin_amdgcn_readlane((int)cl_, t);
+					ddv[t] = (uint32_t)__builtin_amdgcn_readlane((int)dd_, t);
+					/* (the asm keeps the copy in a vector register) */
+					asm volatile("" : "+v"(ddv[t]));
+				}
 			});
 			SSTAT_ADD(1, 1);
 			SSTAT_ADD(12, n);
@@ -607,11 +631,12 @@ k_scans(const scan_args_t A)
 			break;
 		}
 		/* the stripe's runs, list-relative: [low[t], cur[t]) */
-		uint32_t low[NT], cur[NT], cur0[NT];
+		uint32_t low[NT], cur[NT], cur0[NT], pb[NT];
 		static_for<NT>([&](auto tc) {
 			constexpr int t = decltype(tc)::value;
-			low[t] = dsel[t] - pb[t] + c[t];
-			cur[t] = low[t] + ((t + 1 < NT ? c[t + 1 < NT ? t + 1 : t] : n_ld) - c[t]);
+			low[t] = (uint32_t)__builtin_amdgcn_readlane((int)v_e, t);
+			cur[t] = low[t] + (uint32_t)__builtin_amdgcn_readlane((int)cnt_v, t);
+			pb[t] = (uint32_t)__builtin_amdgcn_readlane((int)v_pb, t);
 		});
 		uint32_t rhi = ST_DOCS;		/* docs of the stripe still to take: rel < rhi */
 		while (rhi > 0 && !ovf) {
@@ -743,33 +768,14 @@ k_scans(const scan_args_t A)
 			 * -- most windows of the longer lists -- costs two.
 			 */
 			const uint32_t i0 = i0_ld, iend = min(i0 + WAVE, n_ld);
-#if ST_ADV_SCALAR
-			uint32_t base = dsel[0];	/* (sums of differences: a chain of selects over dsel[] is turned into an indexed load from a stack array -- scratch) */
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				if (t > 0) {
-					base += c[t] <= i0 ? ddel[t] : 0u;
-				}
-			});
-			uint32_t dv = min(i0 + lane, iend - 1) + base;
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				if (t > 0) {
-					if (c[t] > i0 && c[t] < iend) {		/* wave-uniform */
-						dv += i0 + lane >= c[t] ? ddel[t] : 0u;
-					}
-				}
-			});
-#else
 			const uint32_t ic = min(i0 + lane, iend - 1);
-			uint32_t dv = ic + dsel[0];
+			uint32_t dv = ic + dsel0;
 			static_for<NT>([&](auto tc) {
 				constexpr int t = decltype(tc)::value;
 				if (t > 0) {
 					dv += ic >= c[t] ? ddv[t] : 0u;
 				}
 			});
-#endif
 			pa = A.post + dv;
 			pc = iend - i0;
 			pl = iend >= n_ld ? (uint32_t)w_ld + 1 : 0u;	/* (the window ends stripe w_ld) */
@@ -877,16 +883,20 @@ k_scans(const scan_args_t A)
 		SSTAT_ADD(13, 1);
 		flood = 0;
 		n_pend = min(n_pend, mark);
-		{
-			uint32_t v = 0;
-			if (ft < (uint32_t)NT && fj == 0 && w_mark <= w_top) {
-				v = A.bmrank[(uint64_t)f_row + (uint64_t)w_mark * ST_WORDS];
+		{	/* (the range's upper ends and the directory rows again, in term lanes: not kept live for this) */
+			uint32_t dv = 0, vh = 0;
+			if (lane < nt && lane < (uint32_t)NT) {
+				const uint64_t cb = ((uint64_t)qm.seg_first + q + g) * NXSGPU_MAX_TOKENS + lane;
+				const bool dropped = DROP && ((dmask >> lane) & 1);
+				vh = A.cursors[cb + NXSGPU_MAX_TOKENS];
+				if (DROP) {
+					vh = (dropped || cs_left == 0) ? v_lo : max(min(vh, cs[4 + lane]), v_lo);
+				}
+				if (w_mark <= w_top && !dropped) {
+					dv = A.bmrank[(uint64_t)Q->bm_col[lane] * (uint32_t)(A.bm_words + 1) + (uint64_t)w_mark * ST_WORDS];
+				}
 			}
-			static_for<NT>([&](auto tc) {
-				constexpr int t = decltype(tc)::value;
-				const uint32_t raw = (uint32_t)__builtin_amdgcn_readlane((int)v, t * G);
-				e[t] = w_mark > w_top ? hi[t] : min(max(raw, lo[t]), hi[t]);
-			});
+			v_e = w_mark > w_top ? vh : min(max(dv, v_lo), vh);
 		}
 		w_ld = w_mark;
 		j_ld = -1;

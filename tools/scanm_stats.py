@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import nxsearch_amd as N
 from nxsearch_amd import corpus
-docs, nterms, batch, k = 10_000_000, 1_000_000, 1024, 10
+docs, nterms, batch, k = 10_000_000, 1_000_000, int(os.environ.get("STATS_BATCH", "1024")), 10
 work = "/dev/shm/nxs_probe_%d_%d" % (docs, nterms)
 if not os.path.exists(os.path.join(work, "done")):
     info = corpus.write_corpus(work, docs, nterms, seed=0)
@@ -35,7 +35,6 @@ if os.environ.get("STATS_SETS"):
     sets = {k: v for k, v in sets.items() if k in os.environ["STATS_SETS"].split(",")}
 L = N.lib()
 L.nxsgpu_debug_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-gnames = ["waves", "parts", "subtiles", "flushes", "pending", "emitted", "redone", "wave_cyc", "part_docs", "part_postings", "overflows", "splits", "groups"]
 names = ["waves", "tiles", "visits", "flushes", "pending", "emitted", "flush_cyc", "wave_cyc", "tile_w_sum", "lanes_in_visits", "overflows", "reg_chunks", "deep_chunks"]
 ALGO = N.TF_IDF if os.environ.get("STATS_TFIDF") else N.BM25
 for name, qs in sets.items():

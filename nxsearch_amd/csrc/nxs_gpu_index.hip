@@ -271,6 +271,19 @@ k_dense_fill(const posting_t *__restrict__ post, uint64_t beg, uint64_t end, uin
 	}
 }
 
+/* ... and as a byte: ceil(255 x impact / the term's largest impact), never 0 for a posting (the margin
+ * keeps q8 x max / 255 >= impact whatever the divisions round to) */
+__global__ void
+k_dense_fill_q8(const posting_t *__restrict__ post, uint64_t beg, uint64_t end, float scale, uint8_t *__restrict__ col)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = beg + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
+		const posting_t p = post[i];
+		const float q = ceilf(p.imp * scale * 1.00001f);
+		col[p.doc] = (uint8_t)fminf(fmaxf(q, 1.0f), 255.0f);
+	}
+}
+
 /*
  * Block-presence bitmap + rank directory of one list (d_blkmap / d_bmrank rows).  A wavefront
  * reads 64 consecutive postings (coalesced); docs ascend, so the postings of one 4096-doc word
@@ -617,6 +630,7 @@ nxsgpu_index_destroy(nxsgpu_index_t *ix)
 	(void)hipFree(ix->d_post[1]);
 	(void)hipFree(ix->d_dense_col[0]);
 	(void)hipFree(ix->d_dense_col[1]);
+	(void)hipFree(ix->d_dense_q8);
 	(void)hipFree(ix->d_blkmap);
 	(void)hipFree(ix->d_bmrank);
 	(void)hipFree(ix->d_bk);
@@ -981,6 +995,34 @@ rebuild_impacts(nxsgpu_index_t *ix, unsigned only)
 				}
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamSynchronize(ix->stream));
+			}
+			if (a == NXSGPU_BM25 && ix->cfg.use_scans_drop) {
+				/* the byte form (k_scans<.., DROP>'s map fill: opt-in, NXS_GPU_SCANS_DROP) */
+				const uint64_t row = ((ix->n_docs + 16383) & ~(uint64_t)16383) + 16384;
+				const uint64_t bytes = (uint64_t)ix->dense_terms.size() * row;
+				if (bytes > ix->dense_q8_cap || (!bytes && ix->dense_q8_cap)) {
+					(void)hipFree(ix->d_dense_q8);
+					ix->d_dense_q8 = NULL;
+					ix->dense_q8_cap = 0;
+					if (bytes) {
+						const uint64_t cap = bytes + bytes / 16 + 65536;
+						HIP_TRY(hipMalloc((void **)&ix->d_dense_q8, cap));
+						ix->dense_q8_cap = cap;
+					}
+				}
+				ix->dense_q8_stride = row;
+				if (bytes) {
+					HIP_TRY(hipMemsetAsync(ix->d_dense_q8, 0, bytes, ix->stream));
+					for (size_t c = 0; c < ix->dense_terms.size(); c++) {
+						const uint32_t t = ix->dense_terms[c];
+						const float mx = ix->h_maximp[NXSGPU_BM25][t];
+						hipLaunchKernelGGL(k_dense_fill_q8, dim3(1024), dim3(256), 0, ix->stream,
+						    ix->d_post[a], ix->h_post_off[t], ix->h_post_off[t + 1],
+						    mx > 0.0f ? 255.0f / mx : 0.0f, ix->d_dense_q8 + c * row);
+					}
+					HIP_TRY(hipGetLastError());
+					HIP_TRY(hipStreamSynchronize(ix->stream));
+				}
 			}
 		}
 	}

@@ -159,9 +159,10 @@ struct gpu_cfg_t {
 	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
 	bool		use_scans;	/* !NXS_GPU_NOSCANS: the mask path on doc stripes cut out of the lists by the rank directories
 					 * (k_scans) for the queries whose terms all have one */
-	bool		use_scans_drop;	/* NXS_GPU_SCANS_DROP: ... also as the sparse + dense class's second kernel (k_scans<.., DROP>): opt-in --
-					 * level with k_scanm<.., DROP> on big batches, 1.6x slower where the class's few thousand
-					 * wavefronts all start cold at once (a C3 batch: NOTES.md) */
+	bool		use_scans_drop;	/* NXS_GPU_SCANS_DROP: ... also as the sparse + dense class's second kernel (k_scans<.., DROP>, BM25: the
+					 * stripes' byte maps FILLED from the dense term's byte column, built only with this switch):
+					 * opt-in -- 12-30 % faster than k_scanm<.., DROP> on the kprobe sets, no gain in a C3 / C5 step
+					 * (NOTES.md, round 5) */
 	bool		use_scanb;	/* !NXS_GPU_NOSCANB: the mask path's sparsest queries on the presence-bit kernel (k_scanb) */
 	double		scanb_dens;	/* NXS_GPU_SCANB_DENS: ... those whose lists together hold at most this fraction of the docs */
 };
@@ -263,6 +264,11 @@ struct nxsgpu_index {
 	std::vector<uint32_t> dense_terms;	/* ascending term ids; column = position */
 	uint32_t *	d_dense_col[2];
 	uint64_t	dense_cap[2];		/* allocated words per algo */
+	/* BM25: the same columns as bytes, q8[doc] = ceil(255 x impact / the term's largest impact) (0: the doc
+	 * does not hold the term), rows of dense_q8_stride bytes (a multiple of 16 KB beyond n_docs: a doc stripe
+	 * is read whole) -- what k_scans<.., DROP> fills its byte map with (nxs_gpu_scan_stripe.hip) */
+	uint8_t *	d_dense_q8;
+	uint64_t	dense_q8_stride, dense_q8_cap;
 	/*
 	 * TF-IDF: log(tf + 1) does not saturate, so one posting with an outlier tf sets a
 	 * ceiling far above what the term typically adds and the dense terms could never
@@ -404,6 +410,8 @@ struct scan_args_t {
 	const uint32_t *	dense_col;	/* impact columns of the dense terms: [col][n_docs] f32 bits,
 						 * 0xffffffff = the doc does not hold the term */
 	uint64_t		dense_stride;
+	const uint8_t *		dense_q8;	/* BM25: the columns as bytes (nxsgpu_index::d_dense_q8), or NULL */
+	uint64_t		dense_q8_stride;
 };
 
 struct replay_args_t {

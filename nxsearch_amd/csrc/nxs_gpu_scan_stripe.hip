@@ -59,6 +59,11 @@
 #ifndef ST_GO
 #define	ST_GO		96		/* cold start ends when a whole stripe is expected to push at most this many docs */
 #endif
+#ifndef ST_FILL_MIN
+#define	ST_FILL_MIN	48		/* DROP: a stripe's map is filled from the dense term's column if the stripe holds at least this many
+					 * sparse postings (fewer: zeroed, and the postings pass on the term's ceiling -- a fill costs
+					 * 8 KB, a memory latency and ~130 instructions) */
+#endif
 #define	ST_W0		64		/* cold-start sub-range */
 #ifndef ST_W_HINTED
 #define	ST_W_HINTED	ST_DOCS		/* first sub-range when a higher range has published a threshold: whole stripes at once */
@@ -86,14 +91,18 @@ nxsgpu_debug_stats_stripe(unsigned long long *out, int reset)
 #endif
 
 /*
- * DROP (the sparse + dense class, see k_scanm<.., DROP> / k_cold in nxs_gpu_scan_mask.hip): the dense
- * terms are not streamed; k_cold has walked the range's top until the threshold passed what they can add
- * together (U) and hands over threshold, top-k scores, output count and the sparse terms' cursors.  Here
- * the stripes hold the SPARSE terms' postings only, a doc is pushed if its byte bound plus the quantised
- * U can beat the threshold, and in the flush a dropped term's lane takes the candidate's impact from the
- * term's column (one load, no search) -- the gathers of the dense impacts are batched across stripes with
- * everything else (k_scanm<.., DROP>: one dependent gather per tile, 19-23 per wavefront).  Queries whose
- * dropped terms have outlier lists (TF-IDF) stay on k_scanm<.., DROP>: those lists have no directory.
+ * DROP (the sparse + dense class, see k_scanm<.., DROP> / k_cold in nxs_gpu_scan_mask.hip; opt-in,
+ * NXS_GPU_SCANS_DROP; BM25): the dense terms are not streamed; k_cold has walked the range's top until the
+ * threshold passed what they can add together (U) and hands over threshold, top-k scores, output count and
+ * the sparse terms' cursors.  Here the stripes hold the SPARSE terms' postings only.  The first dropped term's
+ * impacts are in the bytes from the start: a stripe with >= ST_FILL_MIN sparse postings has its map FILLED
+ * from the term's byte column (global_load_lds_dwordx4, converted in place by a shift), so a doc's byte is the
+ * bound of its whole score and is compared with the plain threshold; a sparser stripe is zeroed and its
+ * postings are given the term's ceiling (flagged on the pending list: the flush redoes their bound with the
+ * real impact before scoring).  Further dropped terms stay a ceiling on the threshold's side and are refined
+ * in the flush.  In the scoring a dropped term's lane takes the candidate's impact from the f32 column (one
+ * load, no search).  Queries whose dropped terms have outlier lists (TF-IDF) stay on k_scanm<.., DROP>: those
+ * lists have no directory.
  */
 #ifdef ST_OCC
 #define	ST_OCC_ATTR	__attribute__((amdgpu_waves_per_eu(ST_OCC, ST_OCC)))
@@ -114,7 +123,8 @@ k_scans(const scan_args_t A)
 	constexpr int R = ST_RING, UNR = ST_UNR;
 	__shared__ __attribute__((aligned(16))) uint32_t s_map[ST_DOCS / 4];
 	__shared__ uint32_t s_pend[ST_PEND];
-	__shared__ uint8_t s_psum[DROP ? ST_PEND : 4];		/* DROP: the byte bound a doc was pushed with */
+	__shared__ uint16_t s_psum[DROP ? ST_PEND : 4];		/* DROP: the byte bound a doc was pushed with; bit 8: in a stripe whose map was
+								 * NOT filled (the bound holds the filled token's ceiling, not its impact) */
 	__shared__ uint32_t s_truth[GEN ? 8 : 1];
 
 	const unsigned lane = threadIdx.x;
@@ -234,17 +244,46 @@ k_scans(const scan_args_t A)
 
 	/* Quantisation: as k_scanm's (q(x) = floor(x * qs) + 2, a doc's byte <= QSUM_MAX + 2 NT <= 240;
 	 * a doc can only beat thr if its byte exceeds floor(thr * qs) - 1) */
-	const float qs = tsum > 0.0f ? (float)QSUM_MAX / tsum : 0.0f;
-	/* DROP: what the dense tokens can add to a score in byte-map units (part of every doc's bound from
-	 * the start: the threshold the bytes are compared with is lowered by it), and the largest share of one
-	 * sparse posting */
-	uint32_t qU = 0, q1max = 0;
+	float qs = tsum > 0.0f ? (float)QSUM_MAX / tsum : 0.0f;
+	/*
+	 * DROP: the FIRST dropped token's impacts are in every byte from the start -- a stripe's map is FILLED
+	 * from the term's byte column (q8 = ceil(255 x impact / its largest impact), nxsgpu_index::d_dense_q8)
+	 * instead of being zeroed.  The scale is bent so that the conversion is a shift: qs is the largest value
+	 * <= the usual one (the term counted twice: room for the shift's rounding) with cap x qs / 255 = 2^-fk,
+	 * and a byte of the column becomes (q8 >> fk) + 2 >= impact x qs + 1, the bound every posting's share
+	 * obeys.  The other dropped tokens stay a ceiling on the threshold's side (qU) and are refined in the
+	 * flush, as before; q1max = the largest share of one sparse posting.
+	 */
+	uint32_t qU = 0, q1max = 0, fk = 7, fmask = 0, qUf = 0;
+	uint64_t f_col = 0;
 	if constexpr (DROP) {
+		const uint32_t td = (uint32_t)__builtin_ctz(dmask | 0x100u) & 7u;
+		const float cap = Q->tcap[td];
+		const float qs0 = tsum + cap > 0.0f ? (float)QSUM_MAX / (tsum + cap) : 0.0f;
+		fmask = dmask & ~(1u << td);
+		f_col = (uint64_t)rfl32(Q->drop_col[td]) * A.dense_q8_stride;
+		qs = qs0;
+		if (cap > 0.0f) {
+			float p2 = 1.0f;
+			fk = 0;
+			while (fk < 7 && 255.0f * p2 > qs0 * cap) {
+				p2 *= 0.5f;
+				fk++;
+			}
+			if (255.0f * p2 <= qs0 * cap) {
+				qs = 255.0f * p2 / cap;
+			}		/* (else: a share below two units -- the shift by 7 bounds it with the usual scale) */
+		}
+		fk = rfl32(fk);
+		qs = __uint_as_float(rfl32(__float_as_uint(qs)));
+		qUf = rfl32((uint32_t)(cap * qs) + 2);	/* the filled token's ceiling: what a posting of an UNFILLED stripe is given */
 		static_for<NT>([&](auto tc) {
 			constexpr int t = decltype(tc)::value;
 			if (t < (int)nt) {
-				if ((dmask >> t) & 1) {
+				if ((fmask >> t) & 1) {
 					qU += (uint32_t)(Q->tcap[t] * qs) + 2;
+				} else if ((dmask >> t) & 1) {
+					/* (the filled token: in the bytes) */
 				} else {
 					q1max = max(q1max, (uint32_t)(Q->tmax[t] * qs) + 2);
 				}
@@ -321,7 +360,7 @@ k_scans(const scan_args_t A)
 			if (ei < np) {
 				s_pend[rk[c]] = pd[c];
 				if (DROP) {
-					s_psum[rk[c]] = (uint8_t)ps[c];
+					s_psum[rk[c]] = (uint16_t)ps[c];
 				}
 			}
 		}
@@ -337,7 +376,8 @@ k_scans(const scan_args_t A)
 			bool keep = valid && !dup;
 			if constexpr (DROP) {
 				/*
-				 * The docs were pushed on the CEILING of the dense terms (qU); with their real
+				 * Docs of UNFILLED stripes were pushed on the ceiling of the filled token, all docs on the CEILING of the
+				 * other dropped tokens (qU); with their real
 				 * dense impacts -- one load per doc and dropped term, all lanes at once -- the
 				 * bound is redone and only what can still beat the threshold is scored.  A doc
 				 * is pushed once per posting that found it above the threshold (adjacent after
@@ -350,17 +390,23 @@ k_scans(const scan_args_t A)
 						sumq = max(sumq, (uint32_t)s_psum[ei + kk]);
 					}
 				}
+				const bool unfilled = (sumq >> 8) != 0;
+				sumq &= 0xffu;
 				uint32_t qd = 0;
 				static_for<NT>([&](auto tc) {
 					constexpr int t = decltype(tc)::value;
 					if ((dmask >> t) & 1) {
+						const bool mine = ((fmask >> t) & 1) || unfilled;	/* (the filled token: only where its impact is not in the byte) */
 						const uint64_t cbase = (uint64_t)rfl32(Q->drop_col[t]) * A.dense_stride;
-						const uint32_t xb = A.dense_col[cbase + (keep ? d : 0u)];
+						const uint32_t xb = (keep && mine) ? A.dense_col[cbase + d] : 0xffffffffu;
 						if (xb != 0xffffffffu) {
 							qd += (uint32_t)(__uint_as_float(xb) * qs) + 2;
 						}
 					}
 				});
+				if (unfilled) {
+					sumq -= qUf;
+				}
 				keep = keep && (int32_t)(sumq + qd) > thr_q + (int32_t)qU;
 				SSTAT_ADD(14, __popcll(ballot64(keep)));
 			}
@@ -510,10 +556,10 @@ k_scans(const scan_args_t A)
 			s_pend[WAVE + lane] = rest2;
 		}
 		if (DROP && np + lane < n_pend) {
-			s_psum[lane] = (uint8_t)rsum;
+			s_psum[lane] = (uint16_t)rsum;
 		}
 		if (DROP && np + WAVE + lane < n_pend) {
-			s_psum[WAVE + lane] = (uint8_t)rsum2;
+			s_psum[WAVE + lane] = (uint16_t)rsum2;
 		}
 		WAVE_SYNC();
 		n_pend = min(n_pend - np, 2u * WAVE);
@@ -595,12 +641,13 @@ k_scans(const scan_args_t A)
 			}
 		}
 	};
+	uint32_t qadd = 0;	/* DROP: what a posting of the stripe in hand is given on top of its byte (prep, below) */
 	auto push = [&](uint64_t cm, uint32_t doc, uint32_t sum) __attribute__((always_inline)) {
 		const uint32_t np = (uint32_t)__popcll(cm);
 		if (n_pend + np <= ST_PEND && lane_of(cm)) {
 			s_pend[n_pend + lanes_below(cm)] = doc;
 			if (DROP) {
-				s_psum[n_pend + lanes_below(cm)] = (uint8_t)sum;
+				s_psum[n_pend + lanes_below(cm)] = (uint16_t)(sum | (qadd ? 0x100u : 0u));
 			}
 		}
 		n_pend += np;
@@ -612,6 +659,50 @@ k_scans(const scan_args_t A)
 			*(uint4 *)&s_map[i + lane * 4] = make_uint4(0, 0, 0, 0);
 		}
 		WAVE_SYNC();
+	};
+
+	/*
+	 * DROP: stripe w's bytes from the filled token's column -- eight 1 KB pieces straight into LDS
+	 * (global_load_lds_dwordx4: no registers), waited for on the spot (they are the youngest vector memory
+	 * operations: vmcnt(0), the ring's windows have landed by then too), then converted in place.
+	 */
+	uint32_t w_filled = 0;		/* stripe + 1 whose bytes the map holds (0: none) */
+	auto fill = [&](int32_t w) __attribute__((always_inline)) {
+		if constexpr (DROP) {
+			const uint8_t *src = A.dense_q8 + f_col + (uint64_t)(uint32_t)w * ST_DOCS + lane * 16;
+			const uint32_t fm = 0x01010101u * (0xffu >> fk);
+			WAVE_SYNC();
+#pragma unroll
+			for (uint32_t i = 0; i < ST_DOCS / 1024; i++) {
+				__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + i * 1024),
+				    (void __attribute__((address_space(3))) *)&s_map[i * 256], 16, 0, 0);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			WAVE_SYNC();
+#pragma unroll 2
+			for (uint32_t i = 0; i < ST_DOCS / 4; i += WAVE * 4) {
+				uint4 x = *(uint4 *)&s_map[i + lane * 4];
+				x.x = ((x.x >> fk) & fm) + 0x02020202u;
+				x.y = ((x.y >> fk) & fm) + 0x02020202u;
+				x.z = ((x.z >> fk) & fm) + 0x02020202u;
+				x.w = ((x.w >> fk) & fm) + 0x02020202u;
+				*(uint4 *)&s_map[i + lane * 4] = x;
+			}
+			WAVE_SYNC();
+			w_filled = (uint32_t)w + 1;
+			SSTAT_ADD(15, 1);
+		}
+	};
+	/* DROP: stripe w's map before its first posting -- filled (then qadd = 0) or zeroed (qadd = the ceiling) */
+	auto prep = [&](int32_t w, bool filled) __attribute__((always_inline)) {
+		if (filled) {
+			fill(w);
+			qadd = 0;
+		} else {
+			wipe();
+			w_filled = (uint32_t)w + 1;
+			qadd = qUf;
+		}
 	};
 
 	/*
@@ -629,6 +720,9 @@ k_scans(const scan_args_t A)
 		ovf = rfl32(ovf);
 		if (!next_stripe()) {
 			break;
+		}
+		if (DROP) {
+			prep(w_ld, n_ld >= (uint32_t)ST_FILL_MIN);
 		}
 		/* the stripe's runs, list-relative: [low[t], cur[t]) */
 		uint32_t low[NT], cur[NT], cur0[NT], pb[NT];
@@ -682,7 +776,7 @@ k_scans(const scan_args_t A)
 					const uint32_t qq = (uint32_t)(p.imp * qs) + 2;
 					const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], valid ? (qq << shv) : 0u,
 					    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
+					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq + (DROP ? qadd : 0u);
 					const uint64_t vm = ballot64(valid);
 					const uint64_t cm = ballot64(valid && (int32_t)sum > thr_q);
 					SSTAT_ADD(3, 1);
@@ -706,7 +800,11 @@ k_scans(const scan_args_t A)
 					constexpr int t = decltype(tc)::value;
 					cur[t] = cur0[t];
 				});
-				wipe();
+				if (DROP) {
+					prep(w_ld, n_ld >= (uint32_t)ST_FILL_MIN);
+				} else {
+					wipe();
+				}
 				SSTAT_ADD(13, 1 << 16);
 				continue;
 			}
@@ -734,7 +832,9 @@ k_scans(const scan_args_t A)
 			}
 		}
 		i0_ld = n_ld;		/* the stripe is used up */
-		wipe();
+		if (!DROP) {
+			wipe();		/* (DROP: the next stripe's fill overwrites every byte) */
+		}
 	}
 
 	/*
@@ -778,7 +878,12 @@ k_scans(const scan_args_t A)
 			});
 			pa = A.post + dv;
 			pc = iend - i0;
-			pl = iend >= n_ld ? (uint32_t)w_ld + 1 : 0u;	/* (the window ends stripe w_ld) */
+			if (DROP) {
+				/* (every window names its stripe: the consumer fills the map at a stripe's FIRST window) */
+				pl = (((uint32_t)w_ld + 1) << 2) | (n_ld >= (uint32_t)ST_FILL_MIN ? 2u : 0u) | (iend >= n_ld ? 1u : 0u);
+			} else {
+				pl = iend >= n_ld ? (uint32_t)w_ld + 1 : 0u;	/* (the window ends stripe w_ld) */
+			}
 			i0_ld = i0 + WAVE;
 			SSTAT_ADD(3, 1);
 		};
@@ -820,24 +925,34 @@ k_scans(const scan_args_t A)
 				vm_wait_younger(R - 1);
 				bpair_take<s, 63>(pdoc, pimp, pa);
 				if (cnt[s]) {
+					uint32_t ends = last[s];	/* the stripe's number + 1 if this window ends it */
+					if (DROP) {
+						const uint32_t ws = last[s] >> 2;
+						ends = (last[s] & 1) ? ws : 0u;
+						if (ws != w_filled) {
+							prep((int32_t)ws - 1, (last[s] & 2) != 0);
+						}
+					}
 					const uint32_t rel = pdoc & (ST_DOCS - 1);
 					const uint32_t shv = (rel & 3) * 8;
 					const uint32_t qq = (uint32_t)(pimp * qs) + 2;
 					const bool valid = lane < cnt[s];	/* (not a mask built by 1 << cnt: cnt may be 64) */
 					const uint32_t oldv = __hip_atomic_fetch_add(&s_map[rel >> 2], valid ? (qq << shv) : 0u,
 					    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq;
+					const uint32_t sum = ((oldv >> shv) & 0xffu) + qq + (DROP ? qadd : 0u);
 					const uint64_t cm = ballot64(valid && (int32_t)sum > thr_q);
 					if (cm) {
 						push(cm, pdoc, sum);
 					}
-					if (last[s]) {
-						wipe();
+					if (ends) {
+						if (!DROP) {
+							wipe();
+						}
 						/* (a stripe whose pushes did not all fit is not finished: the flood check
 						 * below sends the loader back to it -- its docs are not on the list) */
 						if (n_pend <= (uint32_t)ST_PEND) {
 							mark = n_pend;
-							w_mark = (int32_t)last[s] - 1;
+							w_mark = (int32_t)ends - 1;
 						}
 					}
 				}
@@ -903,6 +1018,7 @@ k_scans(const scan_args_t A)
 		rkv = fetch_dir(w_mark - 1);
 		n_ld = i0_ld = 0;
 		tw = ST_DOCS / 4;
+		w_filled = 0;
 		wipe();
 	}
 	}

@@ -152,7 +152,7 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 					cls[i] = 5u * 64 + 16u + nt_bucket(hq[i].nt);
 					/* ... on doc stripes (k_cold + k_scans<.., DROP>) if the sparse terms all have a rank
 					 * directory and no dropped term brings an outlier list (those have none) */
-					if (cf.use_scans && cf.use_scans_drop && ix->n_post < (1ull << 32) && ix->d_bmrank && !hq[i].outl_mask) {
+					if (cf.use_scans && cf.use_scans_drop && !hq[i].outl_tfidf && ix->d_dense_q8 && ix->n_post < (1ull << 32) && ix->d_bmrank && !hq[i].outl_mask) {
 						bool all = true;
 						for (uint32_t t = 0; t < hq[i].nt; t++) {
 							all = all && (((hq[i].drop_mask >> t) & 1) || hq[i].bm_col[t] != 0xffffffffu);
@@ -1071,6 +1071,8 @@ search_impl(nxsgpu_index_t *ix, int algo, uint64_t limit, const nxsgpu_query_t *
 	sa.post = ix->d_post[algo];
 	sa.dense_col = ix->d_dense_col[algo];
 	sa.dense_stride = ix->n_docs;
+	sa.dense_q8 = algo == NXSGPU_BM25 ? ix->d_dense_q8 : NULL;
+	sa.dense_q8_stride = ix->dense_q8_stride;
 	sa.blkmap = ix->d_blkmap;
 	sa.bmrank = ix->d_bmrank;
 	sa.bm_words = ix->bm_words;
@@ -1779,6 +1781,8 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 	sa.post = ix->d_post[algo];
 	sa.dense_col = ix->d_dense_col[algo];
 	sa.dense_stride = ix->n_docs;
+	sa.dense_q8 = algo == NXSGPU_BM25 ? ix->d_dense_q8 : NULL;
+	sa.dense_q8_stride = ix->dense_q8_stride;
 	sa.blkmap = ix->d_blkmap;
 	sa.bmrank = ix->d_bmrank;
 	sa.bm_words = ix->bm_words;

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import nxsearch_amd as N
 from nxsearch_amd import corpus
-docs, nterms, batch, k = 10_000_000, 1_000_000, 1024, 10
+docs, nterms, batch, k = 10_000_000, 1_000_000, int(os.environ.get("STATS_BATCH", "1024")), 10
 work = "/dev/shm/nxs_probe_%d_%d" % (docs, nterms)
 if not os.path.exists(os.path.join(work, "done")):
     info = corpus.write_corpus(work, docs, nterms, seed=0)

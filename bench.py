@@ -382,7 +382,9 @@ def main():
     # latency-bound class with few wavefronts can span longer than the one that keeps the chip busy);
     # without a PMC summary: the longest one
     with_moved = [e for e in per_kernel if e["moved_bytes"]]
-    dom = max(with_moved, key=lambda e: e["moved_bytes"]) if with_moved else (per_kernel[0] if per_kernel else None)
+    # (an entry without bytes of its own -- a class's top ranges sent ahead: counted with the class -- is never the dominant one)
+    with_bytes = [e for e in per_kernel if e["alg_bytes"] > 0]
+    dom = max(with_moved, key=lambda e: e["moved_bytes"]) if with_moved else (with_bytes[0] if with_bytes else (per_kernel[0] if per_kernel else None))
     # the dominant kernel's own roofline point.  If it streams every posting it is charged for
     # (k_scanm, k_scan1) algorithmic == moved and the fraction is a bandwidth fraction; a kernel that
     # skips postings gets its fraction from the bytes it MOVED (never above 1).

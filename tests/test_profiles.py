@@ -41,8 +41,9 @@ def test_kernel_bytes_within_step_bytes():
         for k in rf.get("per_kernel") or []:
             assert 0 <= k["alg_bytes"] <= step, (name, k["kernel"], k["alg_bytes"], step)
             tot += k["alg_bytes"]
-        # the classes partition the batch's postings: together they cannot exceed the step either
-        assert tot <= step * 1.001, (name, tot, step)
+        # the classes partition the batch's postings -- but for the ranges a retry list scans AGAIN (k_scan8 after an
+        # overflow: charged to both kernels), a fraction of a per cent
+        assert tot <= step * 1.01, (name, tot, step)
 
 
 def test_record_shape():
@@ -51,7 +52,7 @@ def test_record_shape():
         assert d["value"] > 0 and d["ms_per_step"] > 0, name
         rf = d.get("roofline")
         if rf and rf.get("frac") is not None:
-            assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1, (name, rf.get("frac"))
+            assert rf["bound"] in ("hbm", "mfma") and 0 <= rf["frac"] < 1, (name, rf.get("frac"))
             assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3, name
         if "repeat_ms_per_step" in d:
             # the median loop is the one reported

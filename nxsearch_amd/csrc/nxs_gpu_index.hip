@@ -86,6 +86,8 @@ cfg_from_env(gpu_cfg_t &c)
 	c.bigq_em = dbl("NXS_GPU_BIGQ_EM", 16.0);
 	c.use_scans = !on("NXS_GPU_NOSCANS");
 	c.use_scans_drop = on("NXS_GPU_SCANS_DROP");
+	c.scans_workpct = u64("NXS_GPU_SCANS_WORKPCT", 70, 10, 400);
+	c.wave_target_scans = u64("NXS_GPU_WAVES_SCANS", std::min<uint64_t>(c.wave_target, 57344), 1, 1u << 22);
 	c.use_scanb = !on("NXS_GPU_NOSCANB");
 	c.scanb_dens = dbl("NXS_GPU_SCANB_DENS", 0.01);
 	c.replay_join = on("NXS_GPU_REPLAY_JOIN");

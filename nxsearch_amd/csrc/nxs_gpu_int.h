@@ -118,6 +118,7 @@ struct dev_query_t {
  */
 struct gpu_cfg_t {
 	uint64_t	wave_target;	/* NXS_GPU_WAVES */
+	uint64_t	wave_target_scans;	/* NXS_GPU_WAVES_SCANS: ... of a batch that holds the stripe class (default: min(that, 57344)) */
 	uint64_t	min_post;	/* NXS_GPU_MINPOST */
 	uint64_t	min_post_solo;	/* NXS_GPU_MINPOST_SOLO: the same for a small batch with nothing else in flight */
 	double		scanm_dens;	/* NXS_GPU_SCANM_DENS */
@@ -159,6 +160,7 @@ struct gpu_cfg_t {
 	double		bm_gain;	/* NXS_GPU_BM_GAIN (16): k_scanq if (expected surviving blocks) x this < the driver's postings */
 	bool		use_scans;	/* !NXS_GPU_NOSCANS: the mask path on doc stripes cut out of the lists by the rank directories
 					 * (k_scans) for the queries whose terms all have one */
+	uint64_t	scans_workpct;	/* NXS_GPU_SCANS_WORKPCT (70): the stripe class's share of the work list's wavefronts, per cent of what its postings would get */
 	bool		use_scans_drop;	/* NXS_GPU_SCANS_DROP: ... also as the sparse + dense class's second kernel (k_scans<.., DROP>, BM25: the
 					 * stripes' byte maps FILLED from the dense term's byte column, built only with this switch):
 					 * opt-in -- 12-30 % faster than k_scanm<.., DROP> on the kprobe sets, no gain in a C3 / C5 step

@@ -65,6 +65,7 @@ cfg_from_env(gpu_cfg_t &c)
 	auto on = [](const char *name) -> bool { return getenv(name) != NULL; };
 
 	c.wave_target = u64("NXS_GPU_WAVES", 65536, 1, 1u << 22);
+	c.max_post = u64("NXS_GPU_MAXPOST", 65536, 1024, 1ull << 40);
 	c.min_post = u64("NXS_GPU_MINPOST", 4096, 1, ~0ull);
 	c.min_post_solo = u64("NXS_GPU_MINPOST_SOLO", 512, 1, ~0ull);
 	c.scanm_dens = dbl("NXS_GPU_SCANM_DENS", 0.08);

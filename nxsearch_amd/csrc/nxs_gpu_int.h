@@ -118,6 +118,7 @@ struct dev_query_t {
  */
 struct gpu_cfg_t {
 	uint64_t	wave_target;	/* NXS_GPU_WAVES */
+	uint64_t	max_post;	/* NXS_GPU_MAXPOST (65536): a batch too big for that many postings per wavefront at the target gets more wavefronts (<= 4x) */
 	uint64_t	wave_target_scans;	/* NXS_GPU_WAVES_SCANS: ... of a batch that holds the stripe class (default: min(that, 57344)) */
 	uint64_t	min_post;	/* NXS_GPU_MINPOST */
 	uint64_t	min_post_solo;	/* NXS_GPU_MINPOST_SOLO: the same for a small batch with nothing else in flight */

@@ -268,7 +268,10 @@ build_worklist(const nxsgpu_index_t *ix, dev_query_t *hq, uint32_t nq, worklist_
 	for (uint32_t i = 0; i < nq && !any_scans; i++) {
 		any_scans = (cls[i] >> 6) == 8;
 	}
-	const uint64_t target_eff = any_scans ? cf.wave_target_scans : target;
+	/* (... and a huge batch -- C5: 29 G postings -- more wavefronts than the target: a range of more than cf.max_post
+	 * postings leaves the step's tail to a few long wavefronts (C5: 358k -> 377k queries/s); at most four times the target: the staging area's bound) */
+	uint64_t target_eff = any_scans ? cf.wave_target_scans : target;
+	target_eff = std::min<uint64_t>(4 * target_eff, std::max<uint64_t>(target_eff, total / std::max<uint64_t>(cf.max_post, 1)));
 	const uint64_t per_wave = std::max<uint64_t>(std::max<uint64_t>(min_post, (uint64_t)big_k * cf.big_minpost),
 	    total / std::max<uint64_t>(target_eff, 1) + 1);
 	/* launch order of the classes: the mask path first -- a class's heap replay
@@ -1659,7 +1662,7 @@ batch_begin(nxsgpu_index_t *ix, int algo, uint32_t limit, const nxsgpu_query_t *
 
 	/* plans straight into the pinned staging area (room for the work list:
 	 * <= target + nq ranges, see build_worklist) */
-	const uint64_t wave_target = std::max(ix->cfg.wave_target, ix->cfg.wave_target_scans);
+	const uint64_t wave_target = 4 * std::max(ix->cfg.wave_target, ix->cfg.wave_target_scans);	/* (build_worklist: target_eff) */
 	const size_t seg_bound = (size_t)wave_target + 2 * (size_t)nq + 64;
 	const size_t stage_need = 32768 + RETRY_LISTS * 4 + 256 + nq * (sizeof(dev_query_t) + sizeof(qmeta_t) + 16)
 	    + seg_bound * (sizeof(item_t) + 8) + nq * 4 + NXSGPU_STATUS_WORDS(o.n_slots) * 4 + 4096

@@ -38,6 +38,24 @@ def oracle_memo(test, oidx, q, **kw):
     return _ORACLE_MEMO[key]
 
 
+def oracle_many(c, jobs, workers=8):
+    """The oracle's answers to `jobs` = [(query, algo, limit, fuzzymatch)] from tests/oracle_pool.py: a child
+    program without a GPU context that loads the index once and forks `workers` processes."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump([list(j) for j in jobs], f)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_pool.py"),
+                            c["terms"], c["dtmap"], f.name, str(workers)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [None if x is None else [(d, s) for d, s in x] for x in json.loads(r.stdout.strip().splitlines()[-1])]
+    finally:
+        os.unlink(f.name)
+
+
 def assert_same(got, want, ctx=""):
     assert [d for d, _ in got] == [d for d, _ in want], ctx
     for (d, a), (_, b) in zip(got, want):
@@ -1529,6 +1547,12 @@ def test_full_size_c3_c4_properties(nxs, tmp_path, monkeypatch):
             assert_same(base[i], oidx.search(qs[i], limit=10, fuzzymatch=False), qs[i])
         for i in sample[::4] + with_dense[:2]:
             assert_same(tf[i], oidx.search(qs[i], algo=0, limit=10, fuzzymatch=False), (qs[i], "TF-IDF"))
+        # ... and every fourth query of the batch (256 of 1024, both operators, every class of the work list) on eight
+        # cores beside this process: tests/oracle_pool.py
+        wide = list(range(1, 1024, 4))
+        for i, want in zip(wide, oracle_many(c, [(qs[i], 1, 10, False) for i in wide])):
+            assert want is not None
+            assert_same(base[i], want, ("pool", qs[i]))
         # ---- configs[3]: Levenshtein d <= 2 over the 1M-term BK-tree, batch 1024 ----
         toks = corpus.queries_fuzzy(terms, 1024, seed=4)
         ids = gidx.fuzzy(toks)
@@ -1616,6 +1640,14 @@ def test_full_size_c5_properties(nxs, monkeypatch):
         for tok, t in zip(toks[:8], ids[:8]):
             assert t == oidx.fuzzy(tok.encode())[0], tok
         oidx.close()
+        # ... and 64 more queries of the batch (every 128th from the 5th on: all shapes of the mix, fuzzy tokens resolved by
+        # the oracle's own BK-tree walk) on eight cores beside this process: tests/oracle_pool.py
+        wide = list(range(5, 8192, 128))
+        for i, want in zip(wide, oracle_many(c, [(qs[i], 1, k, True) for i in wide])):
+            if want is None:
+                assert isinstance(base[i], N.NxsError), qs[i]
+            else:
+                assert_same(base[i], want, ("pool", qs[i]))
         gidx.close()
     finally:
         shutil.rmtree(work, ignore_errors=True)
